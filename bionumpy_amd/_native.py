@@ -1,0 +1,96 @@
+"""ctypes binding of libbnpk.so (the C-ABI declared in include/bnpk.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import, and
+creating a context without a visible gfx950 device raises ``BnpkError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbnpk.so")
+
+NONE = (1 << 63) - 1          # BNPK_NONE
+
+
+class BnpkError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__("bnpk error %d: %s%s" % (status, _strerror(status), (" (%s)" % detail) if detail else ""))
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "bionumpy_amd: %s is missing. Build it with `python -m bionumpy_amd.csrc.build` "
+        "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+_u8 = C.c_uint8
+
+# name -> (restype, argtypes); must list every symbol of include/bnpk.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "bnpk_version": (_int, []),
+    "bnpk_strerror": (C.c_char_p, [_int]),
+    "bnpk_device_count": (_int, []),
+    "bnpk_ctx_create": (_int, [_int, C.POINTER(_p)]),
+    "bnpk_ctx_destroy": (None, [_p]),
+    "bnpk_last_hip_error": (C.c_char_p, [_p]),
+    "bnpk_device_info": (_int, [_p, C.c_char_p, C.POINTER(_int), C.POINTER(_i64)]),
+    "bnpk_prof_enable": (_int, [_p, _int]),
+    "bnpk_prof_reset": (_int, [_p]),
+    "bnpk_prof_count": (_int, [_p]),
+    "bnpk_prof_get": (_int, [_p, _int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "bnpk_host_alloc": (_int, [C.c_size_t, C.POINTER(_p)]),
+    "bnpk_host_free": (_int, [_p]),
+    "bnpk_copy_h2d_async": (_int, [_p, _p, C.c_size_t, _p]),
+    "bnpk_copy_d2h_async": (_int, [_p, _p, C.c_size_t, _p]),
+    "bnpk_stream_sync": (_int, [_p]),
+    "bnpk_scan_tiles": (_i64, [_i64]),
+    "bnpk_byte_census": (_int, [_p, _p, _i64, _u8, _p, _p]),
+    "bnpk_byte_positions": (_int, [_p, _p, _i64, _u8, _p, _i64, _p, _p]),
+    "bnpk_validate_entries": (_int, [_p, _p, _p, _i64, _int, _u8, _int, _p, _p]),
+    "bnpk_field_table": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
+    "bnpk_row_offsets": (_int, [_p, _p, _i64, _int, _p, _p]),
+    "bnpk_gather_encode_dna": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
+    "bnpk_gather_rows": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "bnpk_take_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "bnpk_encode_dna_flat": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
+    "bnpk_pack_codes": (_int, [_p, _p, _i64, _p, _p]),
+    "bnpk_unpack_codes": (_int, [_p, _p, _i64, _int, _p, _p]),
+    "bnpk_kmers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
+    "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
+    "bnpk_count_dense": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "bnpk_count_dense_rows": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "bnpk_sort_keys": (_int, [_p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
+    "bnpk_sort_pairs": (_int, [_p, _p, _p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
+    "bnpk_run_tiles": (_i64, [_i64]),
+    "bnpk_run_census": (_int, [_p, _p, _p, _i64, _p, C.POINTER(_i64), _p]),
+    "bnpk_run_heads": (_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p]),
+    "bnpk_run_sums": (_int, [_p, _p, _i64, _p, _p, _p]),
+    "bnpk_exclusive_scan_i64": (_int, [_p, _p, _i64, _p, _p]),
+    "bnpk_row_ids": (_int, [_p, _p, _i64, _i64, _p, _p]),
+    "bnpk_search_sorted": (_int, [_p, _p, _i64, _p, _i64, _int, _p, _p]),
+    "bnpk_fill_i64": (_int, [_p, _p, _i64, _i64, _p]),
+    "bnpk_synth_record_bytes": (_i64, [_int]),
+    "bnpk_synth_fastq": (_int, [_p, _p, _i64, _i64, _int, C.c_uint64, _int, _i64, _p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)          # AttributeError here == symbol missing from the build
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def _strerror(status):
+    return lib.bnpk_strerror(int(status)).decode()
+
+
+def check(status, ctx=None):
+    if status != 0:
+        detail = ""
+        if ctx is not None and status == -3:
+            detail = lib.bnpk_last_hip_error(ctx).decode()
+        raise BnpkError(status, detail)

@@ -1,0 +1,179 @@
+// Context, diagnostics, host staging and per-kernel timers of the bnpk C-ABI (include/bnpk.h).
+#include "common.h"
+
+extern "C" {
+
+int bnpk_version(void) { return 100; }
+
+const char* bnpk_strerror(int status) {
+  switch (status) {
+    case BNPK_OK: return "ok";
+    case BNPK_ERR_ARG: return "bad argument";
+    case BNPK_ERR_ALIGN: return "device byte buffer is not 16-byte aligned";
+    case BNPK_ERR_HIP: return "HIP runtime error";
+    case BNPK_ERR_NOMEM: return "out of device memory / workspace too small";
+    case BNPK_ERR_NODEVICE: return "no HIP device visible";
+    case BNPK_ERR_RANGE: return "size out of supported range";
+    default: return "unknown bnpk status";
+  }
+}
+
+int bnpk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int bnpk_ctx_create(int device, bnpk_ctx** out) {
+  if (!out) return BNPK_ERR_ARG;
+  int n = bnpk_device_count();
+  if (n <= 0 || device < 0 || device >= n) return BNPK_ERR_NODEVICE;
+  bnpk_ctx* ctx = new bnpk_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return BNPK_ERR_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->compute_units = prop.multiProcessorCount;
+  *out = ctx;
+  return BNPK_OK;
+}
+
+void bnpk_ctx_destroy(bnpk_ctx* ctx) {
+  if (!ctx) return;
+  for (auto& p : ctx->pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
+  for (auto e : ctx->event_pool) hipEventDestroy(e);
+  if (ctx->scratch) hipFree(ctx->scratch);
+  delete ctx;
+}
+
+const char* bnpk_last_hip_error(bnpk_ctx* ctx) {
+  return hipGetErrorString(ctx ? ctx->last_err : hipSuccess);
+}
+
+int bnpk_device_info(bnpk_ctx* ctx, char* name64, int* compute_units, int64_t* hbm_bytes) {
+  if (!ctx) return BNPK_ERR_ARG;
+  hipDeviceProp_t prop;
+  BNPK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (name64) {
+    // gcnArchName carries the ISA ("gfx950:sramecc+:xnack-"), name the marketing string
+    snprintf(name64, 64, "%s", prop.gcnArchName);
+  }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return BNPK_OK;
+}
+
+// ---- timers ---------------------------------------------------------------------------------
+int bnpk_prof_enable(bnpk_ctx* ctx, int on) {
+  if (!ctx) return BNPK_ERR_ARG;
+  ctx->prof = on != 0;
+  return BNPK_OK;
+}
+
+static int resolve_pending(bnpk_ctx* ctx) {
+  for (auto& p : ctx->pending) {
+    BNPK_HIP(ctx, hipEventSynchronize(p.stop));
+    float ms = 0.f;
+    BNPK_HIP(ctx, hipEventElapsedTime(&ms, p.start, p.stop));
+    ctx->entries[p.entry].total_ms += ms;
+    ctx->entries[p.entry].launches += 1;
+    ctx->event_pool.push_back(p.start);
+    ctx->event_pool.push_back(p.stop);
+  }
+  ctx->pending.clear();
+  return BNPK_OK;
+}
+
+int bnpk_prof_reset(bnpk_ctx* ctx) {
+  if (!ctx) return BNPK_ERR_ARG;
+  BNPK_CHECK(resolve_pending(ctx));
+  ctx->entries.clear();
+  return BNPK_OK;
+}
+
+int bnpk_prof_count(bnpk_ctx* ctx) {
+  if (!ctx) return BNPK_ERR_ARG;
+  int s = resolve_pending(ctx);
+  if (s != BNPK_OK) return s;
+  return (int)ctx->entries.size();
+}
+
+int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t* launches) {
+  if (!ctx || i < 0 || i >= (int)ctx->entries.size()) return BNPK_ERR_ARG;
+  const auto& e = ctx->entries[i];
+  if (name64) snprintf(name64, 64, "%s", e.name.c_str());
+  if (total_ms) *total_ms = e.total_ms;
+  if (launches) *launches = e.launches;
+  return BNPK_OK;
+}
+
+// ---- host staging -----------------------------------------------------------------------------
+int bnpk_host_alloc(size_t bytes, void** h_out) {
+  if (!h_out) return BNPK_ERR_ARG;
+  if (hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return BNPK_ERR_NOMEM;
+  return BNPK_OK;
+}
+
+int bnpk_host_free(void* h_ptr) {
+  if (h_ptr && hipHostFree(h_ptr) != hipSuccess) return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+int bnpk_copy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+  if (bytes == 0) return BNPK_OK;
+  if (!d_dst || !h_src) return BNPK_ERR_ARG;
+  if (hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+    return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
+  if (bytes == 0) return BNPK_OK;
+  if (!h_dst || !d_src) return BNPK_ERR_ARG;
+  if (hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
+    return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+int bnpk_stream_sync(void* stream) {
+  if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+}  // extern "C"
+
+// ---- internals ----------------------------------------------------------------------------------
+int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out) {
+  if (bytes > ctx->scratch_bytes) {
+    // grow-only; hipFree synchronises the device, so earlier users of the old arena are done
+    if (ctx->scratch) BNPK_HIP(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    size_t want = bytes + (bytes >> 2) + (1 << 20);
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) return BNPK_ERR_NOMEM;
+    ctx->scratch_bytes = want;
+  }
+  *out = ctx->scratch;
+  return BNPK_OK;
+}
+
+bnpk_timer::bnpk_timer(bnpk_ctx* c, const char* name, hipStream_t s) : ctx(c), stream(s) {
+  if (!ctx || !ctx->prof) return;
+  for (size_t i = 0; i < ctx->entries.size(); ++i)
+    if (ctx->entries[i].name == name) { entry = (int)i; break; }
+  if (entry < 0) {
+    ctx->entries.push_back(bnpk_prof_entry{name});
+    entry = (int)ctx->entries.size() - 1;
+  }
+  auto take = [&](hipEvent_t* e) {
+    if (!ctx->event_pool.empty()) { *e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return true; }
+    return hipEventCreate(e) == hipSuccess;
+  };
+  if (!take(&start) || !take(&stop)) { entry = -1; return; }
+  (void)hipEventRecord(start, stream);
+}
+
+bnpk_timer::~bnpk_timer() {
+  if (entry < 0) return;
+  (void)hipEventRecord(stop, stream);
+  ctx->pending.push_back(bnpk_pending_event{entry, start, stop});
+}

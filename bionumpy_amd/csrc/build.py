@@ -1,0 +1,88 @@
+"""Builds libbnpk.so (the C-ABI of include/bnpk.h) for gfx950 with hipcc, in-tree.
+
+    python -m bionumpy_amd.csrc.build [--force]
+
+hipcc cross-compiles without a GPU; one object per .hip file so that an edit rebuilds one file.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libbnpk.so")
+OBJ_DIR = os.path.join(HERE, "build")
+SOURCES = ["api.hip", "scan.hip", "decode.hip", "encode.hip", "kmers.hip", "count.hip", "synth.hip"]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"),
+           os.path.join(ROOT, "include", "bnpk.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(hipcc, src):
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    path = os.path.join(HERE, src)
+    if _stale(obj, [path] + HEADERS):
+        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+    return obj
+
+
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(HERE, s) for s in SOURCES] + HEADERS:
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    # content hash, not mtimes: the snapshot shipped to the GPU box does not keep mtimes
+    stamp = LIB + ".sha256"
+    digest = _source_hash()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        if verbose:
+            print("up to date", LIB)
+        return LIB
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(hipcc, s), SOURCES))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,134 @@
+// Internal helpers shared by the gfx950 kernels: ctx, scratch arena, launch timers, block scans.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bnpk.h"
+
+#define BNPK_WAVE 64
+#define BNPK_BLOCK 256
+
+struct bnpk_prof_entry {
+  std::string name;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct bnpk_pending_event {
+  int entry;
+  hipEvent_t start, stop;
+};
+
+struct bnpk_ctx {
+  int device = 0;
+  int compute_units = 256;
+  void* scratch = nullptr;       // grow-only device arena for scan partials and small temporaries
+  size_t scratch_bytes = 0;
+  bool prof = false;
+  std::vector<bnpk_prof_entry> entries;
+  std::vector<bnpk_pending_event> pending;
+  std::vector<hipEvent_t> event_pool;
+  hipError_t last_err = hipSuccess;
+};
+
+#define BNPK_HIP(ctx, call)                          \
+  do {                                               \
+    hipError_t e__ = (call);                         \
+    if (e__ != hipSuccess) {                         \
+      if (ctx) (ctx)->last_err = e__;                \
+      return BNPK_ERR_HIP;                           \
+    }                                                \
+  } while (0)
+
+#define BNPK_CHECK(expr)                 \
+  do {                                   \
+    int s__ = (expr);                    \
+    if (s__ != BNPK_OK) return s__;      \
+  } while (0)
+
+// Scratch arena: returns a device pointer to at least `bytes` bytes (valid until the next call that
+// grows it; every entry point carves what it needs up front, so a single request per call).
+int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out);
+
+// RAII hipEvent timer around a launch (or a group of launches) when profiling is enabled.
+struct bnpk_timer {
+  bnpk_ctx* ctx;
+  hipStream_t stream;
+  int entry = -1;
+  hipEvent_t start = nullptr, stop = nullptr;
+  bnpk_timer(bnpk_ctx* c, const char* name, hipStream_t s);
+  ~bnpk_timer();
+};
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// grid size for a grid-stride style launch over `work_items` blocks' worth of work
+static inline unsigned grid_for(int64_t blocks) {
+  if (blocks < 1) blocks = 1;
+  return (unsigned)(blocks > 0x7fffffffLL ? 0x7fffffffLL : blocks);
+}
+
+// ------------------------------------------------------------------------------------------ device
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// inclusive scan over the 64 lanes of a wavefront
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d, 64);
+    if (lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan across a 256-thread block (4 wavefronts). `smem` needs 5 T's. Returns the
+// exclusive prefix of this thread and writes the block total to *total.
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* smem, T* total) {
+  T inc = wave_inclusive_scan(v);
+  if (lane_id() == 63) smem[wave_id()] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T run = 0;
+#pragma unroll
+    for (int w = 0; w < BNPK_BLOCK / 64; ++w) {
+      T t = smem[w];
+      smem[w] = run;
+      run += t;
+    }
+    smem[BNPK_BLOCK / 64] = run;
+  }
+  __syncthreads();
+  T base = smem[wave_id()];
+  *total = smem[BNPK_BLOCK / 64];
+  __syncthreads();
+  return base + inc - v;
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;
+}
+
+// largest r in [lo, hi] with offsets[r] <= pos (offsets non-decreasing, offsets[lo] <= pos).
+// With runs of equal offsets (empty rows) this returns the LAST such r, i.e. the non-empty row
+// that actually contains pos.
+__device__ __forceinline__ int64_t find_row(const int64_t* __restrict__ offsets, int64_t lo,
+                                            int64_t hi, int64_t pos) {
+  while (lo < hi) {
+    int64_t mid = lo + ((hi - lo + 1) >> 1);
+    if (offsets[mid] <= pos) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,292 @@
+// Counting (A9): dense LDS/global-atomic histograms for small k, sort + run-length for k up to 31,
+// plus the sorted-search used by the k-mer index (A12).
+#include "common.h"
+#include "scan.h"
+
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+namespace {
+
+// ------------------------------------------------------------------------------------ dense histogram
+constexpr int LDS_MAX_BINS = 16384;     // 64 KiB of int32 bins per workgroup (k <= 7)
+
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_lds_kernel(const int64_t* __restrict__ v, int64_t n,
+                                                              int n_bins, int64_t per_block,
+                                                              unsigned long long* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int bins[];
+  for (int i = threadIdx.x; i < n_bins; i += BNPK_BLOCK) bins[i] = 0;
+  __syncthreads();
+  int64_t begin = (int64_t)blockIdx.x * per_block;          // per_block is a multiple of 2
+  int64_t end = min(begin + per_block, n);
+  for (int64_t i = begin + 2 * (int64_t)threadIdx.x; i < end; i += 2 * BNPK_BLOCK) {
+    int64_t a, b = -1;
+    if (i + 1 < end) {
+      longlong2 p = *reinterpret_cast<const longlong2*>(v + i);
+      a = p.x; b = p.y;
+    } else {
+      a = v[i];
+    }
+    if ((uint64_t)a < (uint64_t)n_bins) atomicAdd(&bins[a], 1u);
+    if ((uint64_t)b < (uint64_t)n_bins) atomicAdd(&bins[b], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bins; i += BNPK_BLOCK) {
+    unsigned int c = bins[i];
+    if (c) atomicAdd(&hist[i], (unsigned long long)c);
+  }
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_global_kernel(const int64_t* __restrict__ v, int64_t n,
+                                                                 int64_t n_bins,
+                                                                 unsigned long long* __restrict__ hist) {
+  int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  for (; i < n; i += stride) {
+    int64_t a = v[i];
+    if ((uint64_t)a < (uint64_t)n_bins) atomicAdd(&hist[a], 1ull);
+  }
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_rows_kernel(const int64_t* __restrict__ v,
+                                                               const int64_t* __restrict__ off, int64_t n_rows,
+                                                               int64_t n, int64_t n_bins,
+                                                               unsigned long long* __restrict__ hist) {
+  int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  int64_t row = find_row(off, 0, n_rows - 1, i);
+  int64_t a = v[i];
+  if ((uint64_t)a < (uint64_t)n_bins) atomicAdd(&hist[row * n_bins + a], 1ull);
+}
+
+// ------------------------------------------------------------------------------------ runs of equal keys
+constexpr int RUN_ITEMS = 8;
+constexpr int RUN_TILE = BNPK_BLOCK * RUN_ITEMS;
+
+__device__ __forceinline__ bool is_head(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t i) {
+  if (i == 0) return true;
+  if (a[i] != a[i - 1]) return true;
+  return b != nullptr && b[i] != b[i - 1];
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void run_census_kernel(const int64_t* __restrict__ a,
+                                                                const int64_t* __restrict__ b, int64_t n,
+                                                                int64_t* __restrict__ tile_counts) {
+  __shared__ int smem[BNPK_BLOCK / 64];
+  int64_t base = (int64_t)blockIdx.x * RUN_TILE + (int64_t)threadIdx.x * RUN_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < RUN_ITEMS; ++j) {
+    int64_t i = base + j;
+    if (i < n && is_head(a, b, i)) ++c;
+  }
+  c = wave_reduce_sum(c);
+  if (lane_id() == 0) smem[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < BNPK_BLOCK / 64; ++w) t += smem[w];
+    tile_counts[blockIdx.x] = t;
+  }
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void run_heads_kernel(const int64_t* __restrict__ a,
+                                                               const int64_t* __restrict__ b, int64_t n,
+                                                               const int64_t* __restrict__ tile_offsets,
+                                                               int64_t n_runs, int64_t* __restrict__ keys_out,
+                                                               int64_t* __restrict__ second_out,
+                                                               int64_t* __restrict__ run_starts) {
+  __shared__ int smem[BNPK_BLOCK / 64 + 1];
+  int64_t base = (int64_t)blockIdx.x * RUN_TILE + (int64_t)threadIdx.x * RUN_ITEMS;
+  unsigned flags = 0;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < RUN_ITEMS; ++j) {
+    int64_t i = base + j;
+    if (i < n && is_head(a, b, i)) { flags |= 1u << j; ++c; }
+  }
+  int total;
+  int ex = block_exclusive_scan(c, smem, &total);
+  int64_t r = tile_offsets[blockIdx.x] + ex;
+#pragma unroll
+  for (int j = 0; j < RUN_ITEMS; ++j) {
+    if (flags & (1u << j)) {
+      int64_t i = base + j;
+      keys_out[r] = a[i];
+      if (second_out) second_out[r] = b[i];
+      run_starts[r] = i;
+      ++r;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) run_starts[n_runs] = n;
+}
+
+__global__ void run_sums_kernel(const int64_t* __restrict__ run_starts, int64_t n_runs,
+                                const int64_t* __restrict__ prefix, int64_t* __restrict__ counts) {
+  int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_runs) return;
+  int64_t s = run_starts[j], e = run_starts[j + 1];
+  counts[j] = prefix ? prefix[e] - prefix[s] : e - s;
+}
+
+__global__ void search_sorted_kernel(const int64_t* __restrict__ sorted, int64_t n, const int64_t* __restrict__ q,
+                                     int64_t m, int upper, int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int64_t key = q[i];
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    int64_t v = sorted[mid];
+    bool right = upper ? (v <= key) : (v < key);
+    if (right) lo = mid + 1; else hi = mid;
+  }
+  out[i] = lo;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnpk_count_dense(bnpk_ctx* ctx, const int64_t* d_values, int64_t n, int64_t n_bins, int64_t* d_hist,
+                     void* stream) {
+  if (!ctx || n < 0 || n_bins < 1 || !d_hist) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_values) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_values & 15) != 0) return BNPK_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  auto* hist = reinterpret_cast<unsigned long long*>(d_hist);
+  if (n_bins <= LDS_MAX_BINS) {
+    // enough workgroups to fill 256 CUs a few times over, each streaming a contiguous slab
+    int64_t blocks = std::min<int64_t>(ceil_div(n, 4 * 2 * BNPK_BLOCK), (int64_t)ctx->compute_units * 8);
+    int64_t per_block = ceil_div(ceil_div(n, blocks), 2) * 2;
+    while (per_block >= 0x7fffffffLL) { blocks *= 2; per_block = ceil_div(ceil_div(n, blocks), 2) * 2; }
+    blocks = ceil_div(n, per_block);
+    bnpk_timer t(ctx, "count_dense_lds", s);
+    hipLaunchKernelGGL(hist_lds_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), (size_t)n_bins * sizeof(unsigned),
+                       s, d_values, n, (int)n_bins, per_block, hist);
+  } else {
+    int64_t blocks = std::min<int64_t>(ceil_div(n, BNPK_BLOCK), (int64_t)ctx->compute_units * 16);
+    bnpk_timer t(ctx, "count_dense_global", s);
+    hipLaunchKernelGGL(hist_global_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_values, n, n_bins, hist);
+  }
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t* d_offsets, int64_t n_rows,
+                          int64_t n, int64_t n_bins, int64_t* d_hist, void* stream) {
+  if (!ctx || n < 0 || n_rows < 0 || n_bins < 1) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_values || !d_offsets || !d_hist || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n, BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "count_dense_rows", s);
+  hipLaunchKernelGGL(hist_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_values, d_offsets, n_rows, n,
+                     n_bins, reinterpret_cast<unsigned long long*>(d_hist));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int key_bits, int* h_in_alt,
+                   void* stream) {
+  if (!ctx || n < 0 || key_bits < 1 || key_bits > 64 || !h_in_alt) return BNPK_ERR_ARG;
+  *h_in_alt = 0;
+  if (n <= 1) return BNPK_OK;
+  if (!d_keys || !d_alt) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  rocprim::double_buffer<uint64_t> keys(reinterpret_cast<uint64_t*>(d_keys), reinterpret_cast<uint64_t*>(d_alt));
+  size_t temp_bytes = 0;
+  BNPK_HIP(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, keys, (size_t)n, 0u, (unsigned)key_bits, s));
+  void* temp = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp));
+  bnpk_timer t(ctx, "sort_keys", s);
+  BNPK_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, keys, (size_t)n, 0u, (unsigned)key_bits, s));
+  *h_in_alt = (keys.current() == reinterpret_cast<uint64_t*>(d_alt)) ? 1 : 0;
+  return BNPK_OK;
+}
+
+int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t* d_vals, int64_t* d_vals_alt,
+                    int64_t n, int key_bits, int* h_in_alt, void* stream) {
+  if (!ctx || n < 0 || key_bits < 1 || key_bits > 64 || !h_in_alt) return BNPK_ERR_ARG;
+  *h_in_alt = 0;
+  if (n <= 1) return BNPK_OK;
+  if (!d_keys || !d_keys_alt || !d_vals || !d_vals_alt) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  rocprim::double_buffer<uint64_t> keys(reinterpret_cast<uint64_t*>(d_keys), reinterpret_cast<uint64_t*>(d_keys_alt));
+  rocprim::double_buffer<int64_t> vals(d_vals, d_vals_alt);
+  size_t temp_bytes = 0;
+  BNPK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, vals, (size_t)n, 0u, (unsigned)key_bits, s));
+  void* temp = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp));
+  bnpk_timer t(ctx, "sort_pairs", s);
+  BNPK_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, vals, (size_t)n, 0u, (unsigned)key_bits, s));
+  *h_in_alt = (keys.current() == reinterpret_cast<uint64_t*>(d_keys_alt)) ? 1 : 0;
+  return BNPK_OK;
+}
+
+int64_t bnpk_run_tiles(int64_t n) { return n <= 0 ? 0 : ceil_div(n, RUN_TILE); }
+
+int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,
+                    int64_t* d_tile_offsets, int64_t* h_n_runs, void* stream) {
+  if (!ctx || n < 0 || !d_tile_offsets || !h_n_runs || (n > 0 && !d_sorted)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t tiles = bnpk_run_tiles(n);
+  if (tiles > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
+  {
+    bnpk_timer t(ctx, "run_census", s);
+    if (tiles > 0)
+      hipLaunchKernelGGL(run_census_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_sorted, d_second, n,
+                         d_tile_offsets);
+    BNPK_HIP(ctx, hipGetLastError());
+    BNPK_CHECK(bnpk_scan_launch(ctx, d_tile_offsets, tiles, 1, d_tile_offsets, true, (int64_t*)scratch, s));
+  }
+  BNPK_HIP(ctx, hipMemcpyAsync(h_n_runs, d_tile_offsets + tiles, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  return BNPK_OK;
+}
+
+int bnpk_run_heads(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,
+                   const int64_t* d_tile_offsets, int64_t n_runs, int64_t* d_keys_out, int64_t* d_second_out,
+                   int64_t* d_run_starts, void* stream) {
+  if (!ctx || n < 0 || n_runs < 0 || !d_run_starts) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return bnpk_fill_i64(ctx, d_run_starts, 1, 0, stream);
+  if (!d_sorted || !d_tile_offsets || !d_keys_out || (d_second_out && !d_second)) return BNPK_ERR_ARG;
+  bnpk_timer t(ctx, "run_heads", s);
+  hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)bnpk_run_tiles(n)), dim3(BNPK_BLOCK), 0, s, d_sorted, d_second, n,
+                     d_tile_offsets, n_runs, d_keys_out, d_second_out, d_run_starts);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_run_sums(bnpk_ctx* ctx, const int64_t* d_run_starts, int64_t n_runs, const int64_t* d_weight_prefix,
+                  int64_t* d_counts, void* stream) {
+  if (!ctx || n_runs < 0) return BNPK_ERR_ARG;
+  if (n_runs == 0) return BNPK_OK;
+  if (!d_run_starts || !d_counts) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "run_sums", s);
+  hipLaunchKernelGGL(run_sums_kernel, dim3(grid_for(ceil_div(n_runs, 256))), dim3(256), 0, s, d_run_starts, n_runs,
+                     d_weight_prefix, d_counts);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_search_sorted(bnpk_ctx* ctx, const int64_t* d_sorted, int64_t n, const int64_t* d_queries, int64_t m,
+                       int upper, int64_t* d_out, void* stream) {
+  if (!ctx || n < 0 || m < 0) return BNPK_ERR_ARG;
+  if (m == 0) return BNPK_OK;
+  if (!d_queries || !d_out || (n > 0 && !d_sorted)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "search_sorted", s);
+  hipLaunchKernelGGL(search_sorted_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_sorted, n, d_queries, m,
+                     upper, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,292 @@
+// Ragged gather fused with ASCII -> 2-bit DNA encode (A6 + A7) for gfx950.
+// Output-flat mapping: one lane produces one packed uint64 (32 bases) so that a wavefront stores
+// 512 contiguous bytes of packed words (and 2 KiB of 1-byte codes); the lane walks the source rows
+// it overlaps, finding its first row by a binary search narrowed to the rows the workgroup touches.
+#include "common.h"
+
+namespace {
+
+constexpr int BASES_PER_WORD = 32;
+
+__device__ __forceinline__ uint32_t dna_code(uint32_t b, bool* ok) {
+  uint32_t u = b & 0xDFu;                      // fold lower case onto upper case (exact for A C G T)
+  *ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T');
+  return ((u >> 1) & 3u) ^ ((u >> 2) & 1u);    // A C G T -> 0 1 2 3
+}
+
+// rows overlapped by the workgroup's flat range [first, last] -> smem[0..1]
+__device__ __forceinline__ void block_row_range(const int64_t* __restrict__ offsets, int64_t n_rows,
+                                                int64_t first, int64_t last, int64_t* smem) {
+  if (threadIdx.x == 0) smem[0] = find_row(offsets, 0, n_rows - 1, first);
+  if (threadIdx.x == 64) smem[1] = find_row(offsets, 0, n_rows - 1, last);
+  __syncthreads();
+}
+
+template <bool WRITE_CODES, bool WRITE_PACKED>
+__global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
+    const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
+    int64_t n_rows, int64_t total, uint8_t* __restrict__ codes, uint64_t* __restrict__ packed,
+    unsigned long long* __restrict__ err) {
+  __shared__ int64_t rr[2];
+  int64_t n_words = (total + BASES_PER_WORD - 1) / BASES_PER_WORD;
+  int64_t w0 = (int64_t)blockIdx.x * BNPK_BLOCK;
+  int64_t w = w0 + threadIdx.x;
+  if (w0 >= n_words) {                          // pad word(s) read by the k-mer kernel
+    if (WRITE_PACKED && w <= n_words) packed[w] = 0;
+    return;
+  }
+  int64_t blk_first = w0 * BASES_PER_WORD;
+  int64_t blk_last = min(blk_first + (int64_t)BNPK_BLOCK * BASES_PER_WORD, total) - 1;
+  block_row_range(offsets, n_rows, blk_first, blk_last, rr);
+  if (w >= n_words) {
+    if (WRITE_PACKED && w == n_words) packed[w] = 0;
+    return;
+  }
+  int64_t pos = w * BASES_PER_WORD;
+  int64_t end = min(pos + BASES_PER_WORD, total);
+  int64_t row = find_row(offsets, rr[0], rr[1], pos);
+  int64_t row_end = offsets[row + 1];
+  const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
+  uint64_t word = 0;
+  uint64_t cw[4] = {0, 0, 0, 0};
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+  for (int j = 0; pos < end; ++j, ++pos) {
+    while (pos >= row_end) {                    // next non-empty row
+      ++row;
+      row_end = offsets[row + 1];
+      src = buf + starts[row];
+    }
+    bool ok;
+    uint32_t c = dna_code(*src++, &ok);
+    if (!ok) { c = 0; if ((unsigned long long)pos < bad) bad = (unsigned long long)pos; }
+    word |= (uint64_t)c << (2 * j);
+    if (WRITE_CODES) cw[j >> 3] |= (uint64_t)c << (8 * (j & 7));
+  }
+  if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
+  if (WRITE_PACKED) packed[w] = word;
+  if (WRITE_CODES) {
+    int64_t p0 = w * BASES_PER_WORD;
+    if (p0 + BASES_PER_WORD <= total) {
+      uint4* dst = reinterpret_cast<uint4*>(codes + p0);
+      dst[0] = make_uint4((uint32_t)cw[0], (uint32_t)(cw[0] >> 32), (uint32_t)cw[1], (uint32_t)(cw[1] >> 32));
+      dst[1] = make_uint4((uint32_t)cw[2], (uint32_t)(cw[2] >> 32), (uint32_t)cw[3], (uint32_t)(cw[3] >> 32));
+    } else {
+      for (int j = 0; p0 + j < total; ++j) codes[p0 + j] = (uint8_t)(cw[j >> 3] >> (8 * (j & 7)));
+    }
+  }
+}
+
+// plain gather, 16 output bytes per lane
+__global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
+    const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
+    int64_t n_rows, int64_t total, int subtract, uint8_t* __restrict__ out) {
+  __shared__ int64_t rr[2];
+  constexpr int PER = 16;
+  int64_t blk_first = (int64_t)blockIdx.x * BNPK_BLOCK * PER;
+  if (blk_first >= total) return;
+  int64_t blk_last = min(blk_first + (int64_t)BNPK_BLOCK * PER, total) - 1;
+  block_row_range(offsets, n_rows, blk_first, blk_last, rr);
+  int64_t pos = blk_first + (int64_t)threadIdx.x * PER;
+  if (pos >= total) return;
+  int64_t end = min(pos + PER, total);
+  int64_t row = find_row(offsets, rr[0], rr[1], pos);
+  int64_t row_end = offsets[row + 1];
+  const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
+  uint64_t lo = 0, hi = 0;
+  int64_t p0 = pos;
+  for (int j = 0; pos < end; ++j, ++pos) {
+    while (pos >= row_end) {
+      ++row;
+      row_end = offsets[row + 1];
+      src = buf + starts[row];
+    }
+    uint64_t b = (uint8_t)(*src++ - subtract);
+    if (j < 8) lo |= b << (8 * j); else hi |= b << (8 * (j - 8));
+  }
+  if (p0 + PER <= total && (((uintptr_t)(out + p0)) & 15) == 0) {
+    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  } else {
+    for (int j = 0; p0 + j < total; ++j) out[p0 + j] = (uint8_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))));
+  }
+}
+
+__device__ __forceinline__ void load32(const uint8_t* __restrict__ p, int64_t pos, int64_t n, uint64_t v[4]) {
+  if (pos + 32 <= n && (((uintptr_t)(p + pos)) & 15) == 0) {
+    const uint4* q = reinterpret_cast<const uint4*>(p + pos);
+    uint4 a = q[0], b = q[1];
+    v[0] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    v[1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+    v[2] = (uint64_t)b.x | ((uint64_t)b.y << 32);
+    v[3] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+  } else {
+    v[0] = v[1] = v[2] = v[3] = 0;
+    for (int j = 0; j < 32 && pos + j < n; ++j) v[j >> 3] |= (uint64_t)p[pos + j] << (8 * (j & 7));
+  }
+}
+
+__device__ __forceinline__ void store32(uint8_t* __restrict__ p, int64_t pos, int64_t n, const uint64_t v[4]) {
+  if (pos + 32 <= n && (((uintptr_t)(p + pos)) & 15) == 0) {
+    uint4* q = reinterpret_cast<uint4*>(p + pos);
+    q[0] = make_uint4((uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
+    q[1] = make_uint4((uint32_t)v[2], (uint32_t)(v[2] >> 32), (uint32_t)v[3], (uint32_t)(v[3] >> 32));
+  } else {
+    for (int j = 0; j < 32 && pos + j < n; ++j) p[pos + j] = (uint8_t)(v[j >> 3] >> (8 * (j & 7)));
+  }
+}
+
+// mode 0: ASCII -> codes (+packed, validated); mode 1: codes -> packed
+template <int MODE>
+__global__ __launch_bounds__(BNPK_BLOCK) void flat_encode_kernel(const uint8_t* __restrict__ in, int64_t n,
+                                                                 uint8_t* __restrict__ codes,
+                                                                 uint64_t* __restrict__ packed,
+                                                                 unsigned long long* __restrict__ err) {
+  int64_t n_words = (n + 31) / 32;
+  int64_t w = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
+  if (w > n_words) return;
+  if (w == n_words) { if (packed) packed[w] = 0; return; }
+  int64_t pos = w * 32;
+  uint64_t v[4], cw[4] = {0, 0, 0, 0};
+  load32(in, pos, n, v);
+  uint64_t word = 0;
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+  int cnt = (int)min((int64_t)32, n - pos);
+  for (int j = 0; j < cnt; ++j) {
+    uint32_t b = (uint32_t)(v[j >> 3] >> (8 * (j & 7))) & 0xff;
+    uint32_t c;
+    if (MODE == 0) {
+      bool ok;
+      c = dna_code(b, &ok);
+      if (!ok) { c = 0; if ((unsigned long long)(pos + j) < bad) bad = (unsigned long long)(pos + j); }
+      cw[j >> 3] |= (uint64_t)c << (8 * (j & 7));
+    } else {
+      c = b & 3u;
+    }
+    word |= (uint64_t)c << (2 * j);
+  }
+  if (MODE == 0) {
+    if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
+    if (codes) store32(codes, pos, n, cw);
+  }
+  if (packed) packed[w] = word;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void unpack_kernel(const uint64_t* __restrict__ packed, int64_t n,
+                                                            int to_ascii, uint8_t* __restrict__ out) {
+  int64_t w = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
+  int64_t pos = w * 32;
+  if (pos >= n) return;
+  uint64_t word = packed[w];
+  uint64_t v[4] = {0, 0, 0, 0};
+  const uint32_t alphabet = 0x54474341u;   // 'A','C','G','T' little-endian
+  for (int j = 0; j < 32; ++j) {
+    uint32_t c = (uint32_t)(word >> (2 * j)) & 3u;
+    if (to_ascii) c = (alphabet >> (8 * c)) & 0xff;
+    v[j >> 3] |= (uint64_t)c << (8 * (j & 7));
+  }
+  store32(out, pos, n, v);
+}
+
+__global__ void take_bytes_kernel(const uint8_t* __restrict__ buf, const int64_t* __restrict__ pos, int64_t m,
+                                  int64_t delta, uint8_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = buf[pos[i] + delta];
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnpk_take_bytes(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_pos, int64_t m, int64_t delta,
+                    uint8_t* d_out, void* stream) {
+  if (!ctx || m < 0) return BNPK_ERR_ARG;
+  if (m == 0) return BNPK_OK;
+  if (!d_buf || !d_pos || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "take_bytes", s);
+  hipLaunchKernelGGL(take_bytes_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_buf, d_pos, m, delta, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
+                           const int64_t* d_offsets, int64_t n_rows, int64_t total, uint8_t* d_codes,
+                           uint64_t* d_packed, int64_t* d_err_offset, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || !d_err_offset) return BNPK_ERR_ARG;
+  if (!d_codes && !d_packed) return BNPK_ERR_ARG;
+  if (total > 0 && (!d_buf || !d_starts || !d_offsets || n_rows == 0)) return BNPK_ERR_ARG;
+  if (d_codes && ((uintptr_t)d_codes & 15)) return BNPK_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t n_words = (total + 31) / 32;
+  int64_t blocks = ceil_div(n_words + 1, BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  auto* err = reinterpret_cast<unsigned long long*>(d_err_offset);
+  bnpk_timer t(ctx, "gather_encode_dna", s);
+  dim3 g((unsigned)blocks), b(BNPK_BLOCK);
+  if (d_codes && d_packed)
+    hipLaunchKernelGGL((gather_encode_kernel<true, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
+                       d_codes, d_packed, err);
+  else if (d_packed)
+    hipLaunchKernelGGL((gather_encode_kernel<false, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
+                       d_codes, d_packed, err);
+  else
+    hipLaunchKernelGGL((gather_encode_kernel<true, false>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
+                       d_codes, d_packed, err);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts, const int64_t* d_offsets,
+                     int64_t n_rows, int64_t total, int subtract, uint8_t* d_out, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0) return BNPK_ERR_ARG;
+  if (total == 0) return BNPK_OK;
+  if (!d_buf || !d_starts || !d_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = ceil_div(total, (int64_t)BNPK_BLOCK * 16);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  bnpk_timer t(ctx, "gather_rows", s);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_buf, d_starts, d_offsets,
+                     n_rows, total, subtract, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_encode_dna_flat(bnpk_ctx* ctx, const uint8_t* d_ascii, int64_t n, uint8_t* d_codes, uint64_t* d_packed,
+                         int64_t* d_err_offset, void* stream) {
+  if (!ctx || n < 0 || !d_err_offset || (!d_codes && !d_packed) || (n > 0 && !d_ascii)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = ceil_div((n + 31) / 32 + 1, BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  bnpk_timer t(ctx, "encode_dna_flat", s);
+  hipLaunchKernelGGL((flat_encode_kernel<0>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_ascii, n, d_codes,
+                     d_packed, reinterpret_cast<unsigned long long*>(d_err_offset));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_pack_codes(bnpk_ctx* ctx, const uint8_t* d_codes, int64_t n, uint64_t* d_packed, void* stream) {
+  if (!ctx || n < 0 || !d_packed || (n > 0 && !d_codes)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = ceil_div((n + 31) / 32 + 1, BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  bnpk_timer t(ctx, "pack_codes", s);
+  hipLaunchKernelGGL((flat_encode_kernel<1>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, n,
+                     (uint8_t*)nullptr, d_packed, (unsigned long long*)nullptr);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_unpack_codes(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n, int to_ascii, uint8_t* d_out,
+                      void* stream) {
+  if (!ctx || n < 0) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_packed || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = ceil_div((n + 31) / 32, BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  bnpk_timer t(ctx, "unpack_codes", s);
+  hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, n, to_ascii, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,178 @@
+// 2-bit k-mer hashes (A8), minimizers (A11) and ragged row ids for gfx950.
+// Integer / HBM-write bound: 8 output bytes per k-mer against 0.25 input bytes per base.  Output-flat
+// mapping: every lane produces two adjacent int64 (one 16-byte store, 1 KiB contiguous per wavefront
+// instruction); the packed input words are shared between neighbouring lanes through L1.
+#include "common.h"
+
+namespace {
+
+constexpr int PAIRS = 2;                               // 16-byte stores per lane
+constexpr int TILE_OUT = BNPK_BLOCK * 2 * PAIRS;       // 1024 outputs (8 KiB) per workgroup
+
+struct row_cursor {
+  int64_t row, out_end, in_pos;
+};
+
+__device__ __forceinline__ row_cursor seek_row(const int64_t* __restrict__ in_off,
+                                               const int64_t* __restrict__ out_off, int64_t rlo, int64_t rhi,
+                                               int64_t o) {
+  row_cursor c;
+  c.row = find_row(out_off, rlo, rhi, o);
+  c.out_end = out_off[c.row + 1];
+  c.in_pos = in_off[c.row] + (o - out_off[c.row]);
+  return c;
+}
+
+// advance the cursor from output o-1 to output o
+__device__ __forceinline__ void next_output(row_cursor& c, const int64_t* __restrict__ in_off,
+                                            const int64_t* __restrict__ out_off, int64_t o) {
+  if (o < c.out_end) { c.in_pos += 1; return; }
+  do {
+    ++c.row;
+    c.out_end = out_off[c.row + 1];
+  } while (o >= c.out_end);
+  c.in_pos = in_off[c.row];
+}
+
+struct word_window {
+  int64_t wi = -2;
+  uint64_t lo = 0, hi = 0;
+};
+
+// the 64 bits starting at base `pos` of the packed stream
+__device__ __forceinline__ uint64_t bits_at(const uint64_t* __restrict__ W, int64_t pos, word_window& ww) {
+  int64_t wi = pos >> 5;
+  if (wi != ww.wi) {
+    if (wi == ww.wi + 1) { ww.lo = ww.hi; ww.hi = W[wi + 1]; }
+    else { ww.lo = W[wi]; ww.hi = W[wi + 1]; }
+    ww.wi = wi;
+  }
+  int sh = 2 * (int)(pos & 31);
+  return sh ? (ww.lo >> sh) | (ww.hi << (64 - sh)) : ww.lo;
+}
+
+__device__ __forceinline__ void block_rows(const int64_t* __restrict__ out_off, int64_t n_rows, int64_t first,
+                                           int64_t last, int64_t* smem) {
+  if (threadIdx.x == 0) smem[0] = find_row(out_off, 0, n_rows - 1, first);
+  if (threadIdx.x == 64) smem[1] = find_row(out_off, 0, n_rows - 1, last);
+  __syncthreads();
+}
+
+__device__ __forceinline__ void store_pair(int64_t* __restrict__ out, int64_t o, int64_t n_out, int64_t a,
+                                           int64_t b) {
+  if (o + 1 < n_out && (((uintptr_t)(out + o)) & 15) == 0) {
+    *reinterpret_cast<longlong2*>(out + o) = make_longlong2(a, b);
+  } else {
+    out[o] = a;
+    if (o + 1 < n_out) out[o + 1] = b;
+  }
+}
+
+// MINIMIZER=false: hash of the k-mer starting at each position.
+// MINIMIZER=true : min over the n_kmers = window-k+1 k-mer hashes of each window.
+template <bool MINIMIZER>
+__global__ __launch_bounds__(BNPK_BLOCK) void kmer_kernel(const uint64_t* __restrict__ W,
+                                                          const int64_t* __restrict__ in_off,
+                                                          const int64_t* __restrict__ out_off, int64_t n_rows,
+                                                          int64_t n_out, int k, int n_kmers,
+                                                          int64_t* __restrict__ out) {
+  __shared__ int64_t rr[2];
+  int64_t tile = (int64_t)blockIdx.x * TILE_OUT;
+  if (tile >= n_out) return;
+  block_rows(out_off, n_rows, tile, min(tile + TILE_OUT, n_out) - 1, rr);
+  const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    int64_t o = tile + (int64_t)p * (BNPK_BLOCK * 2) + 2 * threadIdx.x;
+    if (o >= n_out) break;
+    row_cursor c = seek_row(in_off, out_off, rr[0], rr[1], o);
+    word_window ww;
+    int64_t v[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int64_t oo = o + q;
+      if (oo >= n_out) break;
+      if (q) next_output(c, in_off, out_off, oo);
+      if (!MINIMIZER) {
+        v[q] = (int64_t)(bits_at(W, c.in_pos, ww) & mask);
+      } else {
+        uint64_t m = ~0ull;
+        for (int j = 0; j < n_kmers; ++j) {
+          uint64_t h = bits_at(W, c.in_pos + j, ww) & mask;
+          m = h < m ? h : m;
+        }
+        v[q] = (int64_t)m;
+        ww.wi = -2;   // the next output starts one base later: re-seek the window
+      }
+    }
+    store_pair(out, o, n_out, v[0], v[1]);
+  }
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void row_ids_kernel(const int64_t* __restrict__ off, int64_t n_rows,
+                                                             int64_t n, int64_t* __restrict__ rows) {
+  __shared__ int64_t rr[2];
+  int64_t tile = (int64_t)blockIdx.x * TILE_OUT;
+  if (tile >= n) return;
+  block_rows(off, n_rows, tile, min(tile + TILE_OUT, n) - 1, rr);
+#pragma unroll
+  for (int p = 0; p < PAIRS; ++p) {
+    int64_t o = tile + (int64_t)p * (BNPK_BLOCK * 2) + 2 * threadIdx.x;
+    if (o >= n) break;
+    int64_t r0 = find_row(off, rr[0], rr[1], o);
+    int64_t r1 = r0;
+    if (o + 1 < n) { while (o + 1 >= off[r1 + 1]) ++r1; }
+    store_pair(rows, o, n, r0, r1);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
+               int64_t n_rows, int64_t n_out, int k, int64_t* d_hashes, void* stream) {
+  if (!ctx || k < 1 || k > 31 || n_rows < 0 || n_out < 0) return BNPK_ERR_ARG;
+  if (n_out == 0) return BNPK_OK;
+  if (!d_packed || !d_in_offsets || !d_out_offsets || !d_hashes || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n_out, TILE_OUT);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "kmers", s);
+  hipLaunchKernelGGL((kmer_kernel<false>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
+                     d_out_offsets, n_rows, n_out, k, 1, d_hashes);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
+                    const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k, int window_size,
+                    int64_t* d_out, void* stream) {
+  if (!ctx || k < 1 || k > 31 || window_size < k || n_rows < 0 || n_out < 0) return BNPK_ERR_ARG;
+  if (n_out == 0) return BNPK_OK;
+  if (!d_packed || !d_in_offsets || !d_out_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n_out, TILE_OUT);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "minimizers", s);
+  hipLaunchKernelGGL((kmer_kernel<true>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
+                     d_out_offsets, n_rows, n_out, k, window_size - k + 1, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_row_ids(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t n, int64_t* d_rows,
+                 void* stream) {
+  if (!ctx || n_rows < 0 || n < 0) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_offsets || !d_rows || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n, TILE_OUT);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "row_ids", s);
+  hipLaunchKernelGGL(row_ids_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_offsets, n_rows, n, d_rows);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Synthetic FASTQ generator (bench / test input) written straight into HBM.
+// Every byte is a pure function of (seed, read id, position); bionumpy_amd/synth.py holds the numpy twin.
+#include "common.h"
+
+namespace {
+
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+constexpr uint64_t GENOME_SALT = 0x67656E6F6D65ull;   // "genome"
+
+struct base_source {
+  uint64_t seed;
+  int mode;
+  int64_t genome_len;
+  int read_len;
+  // cached 32-base block
+  uint64_t blk_key = ~0ull, blk = 0;
+  int64_t cur_read = -1;
+  uint64_t read_key = 0;
+  int64_t read_start = 0;
+
+  __device__ __forceinline__ uint32_t base(int64_t read, int pos) {
+    if (read != cur_read) {
+      cur_read = read;
+      read_key = mix64(seed + (uint64_t)read);
+      if (mode == 1) read_start = (int64_t)(read_key % (uint64_t)(genome_len - read_len + 1));
+      blk_key = ~0ull;
+    }
+    uint64_t stream, idx;
+    if (mode == 0) { stream = read_key; idx = (uint64_t)pos; }
+    else { stream = mix64(seed ^ GENOME_SALT); idx = (uint64_t)(read_start + pos); }
+    uint64_t key = idx >> 5;
+    if (key != blk_key) { blk_key = key; blk = mix64(stream + key); }
+    return (uint32_t)(blk >> (2 * (idx & 31))) & 3u;
+  }
+};
+
+__global__ __launch_bounds__(BNPK_BLOCK) void synth_fastq_kernel(uint8_t* __restrict__ out, int64_t first_read,
+                                                                 int64_t n_reads, int read_len, uint64_t seed,
+                                                                 int mode, int64_t genome_len) {
+  const int64_t rec = 2 * (int64_t)read_len + 16;
+  const int64_t total = n_reads * rec;
+  int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * 16;
+  if (p0 >= total) return;
+  base_source src{seed, mode, genome_len, read_len};
+  const uint32_t alphabet = 0x54474341u;   // 'A','C','G','T'
+  uint64_t lo = 0, hi = 0;
+  int64_t r = p0 / rec;
+  int64_t off = p0 - r * rec;
+  int cnt = (int)min((int64_t)16, total - p0);
+  for (int j = 0; j < cnt; ++j) {
+    uint32_t b;
+    if (off == 0) b = '@';
+    else if (off <= 10) {                        // 10-digit zero padded read id
+      int64_t id = first_read + r;
+      int64_t div = 1;
+      for (int d = 0; d < 10 - (int)off; ++d) div *= 10;
+      b = '0' + (uint32_t)((id / div) % 10);
+    } else if (off == 11) b = '\n';
+    else if (off < 12 + read_len) b = (alphabet >> (8 * src.base(first_read + r, (int)(off - 12)))) & 0xff;
+    else if (off == 12 + read_len) b = '\n';
+    else if (off == 13 + read_len) b = '+';
+    else if (off == 14 + read_len) b = '\n';
+    else if (off < rec - 1) b = 'I';
+    else b = '\n';
+    if (j < 8) lo |= (uint64_t)b << (8 * j); else hi |= (uint64_t)b << (8 * (j - 8));
+    if (++off == rec) { off = 0; ++r; }
+  }
+  if (cnt == 16) {
+    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+  } else {
+    for (int j = 0; j < cnt; ++j) out[p0 + j] = (uint8_t)(j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8)));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bnpk_synth_record_bytes(int read_len) { return 2 * (int64_t)read_len + 16; }
+
+int bnpk_synth_fastq(bnpk_ctx* ctx, uint8_t* d_out, int64_t first_read, int64_t n_reads, int read_len,
+                     uint64_t seed, int mode, int64_t genome_len, void* stream) {
+  if (!ctx || n_reads < 0 || read_len < 1 || first_read < 0 || (mode != 0 && mode != 1)) return BNPK_ERR_ARG;
+  if (mode == 1 && genome_len < read_len) return BNPK_ERR_ARG;
+  if (first_read + n_reads > 9999999999LL) return BNPK_ERR_RANGE;
+  if (n_reads == 0) return BNPK_OK;
+  if (!d_out) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_out & 15) != 0) return BNPK_ERR_ALIGN;
+  int64_t total = n_reads * bnpk_synth_record_bytes(read_len);
+  int64_t blocks = ceil_div(ceil_div(total, 16), BNPK_BLOCK);
+  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "synth_fastq", s);
+  hipLaunchKernelGGL(synth_fastq_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_out, first_read, n_reads,
+                     read_len, seed, mode, genome_len);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+"""Chunk containers of the sequence path: SequenceEntry{name, sequence} and
+SequenceEntryWithQuality{+quality} (bionumpy/datatypes/__init__.py:40-47), with the lazy-field
+behaviour of the reader's chunk objects (bionumpy/bnpdataclass/lazybnpdataclass.py:52-225): a field is
+decoded from the chunk buffer the first time it is accessed."""
+import numpy as np
+
+
+class SequenceEntry:
+    _fields = ("name", "sequence")
+
+    def __init__(self, *values, **kwargs):
+        values = dict(zip(self._fields, values), **kwargs)
+        assert set(values) == set(self._fields), (values.keys(), self._fields)
+        self._values = values
+        self._buffer = None
+        self._line_offset = 0
+
+    # -- lazy construction from a chunk buffer (ItemGetter, lazybnpdataclass.py:19-49) -----------------
+    @classmethod
+    def _lazy(cls, buffer, n_lines_read=0):
+        obj = cls.__new__(cls)
+        obj._values = {}
+        obj._buffer = buffer
+        obj._line_offset = n_lines_read
+        return obj
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name not in self._fields:
+            raise AttributeError(name)
+        if name not in self._values:
+            from .exceptions import FormatException
+            try:
+                self._values[name] = self._buffer.get_field_by_number(self._fields.index(name))
+            except FormatException as e:
+                e.line_number += self._line_offset
+                raise
+        return self._values[name]
+
+    def __len__(self):
+        if self._buffer is not None:
+            return len(self._buffer)
+        return len(self._values[self._fields[0]])
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)):
+            idx = [int(idx)]
+        if self._buffer is not None and not self._values:
+            return self.__class__._lazy(self._buffer[idx], self._line_offset)
+        return self.__class__(**{f: getattr(self, f)[idx] for f in self._fields})
+
+    @classmethod
+    def empty(cls):
+        obj = cls.__new__(cls)
+        obj._values = {f: [] for f in cls._fields}
+        obj._buffer = None
+        obj._line_offset = 0
+        return obj
+
+    def get_buffer(self):
+        return self._buffer
+
+    def __repr__(self):
+        return "%s with %d entries" % (self.__class__.__name__, len(self))
+
+
+class SequenceEntryWithQuality(SequenceEntry):
+    _fields = ("name", "sequence", "quality")

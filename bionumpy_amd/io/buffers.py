@@ -1,0 +1,253 @@
+"""FASTQ / FASTA chunk buffers on the MI355X path.
+
+Same classes, class attributes and method names as the reference for the sequence formats:
+  bionumpy/io/file_buffers.py:80-271       FileBuffer (base)
+  bionumpy/io/one_line_buffer.py:13-192    OneLineBuffer, TwoLineFastaBuffer
+  bionumpy/io/fastq_buffer.py:14-61        FastQBuffer
+  bionumpy/io/multiline_buffer.py:15-109   MultiLineFastaBuffer
+
+A buffer owns the raw chunk in HBM plus the newline table produced by the device scan
+(``bnpk_byte_census`` / ``bnpk_byte_positions`` / ``bnpk_validate_entries``); fields are ragged *views*
+into the chunk (start / length tables from ``bnpk_field_table``), exactly like the reference's
+``RaggedView2`` extraction (io/file_buffers.py:335-338), so nothing is copied until a field is
+encoded or ravelled.
+"""
+import numpy as np
+
+from ..datatypes import SequenceEntry, SequenceEntryWithQuality
+from ..device import HArray
+from ..encoded_array import EncodedArray, EncodedRaggedArray, BaseEncoding, QualityEncoding
+from ..exceptions import FormatException, IncompleteEntryException  # noqa: F401
+from ..ops import get_ops
+
+NEWLINE = 10
+
+
+def _chunk_to_harray(chunk):
+    """raw chunk (numpy uint8, EncodedArray or HArray) -> HArray of bytes"""
+    if isinstance(chunk, HArray):
+        return chunk
+    if isinstance(chunk, EncodedArray):
+        return chunk._harray()
+    return HArray(host=np.asarray(chunk, dtype=np.uint8))
+
+
+class FileBuffer:
+    """io/file_buffers.py:80-271 (the parts a sequence reader touches)"""
+
+    COMMENT = 0
+    dataclass = None
+
+    @property
+    def size(self):
+        return self._size
+
+    @property
+    def data(self):
+        return EncodedArray(self._data, BaseEncoding)
+
+    @property
+    def header_data(self):
+        return None
+
+    @classmethod
+    def read_header(cls, file_object):
+        return None                     # COMMENT == 0 for the sequence formats (file_buffers.py:155-156)
+
+    @classmethod
+    def modify_class_with_header_data(cls, header_data):
+        return cls
+
+    @classmethod
+    def contains_complete_entry(cls, chunks):
+        # io/file_buffers.py:264-267 (host chunks, before they are uploaded)
+        n_new_lines = sum(int(np.count_nonzero(np.asarray(c) == NEWLINE)) for c in chunks)
+        return n_new_lines >= cls.n_lines_per_entry
+
+
+class OneLineBuffer(FileBuffer):
+    n_lines_per_entry = 2
+    _line_offsets = (1, 0)
+    HEADER = ">"
+    _check_plus = False
+    dataclass = SequenceEntry
+
+    def __init__(self, data, scan, rows=None):
+        self._data = data               # HArray: the chunk cut after the last complete entry
+        self._scan = scan               # ops.LineScan
+        self._size = scan.size
+        self._rows = rows               # optional row selection (host int64 indices)
+
+    @property
+    def n_lines(self):
+        return len(self) * self.n_lines_per_entry
+
+    def __len__(self):
+        return self._scan.n_records if self._rows is None else len(self._rows)
+
+    def count_entries(self):
+        return len(self)
+
+    @classmethod
+    def contains_complete_entry(cls, chunks):
+        # one_line_buffer.py:36-42
+        if len(chunks) == 1:
+            try:
+                return True, cls.from_raw_buffer(chunks[0])
+            except IncompleteEntryException:
+                return False
+        return super().contains_complete_entry(chunks)
+
+    @classmethod
+    def from_raw_buffer(cls, chunk, header_data=None):
+        """newline scan + validation on the device (one_line_buffer.py:45-71)"""
+        assert header_data is None
+        data = _chunk_to_harray(chunk)
+        scan = get_ops().scan_lines(data, data.size, cls.n_lines_per_entry, ord(cls.HEADER), cls._check_plus)
+        return cls(data, scan)
+
+    def _field_view(self, line):
+        starts, lens = get_ops().field_table(self._data, self._scan.newlines, self._scan.n_records,
+                                             self.n_lines_per_entry, line, self._line_offsets[line],
+                                             self._scan.has_cr)
+        view = EncodedRaggedArray._from_parts(self._data, starts, lens, None, self._scan.n_records, None,
+                                              BaseEncoding)
+        return view if self._rows is None else view[self._rows]
+
+    def get_text_field_by_number(self, i):
+        return self._field_view(i)
+
+    def get_field_by_number(self, i, t=None):
+        text = self.get_text_field_by_number(i)
+        if t is not None and t is not str:
+            return t.encode(text) if hasattr(t, "encode") else t(text)
+        return text
+
+    def get_data(self):
+        return SequenceEntry(self.get_field_by_number(0), self.get_field_by_number(1))
+
+    def __getitem__(self, idx):
+        rows = np.arange(self._scan.n_records, dtype=np.int64) if self._rows is None else self._rows
+        return self.__class__(self._data, self._scan, np.atleast_1d(rows[idx]))
+
+
+class TwoLineFastaBuffer(OneLineBuffer):
+    """one_line_buffer.py:185-192"""
+    HEADER = ">"
+    n_lines_per_entry = 2
+    dataclass = SequenceEntry
+
+
+class FastQBuffer(OneLineBuffer):
+    """fastq_buffer.py:14-45"""
+    HEADER = "@"
+    n_lines_per_entry = 4
+    dataclass = SequenceEntryWithQuality
+    _line_offsets = (1, 0, 0, 0)
+    _check_plus = True
+
+    def get_text_field_by_number(self, i):
+        if i == 2:
+            return self._field_view(3)
+        return super().get_text_field_by_number(i)
+
+    def get_field_by_number(self, i, t=None):
+        if i == 2:
+            return QualityEncoding.encode(self.get_text_field_by_number(i))
+        return super().get_field_by_number(i, t)
+
+    def get_data(self):
+        return SequenceEntryWithQuality(self.get_field_by_number(0), self.get_field_by_number(1),
+                                        self.get_field_by_number(2))
+
+
+class MultiLineFastaBuffer(FileBuffer):
+    """multiline_buffer.py:15-106.  The newline scan and the '>' probes run on the device; the per-line
+    bookkeeping (a few int64 per *line*) follows the reference's numpy expressions on the host, and the
+    sequence lines are joined by the device gather when the field is encoded / ravelled."""
+
+    SKIP_LAZY = True
+    _new_entry_marker = ">"
+    n_lines_per_entry = 2
+    dataclass = SequenceEntry
+
+    def __init__(self, data, size, new_lines, new_entries):
+        self._data = data
+        self._size = size
+        self._new_lines = new_lines            # host int64
+        self._new_entries = new_entries        # host int64 (indices into new_lines)
+
+    @property
+    def n_lines(self):
+        return len(self._new_lines)
+
+    def count_entries(self):
+        return len(self._new_entries) + 1
+
+    def __len__(self):
+        return self.count_entries()
+
+    @classmethod
+    def contains_complete_entry(cls, chunks):
+        # multiline_buffer.py:33-44 on the host chunks
+        marker = ord(cls._new_entry_marker)
+        ends_with_new_line = False
+        for chunk in chunks:
+            chunk = np.asarray(chunk)
+            new_lines = np.flatnonzero(chunk[:-1] == NEWLINE)
+            if np.count_nonzero(chunk[new_lines + 1] == marker) >= 1:
+                return True
+            if ends_with_new_line and chunk[0] == marker:
+                return True
+            ends_with_new_line = chunk[-1] == NEWLINE
+        return False
+
+    @classmethod
+    def from_raw_buffer(cls, chunk, header_data=None):
+        assert header_data is None, header_data
+        ops = get_ops()
+        data = _chunk_to_harray(chunk)
+        n = data.size
+        newlines, _ = ops.newline_positions(data, n - 1, 1)          # chunk[:-1] == "\n"  (:93)
+        first = ops.take_bytes(data, HArray(host=np.zeros(1, dtype=np.int64)), 0).host()[0]
+        assert first == ord(cls._new_entry_marker), "multi-line FASTA chunk must start with '>'"
+        marks = ops.take_bytes(data, newlines, 1).host()              # chunk[new_lines + 1]     (:94)
+        new_lines = newlines.host()
+        new_entries = np.flatnonzero(marks == ord(cls._new_entry_marker))
+        if new_entries.size == 0:
+            raise RuntimeError("No complete entry found in %s. This can be due to badly formatted file, or "
+                               "because the buffer_size (%d) is too low. Try increasing buffer_size"
+                               % (cls.__name__, n))
+        entry_starts = new_lines[new_entries] + 1
+        return cls(data, int(entry_starts[-1]), new_lines[:new_entries[-1]], new_entries[:-1])
+
+    def get_data(self):
+        # multiline_buffer.py:46-62
+        ops = get_ops()
+        size = self._size
+        line_starts = np.insert(self._new_lines + 1, 0, 0)
+        line_ends = np.append(self._new_lines, size - 1)
+        probe = HArray(host=np.ascontiguousarray(line_ends[:10]))
+        if np.any(ops.take_bytes(self._data, probe, -1).host() == ord("\r")):          # :103-106
+            cr = ops.take_bytes(self._data, HArray(host=np.ascontiguousarray(line_ends)), -1).host() == ord("\r")
+            line_ends = line_ends - cr
+        line_lens = line_ends - line_starts
+        header_lines = np.insert(self._new_entries + 1, 0, 0)
+        n_lines_per_entry = np.diff(np.append(header_lines, self._new_lines.size + 1)) - 1
+        is_header = np.zeros(line_starts.size, dtype=bool)
+        is_header[header_lines] = True
+        seq_starts, seq_lens = line_starts[~is_header], line_lens[~is_header]
+        line_offsets = np.insert(np.cumsum(n_lines_per_entry), 0, 0)
+        csum = np.insert(np.cumsum(seq_lens), 0, 0)
+        record_lens = csum[line_offsets[1:]] - csum[line_offsets[:-1]]
+        n = header_lines.size
+        headers = EncodedRaggedArray._from_parts(
+            self._data, HArray(host=line_starts[header_lines] + 1), HArray(host=line_lens[header_lines] - 1), None,
+            n, None, BaseEncoding)
+        # join the sequence lines of every record: gather the line views once on the device
+        lines = EncodedRaggedArray._from_parts(self._data, HArray(host=seq_starts), HArray(host=seq_lens), None,
+                                               seq_starts.size, int(seq_lens.sum()), BaseEncoding)
+        lines._compact()
+        sequences = EncodedRaggedArray._from_parts(lines._data, None, HArray(host=record_lens.astype(np.int64)), None,
+                                                   n, int(record_lens.sum()), BaseEncoding)
+        return SequenceEntry(headers, sequences)

@@ -1,0 +1,57 @@
+"""NpDataclassReader: what ``bnp.open`` returns (bionumpy/io/npdataclassreader.py:14-142)."""
+from itertools import takewhile, repeat
+
+from ..exceptions import FormatException
+from ..streams import NpDataclassStream
+
+
+class NpDataclassReader:
+    def __init__(self, numpyfilereader, lazy=None):
+        self._reader = numpyfilereader
+        self._lazy = lazy
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self._reader.close()
+
+    def close(self):
+        self._reader.close()
+
+    def _wrap(self, chunk, n_lines_read=0):
+        if self._should_be_lazy(chunk):
+            return chunk.dataclass._lazy(chunk, n_lines_read)
+        return chunk.get_data()
+
+    def read(self):
+        """the whole file as one chunk object (npdataclassreader.py:36-58)"""
+        chunk = self._reader.read()
+        if chunk is None:
+            return self._reader._buffer_type.dataclass.empty()
+        return self._wrap(chunk)
+
+    def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
+        """all complete entries of the next >= min_chunk_size bytes (npdataclassreader.py:60-92)"""
+        n_lines_read = self._reader.n_lines_read
+        chunk = self._reader.read_chunk(min_chunk_size, max_chunk_size)
+        if chunk is None:
+            return self._reader._buffer_type.dataclass.empty()
+        try:
+            return self._wrap(chunk, n_lines_read)
+        except FormatException as e:
+            e.line_number += n_lines_read
+            raise e
+
+    def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
+        data_stream = takewhile(len, (self.read_chunk(min_chunk_size, max_chunk_size) for _ in repeat(None)))
+        return NpDataclassStream(data_stream, dataclass=self._reader._buffer_type.dataclass)
+
+    def __iter__(self):
+        return self.read_chunks()
+
+    def _should_be_lazy(self, chunk):
+        # npdataclassreader.py:135-142 with config.LAZY = True; multi-line FASTA has SKIP_LAZY
+        if self._lazy is False:
+            return False
+        return hasattr(chunk, "get_field_by_number") and not getattr(chunk, "SKIP_LAZY", False)

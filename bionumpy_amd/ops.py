@@ -1,0 +1,300 @@
+"""HipOps: the hot-path primitives on HBM-resident buffers, each a thin wrapper over the C-ABI
+(include/bnpk.h).  Every method takes and returns ``HArray``s (or ints) so that the host logic
+above it never touches torch or ctypes.
+
+Host logic receives its ops object from ``get_ops()``.  There is exactly one product
+implementation (this one) and it raises if no GPU / no libbnpk.so is present — no CPU fallback.
+``set_ops`` exists so that the CPU-only test-suite can drive the *host* logic (chunk loop,
+exception mapping, API classes) with an oracle-backed stand-in defined under tests/.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _native
+from ._native import lib, check, NONE
+from .device import Device, HArray, ptr
+from .exceptions import EncodingError
+from .exceptions import FormatException, IncompleteEntryException
+
+NEWLINE = 10
+
+LineScan = namedtuple("LineScan", "size n_lines n_records newlines has_cr")
+
+
+class HipOps:
+    def __init__(self, device=None):
+        self.device = device or Device.get()
+        self.ctx = self.device.ctx
+
+    # -- small helpers -------------------------------------------------------------------------
+    def _s(self):
+        return self.device.stream()
+
+    def _chk(self, status):
+        check(status, self.ctx)
+
+    def _empty(self, n, dtype):
+        return self.device.empty(n, dtype)
+
+    # -- A2 + A3: newline scan and entry validation --------------------------------------------------
+    def newline_positions(self, buf, n, limit_multiple=1):
+        """positions of '\\n' in buf[:n], truncated to a multiple of ``limit_multiple`` lines"""
+        d = buf.dev()
+        tiles = lib.bnpk_scan_tiles(n)
+        tile_off = self._empty(tiles + 1, np.int64)
+        self._chk(lib.bnpk_byte_census(self.ctx, ptr(d), n, NEWLINE, ptr(tile_off), self._s()))
+        total = int(tile_off[tiles].item())
+        n_lines = total - (total % limit_multiple)
+        pos = self._empty(n_lines, np.int64)
+        self._chk(lib.bnpk_byte_positions(self.ctx, ptr(d), n, NEWLINE, ptr(tile_off), n_lines, ptr(pos), self._s()))
+        return HArray(dev=pos), total
+
+    def scan_lines(self, buf, n, lines_per_entry, header, check_plus):
+        """OneLineBuffer.from_raw_buffer + _validate on a device chunk (one_line_buffer.py:45-71,156-173)."""
+        newlines, total = self.newline_positions(buf, n, lines_per_entry)
+        if total < lines_per_entry:
+            raise IncompleteEntryException("No complete entry in buffer. Try increasing chunk_size.")
+        n_lines = newlines.size
+        nl = newlines.dev()
+        err = self._empty(4, np.int64)
+        self._chk(lib.bnpk_validate_entries(self.ctx, ptr(buf.dev()), ptr(nl), n_lines, lines_per_entry, header,
+                                            1 if check_plus else 0, ptr(err), self._s()))
+        err[3:4].copy_(nl[n_lines - 1:n_lines])          # last newline -> size, one D2H for all four
+        e = err.cpu().numpy()
+        if e[0] != NONE:
+            raise FormatException("Expected header line to start with %s" % chr(header),
+                                  line_number=int(e[0]) * lines_per_entry)
+        if check_plus and e[1] != NONE:
+            raise FormatException("Expected '+' at third line of entry",
+                                  line_number=2 + int(e[1]) * lines_per_entry)
+        return LineScan(int(e[3]) + 1, n_lines, n_lines // lines_per_entry, newlines, bool(e[2]))
+
+    def field_table(self, buf, newlines, n_entries, lines_per_entry, field, line_offset, strip_cr):
+        starts = self._empty(n_entries, np.int64)
+        lens = self._empty(n_entries, np.int64)
+        self._chk(lib.bnpk_field_table(self.ctx, ptr(buf.dev()), ptr(newlines.dev()), n_entries, lines_per_entry,
+                                       field, line_offset, 1 if strip_cr else 0, ptr(starts), ptr(lens), self._s()))
+        return HArray(dev=starts), HArray(dev=lens)
+
+    def take_bytes(self, buf, positions, delta):
+        m = positions.size
+        out = self._empty(m, np.uint8)
+        self._chk(lib.bnpk_take_bytes(self.ctx, ptr(buf.dev()), ptr(positions.dev()), m, delta, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    # -- ragged offsets ------------------------------------------------------------------------------
+    def row_offsets(self, lens, window=1):
+        """(offsets[n+1], total) of rows trimmed by window-1 (RaggedShape; kmers.py:100)"""
+        n = lens.size
+        off = self._empty(n + 1, np.int64)
+        self._chk(lib.bnpk_row_offsets(self.ctx, ptr(lens.dev()) if n else None, n, window, ptr(off), self._s()))
+        return HArray(dev=off), int(off[n].item())
+
+    def exclusive_scan(self, values):
+        n = values.size
+        out = self._empty(n + 1, np.int64)
+        self._chk(lib.bnpk_exclusive_scan_i64(self.ctx, ptr(values.dev()) if n else None, n, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    # -- A6 + A7 ----------------------------------------------------------------------------------------
+    def _err_cell(self):
+        cell = self._empty(1, np.int64)
+        self._chk(lib.bnpk_fill_i64(self.ctx, ptr(cell), 1, NONE, self._s()))
+        return cell
+
+    def _raise_if_bad(self, cell):
+        off = int(cell.item())
+        if off != NONE:
+            raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character at flat "
+                                "offset %d" % off, off)
+
+    def gather_encode_dna(self, buf, starts, offsets, n_rows, total, want_codes=False, want_packed=True):
+        codes = self._empty(total, np.uint8) if want_codes else None
+        packed = self._empty(total // 32 + 2, np.int64) if want_packed else None
+        cell = self._err_cell()
+        self._chk(lib.bnpk_gather_encode_dna(self.ctx, ptr(buf.dev()), ptr(starts.dev()), ptr(offsets.dev()), n_rows,
+                                             total, ptr(codes), ptr(packed), ptr(cell), self._s()))
+        self._raise_if_bad(cell)
+        return (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)
+
+    def gather_rows(self, buf, starts, offsets, n_rows, total, subtract=0):
+        out = self._empty(total, np.uint8)
+        self._chk(lib.bnpk_gather_rows(self.ctx, ptr(buf.dev()), ptr(starts.dev()), ptr(offsets.dev()), n_rows, total,
+                                       subtract, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def encode_dna_flat(self, ascii_bytes, want_codes=True, want_packed=True):
+        n = ascii_bytes.size
+        codes = self._empty(n, np.uint8) if want_codes else None
+        packed = self._empty(n // 32 + 2, np.int64) if want_packed else None
+        cell = self._err_cell()
+        self._chk(lib.bnpk_encode_dna_flat(self.ctx, ptr(ascii_bytes.dev()), n, ptr(codes), ptr(packed), ptr(cell),
+                                           self._s()))
+        self._raise_if_bad(cell)
+        return (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)
+
+    def pack_codes(self, codes):
+        n = codes.size
+        packed = self._empty(n // 32 + 2, np.int64)
+        self._chk(lib.bnpk_pack_codes(self.ctx, ptr(codes.dev()), n, ptr(packed), self._s()))
+        return HArray(dev=packed)
+
+    def unpack_codes(self, packed, n, to_ascii=False):
+        out = self._empty(n, np.uint8)
+        self._chk(lib.bnpk_unpack_codes(self.ctx, ptr(packed.dev()), n, 1 if to_ascii else 0, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    # -- A8 / A11 ------------------------------------------------------------------------------------------
+    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
+        out = self._empty(n_out, np.int64)
+        self._chk(lib.bnpk_kmers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()), n_rows,
+                                 n_out, k, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
+        out = self._empty(n_out, np.int64)
+        self._chk(lib.bnpk_minimizers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
+                                      n_rows, n_out, k, window_size, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    # -- A9 ---------------------------------------------------------------------------------------------------
+    def count_dense(self, values, n_bins, hist=None):
+        if hist is None:
+            hist = HArray(dev=self.device.zeros(n_bins, np.int64))
+        self._chk(lib.bnpk_count_dense(self.ctx, ptr(values.dev()), values.size, n_bins, ptr(hist.dev()), self._s()))
+        return hist
+
+    def count_dense_rows(self, values, offsets, n_rows, n_bins):
+        hist = self.device.zeros(n_rows * n_bins, np.int64)
+        self._chk(lib.bnpk_count_dense_rows(self.ctx, ptr(values.dev()), ptr(offsets.dev()), n_rows, values.size,
+                                            n_bins, ptr(hist), self._s()))
+        return HArray(dev=hist)
+
+    def sort_keys(self, keys_t, key_bits):
+        """sorts a torch int64 tensor; returns the tensor holding the result and the other (free) one"""
+        n = keys_t.numel()
+        alt = self._empty(n, np.int64)
+        in_alt = C.c_int(0)
+        self._chk(lib.bnpk_sort_keys(self.ctx, ptr(keys_t), ptr(alt), n, key_bits, C.byref(in_alt), self._s()))
+        return (alt, keys_t) if in_alt.value else (keys_t, alt)
+
+    def _runs(self, sorted_t, second_t=None):
+        """run boundaries of a sorted tensor (optionally of (sorted, second) pairs): n_runs, tile offsets"""
+        n = sorted_t.numel()
+        tiles = lib.bnpk_run_tiles(n)
+        tile_off = self._empty(tiles + 1, np.int64)
+        n_runs = C.c_int64(0)
+        self._chk(lib.bnpk_run_census(self.ctx, ptr(sorted_t), ptr(second_t), n, ptr(tile_off), C.byref(n_runs),
+                                      self._s()))
+        return int(n_runs.value), tile_off
+
+    def count_sparse(self, values, key_bits=62, consume=False):
+        """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys)."""
+        t = values.dev()
+        n = t.numel()
+        if n == 0:
+            z = self._empty(0, np.int64)
+            return HArray(dev=z), HArray(dev=z.clone())
+        work = t if consume else t.clone()
+        sorted_t, free_t = self.sort_keys(work, key_bits)
+        n_runs, tile_off = self._runs(sorted_t)
+        keys_out = free_t[:n_runs]                       # the ping-pong buffer is free after the sort
+        starts = self._empty(n_runs + 1, np.int64)
+        self._chk(lib.bnpk_run_heads(self.ctx, ptr(sorted_t), None, n, ptr(tile_off), n_runs, ptr(keys_out), None,
+                                     ptr(starts), self._s()))
+        counts = self._empty(n_runs, np.int64)
+        self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, None, ptr(counts), self._s()))
+        return HArray(dev=keys_out), HArray(dev=counts)
+
+    def reduce_by_key(self, keys, weights, key_bits=62):
+        """sum of weights per distinct key (merge of sparse histograms; EncodedCounts.__add__ analogue)."""
+        t = self.device.torch_cat([k.dev() for k in keys]) if isinstance(keys, (list, tuple)) else keys.dev().clone()
+        w = self.device.torch_cat([x.dev() for x in weights]) if isinstance(weights, (list, tuple)) \
+            else weights.dev().clone()
+        n = t.numel()
+        if n == 0:
+            return HArray(dev=t), HArray(dev=w)
+        t_alt = self._empty(n, np.int64)
+        w_alt = self._empty(n, np.int64)
+        in_alt = C.c_int(0)
+        self._chk(lib.bnpk_sort_pairs(self.ctx, ptr(t), ptr(t_alt), ptr(w), ptr(w_alt), n, key_bits, C.byref(in_alt),
+                                      self._s()))
+        if in_alt.value:
+            t, t_alt, w, w_alt = t_alt, t, w_alt, w
+        n_runs, tile_off = self._runs(t)
+        keys_out = t_alt[:n_runs]
+        starts = self._empty(n_runs + 1, np.int64)
+        self._chk(lib.bnpk_run_heads(self.ctx, ptr(t), None, n, ptr(tile_off), n_runs, ptr(keys_out), None,
+                                     ptr(starts), self._s()))
+        prefix = self._empty(n + 1, np.int64)
+        self._chk(lib.bnpk_exclusive_scan_i64(self.ctx, ptr(w), n, ptr(prefix), self._s()))
+        sums = self._empty(n_runs, np.int64)
+        self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, ptr(prefix), ptr(sums), self._s()))
+        return HArray(dev=keys_out), HArray(dev=sums)
+
+    # -- A12 -------------------------------------------------------------------------------------------------------
+    def row_ids(self, offsets, n_rows, n):
+        rows = self._empty(n, np.int64)
+        self._chk(lib.bnpk_row_ids(self.ctx, ptr(offsets.dev()), n_rows, n, ptr(rows), self._s()))
+        return HArray(dev=rows)
+
+    def unique_pairs(self, keys, values, key_bits=62):
+        """sorted distinct (key, value) pairs; values must already ascend within equal keys' input order
+        (row ids do), since the radix sort is stable."""
+        t = keys.dev().clone()
+        v = values.dev().clone()
+        n = t.numel()
+        if n == 0:
+            return HArray(dev=t), HArray(dev=v)
+        t_alt = self._empty(n, np.int64)
+        v_alt = self._empty(n, np.int64)
+        in_alt = C.c_int(0)
+        self._chk(lib.bnpk_sort_pairs(self.ctx, ptr(t), ptr(t_alt), ptr(v), ptr(v_alt), n, key_bits, C.byref(in_alt),
+                                      self._s()))
+        if in_alt.value:
+            t, t_alt, v, v_alt = t_alt, t, v_alt, v
+        n_runs, tile_off = self._runs(t, v)
+        keys_out, vals_out = t_alt[:n_runs], v_alt[:n_runs]
+        starts = self._empty(n_runs + 1, np.int64)
+        self._chk(lib.bnpk_run_heads(self.ctx, ptr(t), ptr(v), n, ptr(tile_off), n_runs, ptr(keys_out), ptr(vals_out),
+                                     ptr(starts), self._s()))
+        return HArray(dev=keys_out), HArray(dev=vals_out)
+
+    def search_sorted(self, sorted_keys, queries, upper=False):
+        m = queries.size
+        out = self._empty(m, np.int64)
+        self._chk(lib.bnpk_search_sorted(self.ctx, ptr(sorted_keys.dev()), sorted_keys.size, ptr(queries.dev()), m,
+                                         1 if upper else 0, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    # -- misc --------------------------------------------------------------------------------------------------------
+    def concat(self, arrays):
+        return HArray(dev=self.device.torch_cat([a.dev() for a in arrays]))
+
+    def add_i64(self, a, b):
+        return HArray(dev=a.dev() + b.dev())
+
+    def synth_fastq(self, n_reads, read_len, seed, mode=0, genome_len=0, first_read=0):
+        total = n_reads * lib.bnpk_synth_record_bytes(read_len)
+        out = self._empty(total, np.uint8)
+        self._chk(lib.bnpk_synth_fastq(self.ctx, ptr(out), first_read, n_reads, read_len, seed, mode, genome_len,
+                                       self._s()))
+        return HArray(dev=out)
+
+
+_ops = None
+
+
+def get_ops():
+    global _ops
+    if _ops is None:
+        _ops = HipOps()
+    return _ops
+
+
+def set_ops(ops):
+    """Replace the ops object (tests only: CPU-side host-logic tests inject an oracle-backed stand-in)."""
+    global _ops
+    _ops = ops

@@ -1,0 +1,231 @@
+"""RaggedArray: rows of different length over one flat HBM buffer.
+
+Mirrors the parts of ``npstructures.RaggedArray`` the sequence path uses
+(SURVEY.md Appendix A): ``len``, ``.lengths``, ``.shape == (n_rows, lengths)``, ``.size``,
+``.ravel()``, row / row-slice / column-slice / mask indexing, iteration, ``tolist``.
+
+A ragged array is (flat data, row starts, row lengths).  It is *compact* when the rows tile
+the flat buffer (starts == cumsum(lengths) - lengths); otherwise it is a view (the reference's
+``RaggedView``: e.g. the sequence lines inside a raw FASTQ chunk, io/file_buffers.py:335-338)
+and ``ravel()`` gathers it into a compact buffer on the device (copy A6 of SURVEY §8a).
+
+The flat data and the row tables live in HBM (``HArray``); indexing and printing are host
+conveniences that pull what they need.
+"""
+import numpy as np
+
+from .device import HArray, as_harray
+from .ops import get_ops
+
+
+def _row_starts(lengths):
+    out = np.zeros(len(lengths), dtype=np.int64)
+    if len(lengths) > 1:
+        np.cumsum(lengths[:-1], out=out[1:])
+    return out
+
+
+class RaggedArray:
+    def __init__(self, data, shape=None, dtype=None, safe_mode=True):
+        if shape is None:                                   # list of rows
+            rows = [np.asarray(r) for r in data]
+            lengths = np.array([r.size for r in rows], dtype=np.int64)
+            flat = np.concatenate(rows) if rows else np.zeros(0, dtype=dtype or np.int64)
+            if dtype is not None:
+                flat = flat.astype(dtype)
+            self._init(as_harray(flat), None, as_harray(lengths), None, len(rows), int(lengths.sum()))
+            return
+        if isinstance(shape, RaggedArray):
+            shape = shape._shape
+        if isinstance(shape, RaggedShape):
+            self._init(as_harray(data), shape.starts, shape.lens, shape.offsets, shape.n_rows, shape.total)
+            return
+        if isinstance(shape, tuple):                       # (n_rows, lengths) as returned by .shape
+            shape = shape[-1]
+        lengths = np.asarray(shape, dtype=np.int64)
+        data = as_harray(data)
+        total = int(lengths.sum())
+        if safe_mode:
+            assert data.size == total, (data.size, total)
+        self._init(data, None, as_harray(lengths), None, lengths.size, total)
+
+    def _init(self, data, starts, lens, offsets, n_rows, total):
+        self._data = data          # HArray, flat storage
+        self._starts = starts      # HArray int64[n] or None (compact)
+        self._lens = lens          # HArray int64[n]
+        self._offsets = offsets    # HArray int64[n+1] compact offsets (lazy)
+        self._n_rows = int(n_rows)
+        self._total = total        # int or None (lazy)
+
+    # -- construction helpers -------------------------------------------------------------------------
+    @classmethod
+    def _from_parts(cls, data, starts, lens, offsets, n_rows, total):
+        obj = cls.__new__(cls)
+        obj._init(data, starts, lens, offsets, n_rows, total)
+        return obj
+
+    def _like(self, data, starts, lens, offsets, n_rows, total):
+        return RaggedArray._from_parts(data, starts, lens, offsets, n_rows, total)
+
+    @property
+    def _shape(self):
+        return RaggedShape(self._starts, self._lens, self._offsets, self._n_rows, self._total)
+
+    # -- basic properties ------------------------------------------------------------------------------------
+    def __len__(self):
+        return self._n_rows
+
+    @property
+    def lengths(self):
+        return self._lens.host()
+
+    @property
+    def shape(self):
+        return (self._n_rows, self.lengths)
+
+    @property
+    def size(self):
+        return self.total()
+
+    @property
+    def dtype(self):
+        return self._data.dtype
+
+    def total(self):
+        if self._total is None:
+            self.offsets()
+        return self._total
+
+    def is_compact(self):
+        return self._starts is None
+
+    def offsets(self):
+        """compact row offsets (n+1) as an HArray; computed on the device on first use"""
+        if self._offsets is None:
+            self._offsets, self._total = get_ops().row_offsets(self._lens, 1)
+        return self._offsets
+
+    def _flat_data(self):
+        """the flat storage, materialised (EncodedRaggedArray overrides this for packed DNA)"""
+        return self._data
+
+    # -- ravel: gather a view into a compact buffer (device) ------------------------------------------------------
+    def _compact(self):
+        if self._starts is None:
+            return
+        data = self._flat_data()
+        total = self.total()
+        if data.dtype == np.uint8:
+            new = get_ops().gather_rows(data, self._starts, self.offsets(), self._n_rows, total, 0)
+        else:
+            # column/row slices of numeric results: small presentation-side gathers
+            starts, lens = self._starts.host(), self._lens.host()
+            idx = np.repeat(starts - _row_starts(lens), lens) + np.arange(total, dtype=np.int64)
+            new = HArray(host=data.host()[idx])
+        self._data, self._starts = new, None
+
+    def ravel(self):
+        self._compact()
+        return self._flat_data().host()
+
+    def raw(self):
+        return self
+
+    # -- indexing (host side) ------------------------------------------------------------------------------------------
+    def _host_starts(self):
+        if self._starts is not None:
+            return self._starts.host()
+        return self.offsets().host()[:-1]
+
+    def _row(self, i):
+        n = self._n_rows
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("row %d out of range for %d rows" % (i, n))
+        s = int(self._host_starts()[i])
+        return self._flat_data().host()[s:s + int(self.lengths[i])]
+
+    def _wrap_row(self, row):
+        return row
+
+    def _select_rows(self, idx):
+        starts = self._host_starts()[idx]
+        lens = self.lengths[idx]
+        return self._like(self._flat_data(), HArray(host=np.ascontiguousarray(starts)),
+                          HArray(host=np.ascontiguousarray(lens)), None, len(lens), int(lens.sum()))
+
+    def _col_slice(self, sl):
+        starts, lens = self._host_starts(), self.lengths
+        if not isinstance(sl, slice) or (sl.step not in (None, 1)):
+            raise NotImplementedError("only contiguous column slices are supported")
+        lo = 0 if sl.start is None else sl.start
+        lo_abs = np.minimum(lo, lens) if lo >= 0 else np.maximum(lens + lo, 0)
+        if sl.stop is None:
+            hi_abs = lens
+        else:
+            hi = sl.stop
+            hi_abs = np.minimum(hi, lens) if hi >= 0 else np.maximum(lens + hi, 0)
+        new_lens = np.maximum(hi_abs - lo_abs, 0)
+        return self._like(self._flat_data(), HArray(host=starts + lo_abs), HArray(host=new_lens), None, len(lens),
+                          int(new_lens.sum()))
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple):
+            if len(idx) != 2:
+                raise IndexError("ragged arrays are two-dimensional")
+            rows, cols = idx
+            if rows is Ellipsis:
+                rows = slice(None)
+            if isinstance(rows, (int, np.integer)):
+                row = self._row(int(rows))
+                return self._wrap_row(row[cols])
+            sub = self if (isinstance(rows, slice) and rows == slice(None)) else self[rows]
+            if isinstance(cols, (int, np.integer)):
+                starts, lens = sub._host_starts(), sub.lengths
+                c = np.where(cols >= 0, cols, lens + cols)
+                if np.any((c < 0) | (c >= lens)):
+                    raise IndexError("column index out of range")
+                return self._wrap_row(sub._flat_data().host()[starts + c])
+            return sub._col_slice(cols)
+        if isinstance(idx, (int, np.integer)):
+            return self._wrap_row(self._row(int(idx)))
+        if isinstance(idx, slice):
+            return self._select_rows(idx)
+        idx = np.asarray(idx)
+        if idx.dtype == bool:
+            idx = np.flatnonzero(idx)
+        return self._select_rows(idx.astype(np.int64))
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n_rows))
+
+    def tolist(self):
+        return [np.asarray(r).tolist() for r in self]
+
+    def __repr__(self):
+        rows = [repr(np.asarray(self._row(i)).tolist()) for i in range(min(self._n_rows, 20))]
+        more = ", ..." if self._n_rows > 20 else ""
+        return "ragged_array([%s%s])" % (",\n              ".join(rows), more)
+
+    def __eq__(self, other):
+        if not isinstance(other, RaggedArray):
+            return NotImplemented
+        return (np.array_equal(self.lengths, other.lengths)
+                and np.array_equal(np.asarray(self.ravel()), np.asarray(other.ravel())))
+
+
+class RaggedShape:
+    """row layout of a RaggedArray: (starts | None, lens, offsets | None, n_rows, total)"""
+
+    def __init__(self, starts, lens, offsets, n_rows, total):
+        self.starts, self.lens, self.offsets, self.n_rows, self.total = starts, lens, offsets, n_rows, total
+
+    @property
+    def lengths(self):
+        return self.lens.host()
+
+    def __eq__(self, other):
+        if isinstance(other, RaggedShape):
+            return np.array_equal(self.lengths, other.lengths)
+        return NotImplemented

@@ -1,0 +1,9 @@
+"""Sequence ops on the hot path (bionumpy/sequence/__init__.py)."""
+from .kmers import get_kmers, count_kmers
+from .minimizers import get_minimizers
+from .count_encoded import count_encoded, EncodedCounts, SparseKmerCounts
+from . import indexing
+from .indexing import KmerIndex, KmerLookup
+
+__all__ = ["get_kmers", "count_kmers", "get_minimizers", "count_encoded", "EncodedCounts", "SparseKmerCounts",
+           "KmerIndex", "KmerLookup", "indexing"]

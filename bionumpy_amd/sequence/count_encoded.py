@@ -1,0 +1,182 @@
+"""count_encoded / EncodedCounts (bionumpy/sequence/count_encoded.py:11-188) on the MI355X path.
+
+Dense counts (finite alphabets: DNA letters, k-mers with k <= 8) are an LDS / global-atomic histogram
+(``bnpk_count_dense``) and come back as the reference's ``EncodedCounts(alphabet, counts)``.
+k > 8 has no reference implementation (``KmerEncoding.get_labels`` asserts k <= 8); for it
+``count_encoded(..., axis=None)`` returns ``SparseKmerCounts`` = np.unique(hashes, return_counts=True)
+computed by radix sort + run-length on the device — the stated extension of SURVEY.md §3.5.
+"""
+from numbers import Number
+
+import numpy as np
+
+from ..device import HArray
+from ..encoded_array import EncodedArray, EncodedRaggedArray
+from ..ops import get_ops
+
+
+class EncodedCounts:
+    """count_encoded.py:11-147"""
+
+    def __init__(self, alphabet, counts, row_names=None):
+        self.counts = counts
+        self.alphabet = alphabet
+        self.row_names = row_names
+
+    def __str__(self):
+        return "\n".join("%s: %s" % (c, n) for c, n in zip(self.alphabet, self.counts.T))
+
+    def __repr__(self):
+        return "EncodedCounts(alphabet=%r, counts=%r, row_names=%r)" % (self.alphabet, self.counts, self.row_names)
+
+    def __eq__(self, other):
+        if self.alphabet != other.alphabet:
+            return False
+        return bool(np.all(self.counts == other.counts))
+
+    def __getitem__(self, idx):
+        return self.counts[..., self.alphabet.index(idx)]
+
+    def _other_counts(self, other):
+        if isinstance(other, Number):
+            return other
+        assert self.alphabet == other.alphabet
+        return other.counts
+
+    def __add__(self, other):
+        return self.__class__(self.alphabet, self.counts + self._other_counts(other))
+
+    __radd__ = __add__
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        if method != "__call__":
+            return NotImplemented
+        assert all(i.alphabet == self.alphabet for i in inputs if isinstance(i, EncodedCounts))
+        arrays = [i.counts if isinstance(i, EncodedCounts) else i for i in inputs]
+        kwargs = {k: v.counts if isinstance(v, EncodedCounts) else v for k, v in kwargs.items()}
+        return self.__class__(self.alphabet, ufunc(*arrays, **kwargs))
+
+    @property
+    def proportions(self):
+        s = self.counts.sum(axis=-1, keepdims=True)
+        return np.where(s > 0, self.counts / np.where(s > 0, s, 1), 0)
+
+    def get_count_for_label(self, label):
+        return sum(self.counts[..., self.alphabet.index(l)] for l in label)
+
+    @property
+    def labels(self):
+        return self.alphabet
+
+    @classmethod
+    def vstack(cls, counts):
+        alphabet = counts[0].alphabet
+        assert all(c.alphabet == alphabet for c in counts)
+        ret = cls(alphabet, np.array([c.counts for c in counts], dtype="int"))
+        if counts[0].row_names is not None:
+            ret.row_names = [c.row_names for c in counts]
+        return ret
+
+    def most_common(self, n=None):
+        args = np.argsort(self.counts)[::-1]
+        if n is not None:
+            args = args[:n]
+        return self.__class__([self.alphabet[i] for i in args], self.counts[args])
+
+    def as_dict(self):
+        return dict(zip(self.alphabet, self.counts.T))
+
+
+class SparseKmerCounts:
+    """Histogram of k-mers for k > 8: sorted distinct int64 keys + int64 counts, HBM-resident.
+
+    ``+`` merges two histograms (the k = 31 analogue of EncodedCounts.__add__, so that
+    ``sum(count_kmers(chunk.sequence, 31) for chunk in reader)`` works like the reference's streams)."""
+
+    def __init__(self, encoding, keys, counts):
+        self.encoding = encoding
+        self._keys = keys if isinstance(keys, HArray) else HArray(host=np.asarray(keys, dtype=np.int64))
+        self._counts = counts if isinstance(counts, HArray) else HArray(host=np.asarray(counts, dtype=np.int64))
+
+    @property
+    def keys(self):
+        return self._keys.host()
+
+    @property
+    def counts(self):
+        return self._counts.host()
+
+    def __len__(self):
+        return self._keys.size
+
+    def __getitem__(self, kmer):
+        if isinstance(kmer, str):
+            kmer = int(self.encoding.encode(kmer).raw())
+        keys = self.keys
+        i = int(np.searchsorted(keys, kmer))
+        return int(self.counts[i]) if i < keys.size and keys[i] == kmer else 0
+
+    def __add__(self, other):
+        if isinstance(other, Number):
+            assert other == 0, "only 0 (the start value of sum) can be added to a sparse histogram"
+            return self
+        assert self.encoding == other.encoding
+        keys, counts = get_ops().reduce_by_key([self._keys, other._keys], [self._counts, other._counts],
+                                               key_bits=2 * self.encoding.k)
+        return SparseKmerCounts(self.encoding, keys, counts)
+
+    __radd__ = __add__
+
+    def __eq__(self, other):
+        return self.encoding == other.encoding and np.array_equal(self.keys, other.keys) \
+            and np.array_equal(self.counts, other.counts)
+
+    def most_common(self, n=None):
+        args = np.argsort(self.counts, kind="stable")[::-1]
+        if n is not None:
+            args = args[:n]
+        return SparseKmerCounts(self.encoding, self.keys[args], self.counts[args])
+
+    def as_dict(self):
+        return {self.encoding.to_string(k): int(c) for k, c in zip(self.keys, self.counts)}
+
+    def __repr__(self):
+        return "SparseKmerCounts(%s, %d distinct)" % (self.encoding, len(self))
+
+
+def count_encoded(values, weights=None, axis=-1):
+    """Count the occurrences of encoded entries (count_encoded.py:150-188).
+
+    axis=None: flattened counts; axis=-1 on a ragged array: one histogram per row."""
+    if weights is not None:
+        raise NotImplementedError("weights are not on the MI355X path")
+    ops = get_ops()
+    encoding = values.encoding
+    flat_request = axis is None or (isinstance(values, EncodedArray) and values.ndim == 1)
+    k = getattr(encoding, "k", None)
+    if flat_request and k is not None and k > 8:
+        store = _flat_store(values)
+        keys, counts = ops.count_sparse(store, key_bits=2 * k)
+        return SparseKmerCounts(encoding, keys, counts)
+    alphabet = encoding.get_alphabet() if hasattr(encoding, "get_alphabet") else encoding.get_labels()
+    n_bins = len(alphabet)
+    if flat_request:
+        hist = ops.count_dense(_as_int64(_flat_store(values)), n_bins)
+        return EncodedCounts(alphabet, hist.host().copy())
+    assert axis == -1 and isinstance(values, EncodedRaggedArray)
+    values._compact()
+    hist = ops.count_dense_rows(_as_int64(values._flat_data()), values.offsets(), len(values), n_bins)
+    return EncodedCounts(alphabet, hist.host().reshape(len(values), n_bins).copy())
+
+
+def _flat_store(values):
+    if isinstance(values, EncodedRaggedArray):
+        values._compact()
+        return values._flat_data()
+    return values._harray()
+
+
+def _as_int64(store):
+    if store.dtype == np.int64:
+        return store
+    return HArray(host=store.host().astype(np.int64))     # letters (uint8 codes): tiny convenience inputs

@@ -1,0 +1,78 @@
+"""KmerIndex / KmerLookup (bionumpy/sequence/indexing/kmer_indexing.py:7-76) on the MI355X path.
+
+The reference loops over every distinct k-mer with an O(U*N) numpy scan; here the index is the
+sorted, de-duplicated (kmer, row) pair list built by one radix sort on the device, and a lookup is a
+pair of binary searches (``bnpk_search_sorted``) — same answers: the ascending row ids that contain
+the k-mer, ``[]`` for an unseen k-mer.
+"""
+import numpy as np
+
+from ...device import HArray
+from ...encoded_array import as_encoded_array
+from ...ops import get_ops
+from ..kmers import get_kmers
+
+
+class KmerIndex:
+    def __init__(self, k, pair_keys, pair_rows, sequences_encoding):
+        self._k = k
+        self._keys = pair_keys          # HArray int64, sorted (kmer of every distinct (kmer,row) pair)
+        self._rows = pair_rows          # HArray int64, row ids, ascending within a kmer
+        self._sequences_encoding = sequences_encoding
+
+    def __repr__(self):
+        return "%d-merIndex of sequences with %s" % (self._k, self._sequences_encoding)
+
+    @property
+    def k(self):
+        return self._k
+
+    @classmethod
+    def create_index(cls, sequences, k):
+        ops = get_ops()
+        kmers = get_kmers(sequences, k)
+        kmers._compact()
+        rows = ops.row_ids(kmers.offsets(), len(kmers), kmers.total())
+        keys, rows = ops.unique_pairs(kmers._flat_data(), rows, key_bits=2 * k)
+        return cls(k, keys, rows, sequences.encoding)
+
+    def _encode_query(self, kmer):
+        if isinstance(kmer, str):
+            assert len(kmer) == self._k
+            return int(get_kmers(as_encoded_array(kmer, self._sequences_encoding), self._k).raw()[0])
+        return int(kmer)
+
+    def get_indices_batch(self, kmers):
+        """(lo, hi) ranges into the pair list for many int k-mers at once (device binary searches)"""
+        ops = get_ops()
+        q = kmers if isinstance(kmers, HArray) else HArray(host=np.asarray(kmers, dtype=np.int64))
+        lo = ops.search_sorted(self._keys, q, upper=False)
+        hi = ops.search_sorted(self._keys, q, upper=True)
+        return lo, hi
+
+    def get_indices(self, kmer):
+        lo, hi = self.get_indices_batch(np.array([self._encode_query(kmer)], dtype=np.int64))
+        lo, hi = int(lo.host()[0]), int(hi.host()[0])
+        if hi == lo:
+            return []
+        return self._rows.host()[lo:hi]
+
+
+class KmerLookup:
+    index_class = KmerIndex
+
+    def __init__(self, kmer_index, sequences):
+        self._kmer_index = kmer_index
+        self._sequences = sequences
+
+    def __repr__(self):
+        return "Lookup on %d-merIndex of %d sequences" % (self._kmer_index.k, len(self._sequences))
+
+    @classmethod
+    def create_lookup(cls, sequences, *args, **kwargs):
+        index = cls.index_class.create_index(sequences, *args, **kwargs)
+        return cls(index, sequences)
+
+    def get_sequences(self, kmer):
+        idx = self._kmer_index.get_indices(kmer)
+        return self._sequences[np.asarray(idx, dtype=np.int64)]

@@ -1,0 +1,96 @@
+"""get_kmers / count_kmers on the MI355X path (bionumpy/sequence/kmers.py:36-145).
+
+``get_kmers`` keeps the reference's signature and result type: an ``EncodedRaggedArray`` of int64
+hashes tagged ``KmerEncoding(DNAEncoding, k)``; row r holds max(0, L_r - k + 1) hashes with the first
+base in the least significant 2 bits.  The hashes are produced by the rolling 2-bit kernel
+(``bnpk_kmers``) straight from the packed reads in HBM and stay there until ``.raw()`` is asked for.
+"""
+import logging
+
+from ..encoded_array import (EncodedArray, EncodedRaggedArray, BaseEncoding, DNAEncoding, AlphabetEncoding,
+                             change_encoding, as_encoded_array, packed_words)
+from ..encodings.kmer_encodings import KmerEncoding
+from ..exceptions import EncodingError
+from ..ops import get_ops
+from ..streams import streamable
+from .count_encoded import count_encoded
+
+logger = logging.getLogger(__name__)
+
+
+def _as_dna_ragged(sequence):
+    """(packed words, in_offsets, lens, n_rows, total) of a DNA-encoded array, all HBM-resident"""
+    if isinstance(sequence, EncodedArray):                   # a single sequence == one row
+        sequence = EncodedRaggedArray(sequence.ravel(), [sequence.size])
+    sequence._compact()
+    return packed_words(sequence._data), sequence.offsets(), sequence._lens, len(sequence), sequence.total()
+
+
+def _rolling(sequence, window, kernel):
+    """shared skeleton of get_kmers / get_minimizers: trimmed output offsets + one kernel launch"""
+    ops = get_ops()
+    single = isinstance(sequence, EncodedArray)
+    packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
+    out_off, n_out = ops.row_offsets(lens, window)
+    values = kernel(ops, packed, in_off, out_off, n_rows, n_out)
+    return values, out_off, lens, n_rows, n_out, single
+
+
+def get_kmers(sequence, k):
+    """k-mer hashes of every position of every sequence (sequence/kmers.py:36-87)."""
+    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    if sequence.encoding == BaseEncoding:
+        try:
+            sequence = change_encoding(sequence, DNAEncoding)
+        except EncodingError:
+            logging.error("Tried to change encoding of sequences to DNAEncoding, but failed. "
+                          "Make sure your sequences are valid DNA, only containing A, C, G, and T")
+            raise
+    assert isinstance(sequence.encoding, AlphabetEncoding), \
+        "Sequence needs to be encoded with an AlphabetEncoding, e.g. DNAEncoding. " \
+        "Change encoding of your sequences by using e.g. bnp.change_encoding(sequences, bnp.DNAEncoding)"
+    if sequence.encoding.alphabet_size != 4:
+        raise NotImplementedError("only 4-letter alphabets (the 2-bit fast path, kmers.py:82-85) are on the "
+                                  "MI355X path")
+    hashes, out_off, lens, n_rows, n_out, single = _rolling(
+        sequence, k, lambda ops, p, i, o, n, m: ops.kmers(p, i, o, n, m, k))
+    encoding = KmerEncoding(sequence.encoding, k)
+    if single:
+        return EncodedArray(hashes, encoding)
+    new_lens = _trimmed_lens(out_off, lens, k)
+    return EncodedRaggedArray._from_parts(hashes, None, new_lens, out_off, n_rows, n_out, encoding)
+
+
+def _trimmed_lens(out_off, lens, window):
+    """row lengths after the trim, derived lazily from the offsets"""
+    return _LazyLens(out_off) if window > 1 else lens
+
+
+class _LazyLens:
+    """int64 row lengths = diff(offsets); only materialised (on the host) when somebody asks"""
+
+    def __init__(self, offsets):
+        self._offsets = offsets
+        self._np = None
+
+    @property
+    def size(self):
+        return self._offsets.size - 1
+
+    def host(self):
+        if self._np is None:
+            import numpy as np
+            self._np = np.diff(self._offsets.host())
+        return self._np
+
+    def dev(self):
+        from ..device import HArray
+        return HArray(host=self.host()).dev()
+
+
+@streamable(sum)
+def count_kmers(sequence, k, axis=None):
+    """count every k-mer (sequence/kmers.py:129-145); k <= 8 gives the reference's dense EncodedCounts,
+    larger k the sparse (sorted unique keys, counts) extension — see count_encoded."""
+    kmers = get_kmers(sequence, k)
+    return count_encoded(kmers, axis=axis)

@@ -1,0 +1,26 @@
+"""get_minimizers on the MI355X path (bionumpy/sequence/minimizers.py:8-54).
+
+For every window of ``window_size`` bases the minimum raw (LSB-first) hash among its
+window_size - k + 1 k-mers; one value per window position, no dedup; row r keeps
+max(0, L_r - window_size + 1) values.  One kernel (``bnpk_minimizers``) reads the packed reads and
+writes the minimizers; the reference's N*w*k intermediate never exists.
+"""
+from ..encoded_array import EncodedArray, EncodedRaggedArray, AlphabetEncoding
+from ..encodings.kmer_encodings import KmerEncoding
+from .kmers import _rolling, _trimmed_lens
+
+
+def get_minimizers(sequence, k, window_size):
+    assert isinstance(sequence.encoding, AlphabetEncoding), \
+        "Sequence needs to be encoded with an AlphabetEncoding, e.g. DNAEncoding"
+    assert k <= window_size, "kmer size must be smaller than window size"
+    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    if sequence.encoding.alphabet_size != 4:
+        raise NotImplementedError("only 4-letter alphabets are on the MI355X path")
+    values, out_off, lens, n_rows, n_out, single = _rolling(
+        sequence, window_size, lambda ops, p, i, o, n, m: ops.minimizers(p, i, o, n, m, k, window_size))
+    encoding = KmerEncoding(sequence.encoding, k)
+    if single:
+        return EncodedArray(values, encoding)
+    return EncodedRaggedArray._from_parts(values, None, _trimmed_lens(out_off, lens, window_size), out_off, n_rows,
+                                          n_out, encoding)

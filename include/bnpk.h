@@ -1,0 +1,217 @@
+/*
+ * bnpk.h — C-ABI of the MI355X (gfx950) sequence hot path: FASTQ/FASTA chunk decode ->
+ * 2-bit DNA -> k-mer / minimizer hash -> count / index.
+ *
+ * The reference (bionumpy v1.0.14, pure Python on numpy + npstructures) has no FFI for this
+ * path; its only backend seam is the `bnp.set_backend(cupy)` monkey-patch
+ * (bionumpy/__init__.py:47-94, bionumpy/cupy_compatible/parser.py:10-17), which puts the
+ * host/device boundary at the raw uint8 chunk.  This header puts the boundary at the same
+ * place and declares one entry point per numpy expression the path is built from; each
+ * declaration cites the reference expression (file:line) it replaces.  The Python host side
+ * (bionumpy_amd/) binds these with ctypes; see INTEGRATION.md for the stub a bionumpy
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (BNPK_OK) or a negative bnpk_status; nothing throws across the ABI
+ *   - `d_` pointers are device (HBM) pointers, `h_` pointers are host pointers; the caller owns
+ *     every buffer (the Python side allocates HBM through torch, pinned host memory through
+ *     bnpk_host_alloc); the library keeps only a small grow-only scratch arena inside the ctx
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *     asynchronous on that stream unless documented otherwise
+ *   - byte buffers handed to the scanners must be 16-byte aligned (any torch allocation is)
+ *   - one ctx per GPU per host thread
+ */
+#ifndef BNPK_H
+#define BNPK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bnpk_ctx bnpk_ctx;
+
+typedef enum {
+  BNPK_OK = 0,
+  BNPK_ERR_ARG = -1,        /* bad argument (null pointer, k out of range, ...) */
+  BNPK_ERR_ALIGN = -2,      /* device byte buffer not 16-byte aligned */
+  BNPK_ERR_HIP = -3,        /* a HIP runtime call failed; see bnpk_last_hip_error */
+  BNPK_ERR_NOMEM = -4,      /* scratch arena / workspace too small or allocation failed */
+  BNPK_ERR_NODEVICE = -5,   /* no gfx950 device visible */
+  BNPK_ERR_RANGE = -6       /* size exceeds what the entry point supports */
+} bnpk_status;
+
+#define BNPK_NONE INT64_MAX   /* "no error found" value of the d_err outputs below */
+
+/* ---- lifecycle / diagnostics --------------------------------------------------------- */
+int         bnpk_version(void);
+const char* bnpk_strerror(int status);
+int         bnpk_device_count(void);
+int         bnpk_ctx_create(int device, bnpk_ctx** out);
+void        bnpk_ctx_destroy(bnpk_ctx* ctx);
+const char* bnpk_last_hip_error(bnpk_ctx* ctx);
+/* name (<=63 chars), compute units, total HBM bytes of the ctx's device */
+int         bnpk_device_info(bnpk_ctx* ctx, char* name64, int* compute_units, int64_t* hbm_bytes);
+
+/* per-kernel hipEvent timers (used by bench.py for the live roofline numbers) */
+int bnpk_prof_enable(bnpk_ctx* ctx, int on);
+int bnpk_prof_reset(bnpk_ctx* ctx);
+int bnpk_prof_count(bnpk_ctx* ctx);                 /* resolves pending events (synchronises) */
+int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t* launches);
+
+/* ---- host staging: pinned buffers and async copies ----------------------------------- */
+/* replaces np.frombuffer(file.read(n)) + cp.asanyarray(chunk)
+ * (bionumpy/io/parser.py:203-206, bionumpy/cupy_compatible/parser.py:11-17) */
+int bnpk_host_alloc(size_t bytes, void** h_out);
+int bnpk_host_free(void* h_ptr);
+int bnpk_copy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
+int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
+int bnpk_stream_sync(void* stream);
+
+/* ---- A2: newline scan ------------------------------------------------------------------
+ * replaces `np.flatnonzero(chunk == NEWLINE)` (bionumpy/io/one_line_buffer.py:63,
+ * bionumpy/io/multiline_buffer.py:93) as a two-pass tile census + ordered compaction. */
+int64_t bnpk_scan_tiles(int64_t n_bytes);           /* number of tiles the census uses */
+/* pass 1: d_tile_offsets[0..tiles] = exclusive scan of per-tile match counts (total at [tiles]) */
+int bnpk_byte_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t value,
+                     int64_t* d_tile_offsets, void* stream);
+/* pass 2: d_pos[j] = position of the j-th byte equal to `value` (ascending), j < limit */
+int bnpk_byte_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t value,
+                        const int64_t* d_tile_offsets, int64_t limit, int64_t* d_pos, void* stream);
+
+/* ---- A3: record validation ------------------------------------------------------------
+ * replaces OneLineBuffer._validate + FastQBuffer._validate
+ * (bionumpy/io/one_line_buffer.py:156-173, bionumpy/io/fastq_buffer.py:39-45).
+ * n_lines must be a multiple of lines_per_entry.  d_err[0] = first entry whose header line does
+ * not start with `header` (BNPK_NONE if none; reference line_number = entry*lines_per_entry),
+ * d_err[1] = first entry whose third line does not start with '+' (only if check_plus;
+ * line_number = 2 + entry*lines_per_entry), d_err[2] = 1 if one of the first lines_per_entry
+ * header lines ends in '\r' (_modify_for_carriage_return, one_line_buffer.py:176-182). */
+int bnpk_validate_entries(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines,
+                          int64_t n_lines, int lines_per_entry, uint8_t header, int check_plus,
+                          int64_t* d_err3, void* stream);
+
+/* ---- A4/A5: field table ----------------------------------------------------------------
+ * replaces OneLineBuffer._get_buffer_extractor + TextBufferExtractor.get_field_by_number
+ * (bionumpy/io/one_line_buffer.py:140-152, bionumpy/io/file_buffers.py:315-338): start and
+ * length of line `field` of every entry (+line_offset on the start, optional '\r' strip). */
+int bnpk_field_table(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines,
+                     int64_t n_entries, int lines_per_entry, int field, int line_offset,
+                     int strip_cr, int64_t* d_starts, int64_t* d_lens, void* stream);
+
+/* ---- ragged offsets ----------------------------------------------------------------------
+ * replaces npstructures RaggedShape (starts = cumsum(lengths) - lengths):
+ * d_offsets[0..n] = exclusive scan of d_lens (d_offsets[n] = total).  If window > 1 the scanned
+ * value is max(0, len - (window-1)): the row lengths after `ragged[..., :-(window-1)]`
+ * (bionumpy/sequence/kmers.py:100, bionumpy/sequence/rollable.py:66). */
+int bnpk_row_offsets(bnpk_ctx* ctx, const int64_t* d_lens, int64_t n, int window,
+                     int64_t* d_offsets, void* stream);
+
+/* ---- A6 + A7: ragged gather + ASCII -> DNA code ------------------------------------------
+ * replaces EncodedRaggedArray.ravel() of the RaggedView (bionumpy/encoded_array.py:688-690) fused
+ * with AlphabetEncoding._encode for 'ACGT' (bionumpy/encodings/alphabet_encoding.py:19-46):
+ * A/a C/c G/g T/t -> 0 1 2 3, anything else is an error; *d_err_offset = smallest flat offset of
+ * an invalid byte (EncodingError.offset) or BNPK_NONE (caller initialises it to BNPK_NONE via
+ * bnpk_fill_i64).  Row r is d_buf[d_starts[r] .. +len) and lands at flat offset d_offsets[r].
+ * d_codes (1 byte/base, the reference layout) and d_packed (2 bits/base, 32 bases per uint64,
+ * base i at bits 2*(i%32) of word i/32 == npstructures BitArray.pack(.., bit_stride=2),
+ * bionumpy/sequence/kmers.py:121) are both optional; d_packed needs total/32 + 2 words. */
+int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
+                           const int64_t* d_offsets, int64_t n_rows, int64_t total,
+                           uint8_t* d_codes, uint64_t* d_packed, int64_t* d_err_offset,
+                           void* stream);
+/* plain ragged gather with an optional constant subtracted (33 -> QualityEncoding,
+ * bionumpy/encodings/__init__.py:15-16,26; 0 -> names / raw text) */
+int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
+                     const int64_t* d_offsets, int64_t n_rows, int64_t total, int subtract,
+                     uint8_t* d_out, void* stream);
+/* d_out[i] = d_buf[d_pos[i] + delta]: the strided byte gathers `chunk[new_lines + 1]` of
+ * MultiLineFastaBuffer (bionumpy/io/multiline_buffer.py:37-38,93-94) */
+int bnpk_take_bytes(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_pos, int64_t m, int64_t delta,
+                    uint8_t* d_out, void* stream);
+/* ASCII -> code over a flat array (no gather), same error rule */
+int bnpk_encode_dna_flat(bnpk_ctx* ctx, const uint8_t* d_ascii, int64_t n, uint8_t* d_codes,
+                         uint64_t* d_packed, int64_t* d_err_offset, void* stream);
+/* codes (1 B/base) <-> packed 2-bit words; codes -> ASCII ('ACGT'[code], _decode :48-51) */
+int bnpk_pack_codes(bnpk_ctx* ctx, const uint8_t* d_codes, int64_t n, uint64_t* d_packed, void* stream);
+int bnpk_unpack_codes(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n, int to_ascii,
+                      uint8_t* d_out, void* stream);
+
+/* ---- A8: 2-bit k-mer hashes ------------------------------------------------------------------
+ * replaces _get_dna_kmers + the ragged trim (bionumpy/sequence/kmers.py:90-126): for row r and
+ * i < max(0, L_r-k+1): d_hashes[d_out_offsets[r] + i] = sum_{j<k} code[d_in_offsets[r]+i+j] << 2j
+ * (first base = least significant, tests/test_kmer.py:85-94).  0 < k < 32.
+ * d_out_offsets = bnpk_row_offsets(lens, window=k). */
+int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
+               const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
+               int64_t* d_hashes, void* stream);
+
+/* ---- A11: minimizers -----------------------------------------------------------------------------
+ * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every
+ * window of `window_size` bases the minimum raw hash of its window_size-k+1 k-mers.
+ * d_out_offsets = bnpk_row_offsets(lens, window=window_size). */
+int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
+                    const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
+                    int window_size, int64_t* d_out, void* stream);
+
+/* ---- A9: counting ---------------------------------------------------------------------------------
+ * dense: replaces np.bincount(values, minlength=4^k) of count_encoded
+ * (bionumpy/sequence/count_encoded.py:166-177); d_hist (n_bins int64) is ACCUMULATED into, so the
+ * sum over chunks (EncodedCounts.__add__, count_encoded.py:41-55) is the same buffer. */
+int bnpk_count_dense(bnpk_ctx* ctx, const int64_t* d_values, int64_t n, int64_t n_bins,
+                     int64_t* d_hist, void* stream);
+/* per-row dense counts (count_encoded(axis=-1) on a ragged array, count_encoded.py:178-182):
+ * d_hist is [n_rows, n_bins] int64, zero-initialised by the caller */
+int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t* d_offsets,
+                          int64_t n_rows, int64_t n, int64_t n_bins, int64_t* d_hist, void* stream);
+
+/* sparse (k > 8 has no reference implementation; defined as np.unique(h, return_counts=True),
+ * SURVEY.md §3.5): step 1 sorts the keys (d_alt is an n-element ping-pong buffer; only bits
+ * [0, key_bits) are sorted; *h_in_alt = 1 if the sorted keys ended up in d_alt, known on the host
+ * without a synchronisation), step 2 counts distinct keys (synchronous: returns the count
+ * through h_n_unique), step 3 writes sorted unique keys + run lengths. */
+int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int key_bits,
+                   int* h_in_alt, void* stream);
+int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t* d_vals,
+                    int64_t* d_vals_alt, int64_t n, int key_bits, int* h_in_alt, void* stream);
+/* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */
+int64_t bnpk_run_tiles(int64_t n);
+int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,
+                    int64_t* d_tile_offsets, int64_t* h_n_runs, void* stream);
+/* d_run_starts[j] = index of the first element of run j (n_runs+1 entries, last = n);
+ * d_keys_out[j] = d_sorted[start]; optional d_second_out[j] = d_second[start] */
+int bnpk_run_heads(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,
+                   const int64_t* d_tile_offsets, int64_t n_runs, int64_t* d_keys_out,
+                   int64_t* d_second_out, int64_t* d_run_starts, void* stream);
+/* d_counts[j] = sum of weights over run j (d_weight_prefix = exclusive scan of the weights,
+ * n+1 entries) or, with d_weight_prefix NULL, the run length */
+int bnpk_run_sums(bnpk_ctx* ctx, const int64_t* d_run_starts, int64_t n_runs,
+                  const int64_t* d_weight_prefix, int64_t* d_counts, void* stream);
+int bnpk_exclusive_scan_i64(bnpk_ctx* ctx, const int64_t* d_in, int64_t n, int64_t* d_out, void* stream);
+
+/* ---- A12: k-mer index helpers ------------------------------------------------------------------------
+ * row id of every flat element of a ragged array (np.repeat(arange(n_rows), lens)); with the sorted
+ * (kmer,row) pairs, run census on pairs and lower/upper bound this rebuilds
+ * KmerIndex.create_index / get_indices (bionumpy/sequence/indexing/kmer_indexing.py:24-55). */
+int bnpk_row_ids(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t n,
+                 int64_t* d_rows, void* stream);
+/* d_out[i] = first index j with d_sorted[j] >= q (upper=0) or > q (upper=1) */
+int bnpk_search_sorted(bnpk_ctx* ctx, const int64_t* d_sorted, int64_t n, const int64_t* d_queries,
+                       int64_t m, int upper, int64_t* d_out, void* stream);
+
+/* ---- utilities ------------------------------------------------------------------------------------------ */
+int bnpk_fill_i64(bnpk_ctx* ctx, int64_t* d_ptr, int64_t n, int64_t value, void* stream);
+/* synthetic FASTQ (bench/test input; record = "@%010d\n" + L bases + "\n+\n" + L*'I' + "\n").
+ * mode 0: bases i.i.d. uniform (the reference's own generator, benchmarks/rules/simulation.smk:3-11);
+ * mode 1: reads sampled from a fixed pseudo-random genome of genome_len bases.
+ * Bytes are a pure function of (seed, read id, position) — see bionumpy_amd/synth.py. */
+int64_t bnpk_synth_record_bytes(int read_len);
+int bnpk_synth_fastq(bnpk_ctx* ctx, uint8_t* d_out, int64_t first_read, int64_t n_reads, int read_len,
+                     uint64_t seed, int mode, int64_t genome_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNPK_H */

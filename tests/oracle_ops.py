@@ -1,0 +1,164 @@
+"""TEST-ONLY stand-in for bionumpy_amd.ops.HipOps backed by the CPU oracle.
+
+Lets the CPU-only suite (-m "not gpu") drive the *host logic* of bionumpy_amd (chunk loop, lazy
+chunk objects, ragged/encoded array classes, exception mapping, API surface) without a GPU.  It is
+never importable from the product package and never used on the GPU box: the -m gpu tests run the
+same API tests through the real HIP ops and compare against the oracle's outputs.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+import oracle
+from oracle import text as otext
+from bionumpy_amd.device import HArray
+from bionumpy_amd.exceptions import FormatException, IncompleteEntryException, EncodingError
+
+LineScan = namedtuple("LineScan", "size n_lines n_records newlines has_cr")
+NEWLINE = 10
+
+
+def _h(a):
+    return HArray(host=np.ascontiguousarray(a))
+
+
+def _unpack(packed, n):
+    words = packed.host().view(np.uint64)
+    i = np.arange(n, dtype=np.int64)
+    return ((words[i >> 5] >> (2 * (i & 31)).astype(np.uint64)) & np.uint64(3)).astype(np.uint8)
+
+
+def _pack(codes):
+    n = codes.size
+    out = np.zeros(n // 32 + 2, dtype=np.uint64)
+    w = oracle.pack_2bit(codes)
+    out[:w.size] = w
+    return _h(out.view(np.int64))
+
+
+class OracleOps:
+    # -- decode -----------------------------------------------------------------------------------
+    def newline_positions(self, buf, n, limit_multiple=1):
+        pos = np.flatnonzero(buf.host()[:n] == NEWLINE).astype(np.int64)
+        total = pos.size
+        return _h(pos[:total - total % limit_multiple]), total
+
+    def scan_lines(self, buf, n, lines_per_entry, header, check_plus):
+        fmt = otext.LineFormat(header, lines_per_entry, (0,) * lines_per_entry, check_plus)
+        try:
+            res = oracle.scan_one_line_buffer(buf.host()[:n], fmt)
+        except otext.IncompleteEntryException as e:
+            raise IncompleteEntryException(str(e))
+        except otext.FormatException as e:
+            raise FormatException(str(e), line_number=e.line_number)
+        data = buf.host()
+        nl = res.new_lines
+        ends = nl.reshape(-1, lines_per_entry)
+        has_cr = bool(ends[0, 0] >= 1 and np.any(data[ends[:lines_per_entry, 0] - 1] == 13))
+        return LineScan(res.size, res.n_lines, res.n_records, _h(nl.astype(np.int64)), has_cr)
+
+    def field_table(self, buf, newlines, n_entries, lines_per_entry, field, line_offset, strip_cr):
+        nl = newlines.host()
+        data = buf.host()
+        line_starts = np.concatenate(([0], nl + 1))[:-1].reshape(-1, lines_per_entry)[:, field] + line_offset
+        ends = nl.reshape(-1, lines_per_entry)[:, field]
+        if strip_cr:
+            ends = ends - ((ends >= 1) & (data[np.maximum(ends - 1, 0)] == 13))
+        return _h(line_starts.astype(np.int64)), _h((ends - line_starts).astype(np.int64))
+
+    def take_bytes(self, buf, positions, delta):
+        return _h(buf.host()[positions.host() + delta])
+
+    # -- offsets -----------------------------------------------------------------------------------
+    def row_offsets(self, lens, window=1):
+        l = lens.host().astype(np.int64)
+        if window > 1:
+            l = np.maximum(l - (window - 1), 0)
+        off = np.concatenate(([0], np.cumsum(l))).astype(np.int64)
+        return _h(off), int(off[-1])
+
+    def exclusive_scan(self, values):
+        return _h(np.concatenate(([0], np.cumsum(values.host()))).astype(np.int64))
+
+    # -- encode ------------------------------------------------------------------------------------
+    def _encode(self, ascii_):
+        try:
+            return oracle.encode_dna(ascii_)
+        except otext.EncodingError as e:
+            raise EncodingError(e.message, e.offset)
+
+    def gather_encode_dna(self, buf, starts, offsets, n_rows, total, want_codes=False, want_packed=True):
+        lens = np.diff(offsets.host())
+        codes = self._encode(oracle.gather_rows(buf.host(), starts.host(), lens))
+        return (_h(codes) if want_codes else None, _pack(codes) if want_packed else None)
+
+    def gather_rows(self, buf, starts, offsets, n_rows, total, subtract=0):
+        lens = np.diff(offsets.host())
+        out = oracle.gather_rows(buf.host(), starts.host(), lens)
+        return _h((out.astype(np.int64) - subtract).astype(np.uint8))
+
+    def encode_dna_flat(self, ascii_bytes, want_codes=True, want_packed=True):
+        codes = self._encode(ascii_bytes.host())
+        return (_h(codes) if want_codes else None, _pack(codes) if want_packed else None)
+
+    def pack_codes(self, codes):
+        return _pack(codes.host())
+
+    def unpack_codes(self, packed, n, to_ascii=False):
+        codes = _unpack(packed, n)
+        return _h(oracle.decode_dna(codes) if to_ascii else codes)
+
+    # -- k-mers ------------------------------------------------------------------------------------
+    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
+        off = in_offsets.host()
+        h, _ = oracle.get_kmers(_unpack(packed, int(off[-1])), np.diff(off), k)
+        assert h.size == n_out
+        return _h(h)
+
+    def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
+        off = in_offsets.host()
+        m, _ = oracle.get_minimizers(_unpack(packed, int(off[-1])), np.diff(off), k, window_size)
+        assert m.size == n_out
+        return _h(m)
+
+    # -- counting ----------------------------------------------------------------------------------
+    def count_dense(self, values, n_bins, hist=None):
+        c = np.bincount(values.host(), minlength=n_bins).astype(np.int64)
+        if hist is not None:
+            c = c + hist.host()
+        return _h(c)
+
+    def count_dense_rows(self, values, offsets, n_rows, n_bins):
+        off = offsets.host()
+        v = values.host()
+        return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins) for r in range(n_rows)],
+                           dtype=np.int64).reshape(-1))
+
+    def count_sparse(self, values, key_bits=62, consume=False):
+        k, c = oracle.count_sparse(values.host())
+        return _h(k), _h(c)
+
+    def reduce_by_key(self, keys, weights, key_bits=62):
+        if not isinstance(keys, (list, tuple)):
+            keys, weights = [keys], [weights]
+        k, c = oracle.merge_sparse([(a.host(), b.host()) for a, b in zip(keys, weights)])
+        return _h(k), _h(c)
+
+    def row_ids(self, offsets, n_rows, n):
+        return _h(np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(offsets.host())))
+
+    def unique_pairs(self, keys, values, key_bits=62):
+        pairs = np.unique(np.stack([keys.host(), values.host()], axis=1), axis=0) if keys.size else \
+            np.zeros((0, 2), dtype=np.int64)
+        return _h(pairs[:, 0]), _h(pairs[:, 1])
+
+    def search_sorted(self, sorted_keys, queries, upper=False):
+        return _h(np.searchsorted(sorted_keys.host(), queries.host(), side="right" if upper else "left")
+                  .astype(np.int64))
+
+    def concat(self, arrays):
+        return _h(np.concatenate([a.host() for a in arrays]))
+
+    def synth_fastq(self, n_reads, read_len, seed, mode=0, genome_len=0, first_read=0):
+        from bionumpy_amd import synth
+        return _h(synth.fastq_bytes(n_reads, read_len, seed, mode, genome_len, first_read))

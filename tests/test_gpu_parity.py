@@ -1,0 +1,152 @@
+"""-m gpu: HIP primitives through the C-ABI vs the CPU oracle on seeded inputs, plus size-independent
+properties at larger sizes (bit-exact: everything here is integer / byte work)."""
+import numpy as np
+import pytest
+
+import oracle
+from bionumpy_amd import synth
+from bionumpy_amd.device import HArray
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    return ops_mod.get_ops()
+
+
+def _h(a):
+    return HArray(host=np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 1023, 16384, 16385, 70001, 3_000_001])
+def test_newline_scan_matches_flatnonzero(ops, n):
+    rng = np.random.default_rng(n)
+    buf = rng.integers(0, 40, size=n).astype(np.uint8)          # ~1/40 of the bytes are '\n' (10)
+    if n:
+        buf[-1] = 10
+    pos, total = ops.newline_positions(_h(buf), n, 1)
+    expect = np.flatnonzero(buf == 10)
+    assert total == expect.size and np.array_equal(pos.host(), expect)
+    pos4, total4 = ops.newline_positions(_h(buf), n, 4)
+    assert total4 == expect.size and np.array_equal(pos4.host(), expect[:expect.size - expect.size % 4])
+
+
+@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 2048 * 2048 + 5])
+def test_exclusive_scan(ops, n):
+    rng = np.random.default_rng(n + 7)
+    v = rng.integers(0, 1000, size=n).astype(np.int64)
+    got = ops.exclusive_scan(_h(v)).host()
+    assert np.array_equal(got, np.concatenate(([0], np.cumsum(v))))
+    off, total = ops.row_offsets(_h(v), 31)
+    expect = np.concatenate(([0], np.cumsum(np.maximum(v - 30, 0))))
+    assert total == expect[-1] and np.array_equal(off.host(), expect)
+
+
+@pytest.mark.parametrize("mode,genome_len", [(0, 0), (1, 100_000)])
+def test_synthetic_generator_matches_numpy_twin(ops, mode, genome_len):
+    for n_reads, read_len, first in ((1, 1, 0), (77, 150, 0), (1000, 150, 123456789), (33, 251, 5)):
+        dev = ops.synth_fastq(n_reads, read_len, 20260925, mode, max(genome_len, read_len), first).host()
+        host = synth.fastq_bytes(n_reads, read_len, 20260925, mode, max(genome_len, read_len), first)
+        assert np.array_equal(dev, host)
+
+
+def _random_reads(seed, n_rows, max_len, with_empty=True):
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(0 if with_empty else 1, max_len, size=n_rows).astype(np.int64)
+    text = rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=int(lengths.sum()) + n_rows)
+    # lay the rows out with one junk byte between them so that starts are not contiguous
+    starts = np.concatenate(([0], np.cumsum(lengths[:-1] + 1))).astype(np.int64)
+    return text, starts, lengths
+
+
+@pytest.mark.parametrize("seed,n_rows,max_len", [(0, 1, 5), (1, 1000, 40), (2, 50_000, 300), (3, 17, 200_000)])
+def test_gather_encode_and_kmers(ops, seed, n_rows, max_len):
+    text, starts, lengths = _random_reads(seed, n_rows, max_len)
+    offsets, total = ops.row_offsets(_h(lengths), 1)
+    codes, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=True,
+                                          want_packed=True)
+    expect = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
+    assert np.array_equal(codes.host(), expect)
+    words = oracle.pack_2bit(expect)
+    assert np.array_equal(packed.host().view(np.uint64)[:words.size], words)
+    assert np.array_equal(ops.unpack_codes(packed, total).host(), expect)
+    assert np.array_equal(ops.unpack_codes(packed, total, to_ascii=True).host(), oracle.decode_dna(expect))
+    assert np.array_equal(ops.pack_codes(codes).host()[:words.size].view(np.uint64), words)
+    plain = ops.gather_rows(_h(text), _h(starts), offsets, n_rows, total, 0)
+    assert np.array_equal(plain.host(), oracle.gather_rows(text, starts, lengths))
+    for k in (1, 3, 31):
+        out_off, n_out = ops.row_offsets(_h(lengths), k)
+        got = ops.kmers(packed, offsets, out_off, n_rows, n_out, k).host()
+        h, hl = oracle.get_kmers(expect, lengths, k)
+        assert np.array_equal(got, h)
+    if total < 3_000_000:
+        for k, w in ((2, 4), (31, 40)):
+            out_off, n_out = ops.row_offsets(_h(lengths), w)
+            got = ops.minimizers(packed, offsets, out_off, n_rows, n_out, k, w).host()
+            m, _ = oracle.get_minimizers(expect, lengths, k, w)
+            assert np.array_equal(got, m)
+
+
+def test_encoding_error_offset_is_first_bad_byte(ops):
+    from bionumpy_amd.exceptions import EncodingError
+    text, starts, lengths = _random_reads(11, 2000, 100, with_empty=False)
+    offsets, total = ops.row_offsets(_h(lengths), 1)
+    flat_idx = np.sort(np.random.default_rng(1).choice(total, size=5, replace=False))
+    row_of = np.searchsorted(np.cumsum(lengths), flat_idx, side="right")
+    off_host = offsets.host()
+    for f, r in zip(flat_idx, row_of):
+        text[starts[r] + (f - off_host[r])] = ord("N")
+    with pytest.raises(EncodingError) as e:
+        ops.gather_encode_dna(_h(text), _h(starts), offsets, len(lengths), total)
+    assert e.value.offset == int(flat_idx[0])
+
+
+@pytest.mark.parametrize("k", [1, 3, 6, 7, 8, 10])
+def test_dense_counts(ops, k):
+    rng = np.random.default_rng(k)
+    v = rng.integers(0, 4 ** k, size=1_234_567).astype(np.int64)
+    got = ops.count_dense(_h(v), 4 ** k).host()
+    assert np.array_equal(got, np.bincount(v, minlength=4 ** k))
+    twice = ops.count_dense(_h(v), 4 ** k, HArray(dev=ops.count_dense(_h(v), 4 ** k).dev())).host()
+    assert np.array_equal(twice, 2 * got)                       # accumulation == EncodedCounts.__add__
+
+
+def test_sparse_counts_and_merge(ops):
+    rng = np.random.default_rng(42)
+    v = (rng.integers(0, 300_000, size=2_000_003).astype(np.int64) * 7919) & ((1 << 62) - 1)
+    keys, counts = ops.count_sparse(_h(v), key_bits=62)
+    ek, ec = oracle.count_sparse(v)
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+    halves = [ops.count_sparse(_h(v[:900_000])), ops.count_sparse(_h(v[900_000:]))]
+    mk, mc = ops.reduce_by_key([h[0] for h in halves], [h[1] for h in halves])
+    assert np.array_equal(mk.host(), ek) and np.array_equal(mc.host(), ec)
+    lo = ops.search_sorted(keys, _h(ek[::1000]), upper=False).host()
+    assert np.array_equal(lo, np.arange(0, ek.size, 1000))
+
+
+def test_full_path_properties_at_scale(ops):
+    """1M synthetic reads (316 MB of FASTQ): size-independent properties of the whole path"""
+    import bionumpy_amd as bnp
+    n_reads, read_len, k = 1_000_000, 150, 31
+    text = ops.synth_fastq(n_reads, read_len, 99, mode=1, genome_len=2_000_000)
+    buf = bnp.FastQBuffer.from_raw_buffer(text)
+    assert len(buf) == n_reads and buf.size == n_reads * 316
+    seqs = bnp.change_encoding(buf.get_field_by_number(1), bnp.DNAEncoding)
+    kmers = bnp.get_kmers(seqs, k)
+    assert kmers.total() == n_reads * (read_len - k + 1)
+    counts = bnp.count_encoded(kmers, axis=None)
+    keys, cnt = counts.keys, counts.counts
+    assert int(cnt.sum()) == kmers.total()                       # every k-mer counted once
+    assert np.all(np.diff(keys) > 0)                              # sorted, distinct
+    assert keys.size <= 2 * 2_000_000                             # bounded by the genome's k-mers
+    again = bnp.sequence.SparseKmerCounts(counts.encoding, *ops.count_sparse(HArray(host=keys), 62))
+    assert np.array_equal(again.keys, keys) and np.all(again.counts == 1)     # idempotence
+    # first 2000 reads bit-exact against the oracle
+    sample = text.host()[:2000 * 316]
+    res = oracle.scan_one_line_buffer(sample, oracle.FASTQ)
+    codes = oracle.encode_dna(oracle.gather_rows(sample, res.field_starts[:, 1], res.field_lens[:, 1]))
+    h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], k)
+    assert np.array_equal(kmers._flat_data().dev()[:h.size].cpu().numpy(), h)
