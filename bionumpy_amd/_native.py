@@ -23,6 +23,11 @@ if not os.path.exists(LIB_PATH):
         "bionumpy_amd: %s is missing. Build it with `python -m bionumpy_amd.csrc.build` "
         "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
 
+# torch bundles its own libamdhip64.so.7; it must be the first HIP runtime in the process (loading the
+# system one first leaves torch.cuda unusable), so import torch before dlopen-ing libbnpk.so, whose
+# libamdhip64.so.7 dependency then resolves to the runtime torch already loaded.
+import torch  # noqa: E402,F401
+
 lib = C.CDLL(LIB_PATH)
 
 _p = C.c_void_p
