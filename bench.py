@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py — FASTQ -> k-mer histogram throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path (newline scan + validation, field table, ragged gather + 2-bit
+encode, 31-mer hashes, sort + run-length histogram; for N > 1 plus the key-range all-to-all over RCCL)
+over one HBM-resident batch of synthetic FASTQ: ``--reads`` reads of ``--read-len`` bp PER GPU (weak
+scaling; default 50 M x 150 bp = BASELINE config 2, 15.8 GB of text, 7.5 Gbases, 6.0 G 31-mers per GPU).
+The input is generated on the device before the timed region; nothing is cached between steps.
+
+Rank 0 prints ONE JSON line: value = Gbases/s of the whole job (all GPUs), plus
+  roofline     — the dominant kernel of the step: algorithmic bytes per launch / its hipEvent-measured
+                 average launch duration vs the 8 TB/s HBM peak (DESIGN.md §5 states the byte model)
+  cpu_baseline — the numpy oracle (a statement-by-statement port of the reference's numpy path, which
+                 cannot be imported here: npstructures is absent) timed on a bounded sample of the same
+                 reads on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+# algorithmic HBM bytes per launch of each kernel, as a function of the batch
+def algorithmic_bytes(name, s, read_len, k):
+    n, bases, kmers, text = s.n_reads, s.n_bases, s.n_kmers, s.n_bytes
+    return {
+        "byte_census": text,                                  # read the text once
+        "byte_positions": text + 8 * 4 * n,                   # read it again, write 4 newline offsets/read
+        "validate_entries": 2 * 8 * n + 2 * n,                # two offsets + two probe bytes per read
+        "field_table": 2 * 8 * n + 2 * 8 * n,                 # two offsets in, start+len out
+        "row_offsets": 8 * n + 8 * n,                         # lens in, offsets out
+        "gather_encode_dna": bases + 16 * n + bases / 4,      # sequence bytes + start/offset + packed out
+        "kmers": bases / 4 + 16 * n + 8 * kmers,              # packed in, offsets, 8 B per k-mer out
+        "sort_keys": 16 * kmers,                              # read every key once, write it once sorted
+        "partition_keys": 16 * kmers,
+        "run_census": 8 * kmers,                              # read sorted keys
+        "run_heads": 8 * kmers + 16 * kmers,                  # read keys, write key + run start (all distinct)
+        "run_sums": 16 * kmers,
+        "count_dense_lds": 8 * kmers,
+        "count_dense_global": 8 * kmers,
+    }.get(name)
+
+
+def cpu_baseline(host_text, k, budget_s=20.0):
+    """the oracle (numpy port of the reference path) on a bounded sample of the same reads, 1 thread"""
+    import numpy as np
+    import oracle
+    t0 = time.perf_counter()
+    res = oracle.scan_one_line_buffer(host_text, oracle.FASTQ)
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    codes = oracle.encode_dna(oracle.gather_rows(host_text, starts, lens))
+    h, _ = oracle.get_kmers(codes, lens, k)
+    if k <= 8:
+        oracle.count_dense(h, k)
+    else:
+        oracle.count_sparse(h)
+    dt = time.perf_counter() - t0
+    return {"value": float(codes.size / dt / 1e9), "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": "%d reads x %d bp of the same synthetic FASTQ (%.1f s of numpy: flatnonzero scan, "
+                      "ragged gather, LUT encode, BitArray pack+sliding_window, np.unique)"
+                      % (res.n_records, int(lens[0]) if len(lens) else 0, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=50_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--mode", choices=["uniform", "genome"], default="uniform")
+    ap.add_argument("--genome-len", type=int, default=100_000_000)
+    ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bionumpy_amd.device import Device, HArray
+    from bionumpy_amd.ops import get_ops
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    ops = get_ops()
+    dev = Device.get()
+    mode = 0 if args.mode == "uniform" else 1
+
+    # ---- input: generated on the device, resident in HBM before the timed region ------------------------
+    text = ops.synth_fastq(args.reads, args.read_len, args.seed, mode, args.genome_len, first_read=rank * args.reads)
+    dev.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        hist, stats = fastq_kmer_histogram(text, args.k)
+        return hist, stats
+
+    stats = None
+    for _ in range(args.warmup):
+        hist, stats = step()
+        del hist
+    barrier()
+    dev.prof_enable(True)
+    dev.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hist, stats = step()
+        if _ != args.steps - 1:
+            del hist
+    barrier()
+    dt = time.perf_counter() - t0
+    dev.prof_enable(False)
+    prof = dev.prof_report()
+
+    # ---- sanity on the last step's result (outside the timed region) ----------------------------------------
+    if isinstance(hist, tuple):
+        keys, counts = hist
+        total_counted = int(counts.dev().sum().item())
+        n_distinct = keys.size
+        sorted_ok = bool((keys.dev()[1:] > keys.dev()[:-1]).all().item()) if n_distinct > 1 else True
+    else:
+        total_counted = int(hist.dev().sum().item())
+        n_distinct = int((hist.dev() > 0).sum().item())
+        sorted_ok = True
+    counted = torch.tensor([total_counted, stats.n_kmers], dtype=torch.int64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counted)                     # range-partitioned histogram: totals must match globally
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if args.k > 13 or world == 1:
+        assert int(counted[0]) == int(counted[1]), "histogram does not account for every k-mer: %s" % counted
+    assert sorted_ok, "sparse histogram keys are not strictly increasing"
+    dt = float(tmax.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    if args.verify:
+        import oracle
+        m = min(args.reads, 2000)
+        sample = text.dev()[:m * (2 * args.read_len + 16)].cpu().numpy()
+        sub, _ = fastq_kmer_histogram(HArray(host=sample), args.k)
+        res = oracle.scan_one_line_buffer(sample, oracle.FASTQ)
+        codes = oracle.encode_dna(oracle.gather_rows(sample, res.field_starts[:, 1], res.field_lens[:, 1]))
+        h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], args.k)
+        ek, ec = oracle.count_sparse(h)
+        assert np.array_equal(sub[0].host(), ek) and np.array_equal(sub[1].host(), ec), "verify failed"
+
+    gbases = world * stats.n_bases * args.steps / dt / 1e9
+    # dominant kernel and its roofline
+    dom = max(prof, key=lambda kname: prof[kname]["total_ms"]) if prof else None
+    roofline = None
+    kernels = {}
+    for name, p in prof.items():
+        avg_ms = p["total_ms"] / max(p["launches"], 1)
+        b = algorithmic_bytes(name, stats, args.read_len, args.k)
+        kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
+                         "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
+    if dom is not None:
+        p = prof[dom]
+        avg_ms = p["total_ms"] / max(p["launches"], 1)
+        b = algorithmic_bytes(dom, stats, args.read_len, args.k)
+        achieved = b / (avg_ms * 1e-3) / 1e9 if b else None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "avg_launch_ms": round(avg_ms, 3),
+                    "algorithmic_bytes_per_launch": b}
+    out = {
+        "metric": "Gbases/s FASTQ->k-mer count (k=%d)" % args.k,
+        "value": round(gbases, 4), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+        "config": {"workload": "synthetic %dbp x %d reads/GPU FASTQ (%s), k=%d get_kmers+count on %dxMI355X"
+                               % (args.read_len, args.reads, args.mode, args.k, world),
+                   "reads_per_gpu": args.reads, "read_len": args.read_len, "k": args.k, "mode": args.mode,
+                   "kmers_per_gpu": stats.n_kmers, "distinct_rank0": n_distinct,
+                   "histogram": "dense" if args.k <= 13 else "sparse (sorted unique int64 keys + counts)",
+                   "parallelism": "chunk-sharded x%d%s" % (world, ", key-range all-to-all" if world > 1 else "")},
+        "roofline": roofline,
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        m = min(args.reads, args.cpu_sample_reads)
+        sample = text.dev()[:m * (2 * args.read_len + 16)].cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(sample, args.k)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

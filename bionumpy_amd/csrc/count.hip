@@ -189,20 +189,22 @@ int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t*
   return BNPK_OK;
 }
 
-int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int key_bits, int* h_in_alt,
-                   void* stream) {
-  if (!ctx || n < 0 || key_bits < 1 || key_bits > 64 || !h_in_alt) return BNPK_ERR_ARG;
+int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int begin_bit, int end_bit,
+                   int* h_in_alt, void* stream) {
+  if (!ctx || n < 0 || begin_bit < 0 || end_bit <= begin_bit || end_bit > 64 || !h_in_alt) return BNPK_ERR_ARG;
   *h_in_alt = 0;
   if (n <= 1) return BNPK_OK;
   if (!d_keys || !d_alt) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   rocprim::double_buffer<uint64_t> keys(reinterpret_cast<uint64_t*>(d_keys), reinterpret_cast<uint64_t*>(d_alt));
   size_t temp_bytes = 0;
-  BNPK_HIP(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, keys, (size_t)n, 0u, (unsigned)key_bits, s));
+  BNPK_HIP(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, keys, (size_t)n, (unsigned)begin_bit,
+                                         (unsigned)end_bit, s));
   void* temp = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp));
-  bnpk_timer t(ctx, "sort_keys", s);
-  BNPK_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, keys, (size_t)n, 0u, (unsigned)key_bits, s));
+  bnpk_timer t(ctx, begin_bit == 0 ? "sort_keys" : "partition_keys", s);
+  BNPK_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, keys, (size_t)n, (unsigned)begin_bit,
+                                         (unsigned)end_bit, s));
   *h_in_alt = (keys.current() == reinterpret_cast<uint64_t*>(d_alt)) ? 1 : 0;
   return BNPK_OK;
 }

@@ -172,13 +172,24 @@ class HipOps:
                                             n_bins, ptr(hist), self._s()))
         return HArray(dev=hist)
 
-    def sort_keys(self, keys_t, key_bits):
-        """sorts a torch int64 tensor; returns the tensor holding the result and the other (free) one"""
+    def sort_keys(self, keys_t, key_bits, begin_bit=0):
+        """sorts a torch int64 tensor on bits [begin_bit, key_bits); returns the tensor holding the result
+        and the other (free) one"""
         n = keys_t.numel()
         alt = self._empty(n, np.int64)
         in_alt = C.c_int(0)
-        self._chk(lib.bnpk_sort_keys(self.ctx, ptr(keys_t), ptr(alt), n, key_bits, C.byref(in_alt), self._s()))
+        self._chk(lib.bnpk_sort_keys(self.ctx, ptr(keys_t), ptr(alt), n, begin_bit, key_bits, C.byref(in_alt),
+                                     self._s()))
         return (alt, keys_t) if in_alt.value else (keys_t, alt)
+
+    def partition_by_top_bits(self, values, key_bits, top_bits):
+        """stable partition of the keys by their top ``top_bits`` bits (of ``key_bits``); consumes ``values``.
+        Returns the partitioned keys and the bucket boundaries (2^top_bits + 1 offsets, host numpy)."""
+        t = values.dev()
+        part, _ = self.sort_keys(t, key_bits, begin_bit=key_bits - top_bits)
+        bounds = np.arange(1 << top_bits, dtype=np.int64) << (key_bits - top_bits)
+        cuts = self.search_sorted(HArray(dev=part), HArray(host=bounds), upper=False).host()
+        return HArray(dev=part), np.append(cuts, part.numel()).astype(np.int64)
 
     def _runs(self, sorted_t, second_t=None):
         """run boundaries of a sorted tensor (optionally of (sorted, second) pairs): n_runs, tile offsets"""

@@ -1,0 +1,60 @@
+"""The whole hot path over one HBM-resident FASTQ batch: decode -> 2-bit -> k-mers -> histogram.
+
+Equivalent to, chunk by chunk in the reference (scripts/kmer_counting_example.py:4-17,
+docs_source/topics/kmers.rst:42-62):
+
+    for chunk in bnp.open(fq).read_chunks(): counts += count_kmers(change_encoding(chunk.sequence, DNA), k)
+
+but on one batch sized for 288 GB of HBM (tens of millions of reads) instead of 5 MB chunks, and with
+every intermediate released as soon as the next stage has consumed it.  bench.py times exactly this
+function; __graft_entry__.smoke() and the tests check it against the oracle.
+"""
+from collections import namedtuple
+
+from . import parallel
+from .io.buffers import FastQBuffer
+from .ops import get_ops
+
+DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB; above that the histogram is sparse
+
+BatchStats = namedtuple("BatchStats", "n_reads n_bases n_kmers n_bytes")
+
+
+def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer):
+    """text: HArray uint8 holding complete FASTQ records.  Returns (histogram, BatchStats) where the
+    histogram is a dense int64 HArray (k <= 13; summed over ranks if ``group``) or a (keys, counts) pair
+    of HArrays (k > 13; range-partitioned over ranks if ``group``)."""
+    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    ops = get_ops()
+    lpe = buffer_type.n_lines_per_entry
+    scan = ops.scan_lines(text, text.size, lpe, ord(buffer_type.HEADER), buffer_type._check_plus)   # A2 + A3
+    n = scan.n_records
+    starts, lens = ops.field_table(text, scan.newlines, n, lpe, 1, buffer_type._line_offsets[1], scan.has_cr)  # A4
+    n_bytes = scan.size
+    del scan
+    offsets, n_bases = ops.row_offsets(lens, 1)
+    _, packed = ops.gather_encode_dna(text, starts, offsets, n, n_bases, want_codes=False, want_packed=True)  # A6+A7
+    del starts
+    out_offsets, n_kmers = ops.row_offsets(lens, k)
+    del lens
+    hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)                                   # A8
+    del packed, offsets, out_offsets
+    stats = BatchStats(n, n_bases, n_kmers, n_bytes)
+    distributed = group is not None or _world_size() > 1
+    if k <= DENSE_MAX_K:                                                                              # A9 dense
+        hist = ops.count_dense(hashes, 4 ** k)
+        del hashes
+        if distributed:
+            hist = parallel.allreduce_dense(hist, group)
+        return hist, stats
+    if distributed:                                                                                   # A9 sparse
+        return parallel.count_sparse_distributed(hashes, 2 * k, group), stats
+    return ops.count_sparse(hashes, key_bits=2 * k, consume=True), stats
+
+
+def _world_size():
+    try:
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    except Exception:
+        return 1

@@ -169,11 +169,12 @@ int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t*
 
 /* sparse (k > 8 has no reference implementation; defined as np.unique(h, return_counts=True),
  * SURVEY.md §3.5): step 1 sorts the keys (d_alt is an n-element ping-pong buffer; only bits
- * [0, key_bits) are sorted; *h_in_alt = 1 if the sorted keys ended up in d_alt, known on the host
+ * [begin_bit, end_bit) take part, stably — begin_bit > 0 is the key-range partition of the
+ * multi-GPU exchange; *h_in_alt = 1 if the sorted keys ended up in d_alt, known on the host
  * without a synchronisation), step 2 counts distinct keys (synchronous: returns the count
  * through h_n_unique), step 3 writes sorted unique keys + run lengths. */
-int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int key_bits,
-                   int* h_in_alt, void* stream);
+int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, int begin_bit,
+                   int end_bit, int* h_in_alt, void* stream);
 int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t* d_vals,
                     int64_t* d_vals_alt, int64_t n, int key_bits, int* h_in_alt, void* stream);
 /* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */

@@ -1,0 +1,58 @@
+"""world_size-2 gloo worker for tests/test_parallel.py: the multi-GPU merge path of bionumpy_amd.parallel
+driven on CPU with the oracle-backed ops (host logic + collectives; the kernels are covered by -m gpu)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import oracle
+    from oracle_ops import OracleOps
+    from bionumpy_amd import ops as ops_mod, parallel, synth
+    from bionumpy_amd.device import HArray
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    ops_mod.set_ops(OracleOps())
+
+    n_reads, read_len, seed, genome = 300, 80, 7, 5000
+    text = synth.fastq_bytes(n_reads, read_len, seed, 1, genome, first_read=rank * n_reads)
+    out = {}
+    for k in (4, 15, 31):
+        hist, stats = fastq_kmer_histogram(HArray(host=text), k)
+        if isinstance(hist, tuple):
+            out[k] = (hist[0].host().copy(), hist[1].host().copy())
+        else:
+            out[k] = hist.host().copy()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        all_text = synth.fastq_bytes(n_reads * world, read_len, seed, 1, genome, first_read=0)
+        res = oracle.scan_one_line_buffer(all_text, oracle.FASTQ)
+        codes = oracle.encode_dna(oracle.gather_rows(all_text, res.field_starts[:, 1], res.field_lens[:, 1]))
+        for k in (4, 15, 31):
+            h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], k)
+            if k <= 13:
+                expect = oracle.count_dense(h, k)
+                for r in range(world):
+                    assert np.array_equal(gathered[r][k], expect), "dense all-reduce mismatch"
+            else:
+                ek, ec = oracle.count_sparse(h)
+                keys = np.concatenate([gathered[r][k][0] for r in range(world)])
+                counts = np.concatenate([gathered[r][k][1] for r in range(world)])
+                assert np.array_equal(keys, ek) and np.array_equal(counts, ec), "sparse key-range merge mismatch"
+                bounds = [g[k][0] for g in gathered]
+                for a, b in zip(bounds[:-1], bounds[1:]):
+                    assert a.size == 0 or b.size == 0 or a[-1] < b[0], "rank ranges overlap"
+        print("DIST_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,15 @@ def _pack(codes):
 
 
 class OracleOps:
+    host_only = True          # parallel.py then moves numpy-backed tensors (gloo) instead of HBM tensors
+
+    def partition_by_top_bits(self, values, key_bits, top_bits):
+        v = values.host()
+        bucket = v >> (key_bits - top_bits)
+        order = np.argsort(bucket, kind="stable")
+        cuts = np.searchsorted(bucket[order], np.arange((1 << top_bits) + 1))
+        return _h(v[order]), cuts.astype(np.int64)
+
     # -- decode -----------------------------------------------------------------------------------
     def newline_positions(self, buf, n, limit_multiple=1):
         pos = np.flatnonzero(buf.host()[:n] == NEWLINE).astype(np.int64)
