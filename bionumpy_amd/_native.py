@@ -20,7 +20,7 @@ class BnpkError(RuntimeError):
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
-        "bionumpy_amd: %s is missing. Build it with `python -m bionumpy_amd.csrc.build` "
+        "bionumpy_amd: %s is missing. Build it with `python bionumpy_amd/csrc/build.py` "
         "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
 
 # torch bundles its own libamdhip64.so.7; it must be the first HIP runtime in the process (loading the
@@ -71,6 +71,8 @@ SIGNATURES = {
     "bnpk_count_dense_rows": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "bnpk_sort_keys": (_int, [_p, _p, _p, _i64, _int, _int, C.POINTER(_int), _p]),
     "bnpk_sort_pairs": (_int, [_p, _p, _p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
+    "bnpk_finish_state_words": (_i64, [_i64]),
+    "bnpk_finish_buckets": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
     "bnpk_run_tiles": (_i64, [_i64]),
     "bnpk_run_census": (_int, [_p, _p, _p, _i64, _p, C.POINTER(_i64), _p]),
     "bnpk_run_heads": (_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p]),

@@ -1,6 +1,6 @@
 """Builds libbnpk.so (the C-ABI of include/bnpk.h) for gfx950 with hipcc, in-tree.
 
-    python -m bionumpy_amd.csrc.build [--force]
+    python bionumpy_amd/csrc/build.py [--force]
 
 hipcc cross-compiles without a GPU; one object per .hip file so that an edit rebuilds one file.
 """
@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbnpk.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "scan.hip", "decode.hip", "encode.hip", "kmers.hip", "count.hip", "synth.hip"]
+SOURCES = ["api.hip", "scan.hip", "decode.hip", "encode.hip", "kmers.hip", "count.hip", "finish.hip", "synth.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"),
            os.path.join(ROOT, "include", "bnpk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

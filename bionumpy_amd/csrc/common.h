@@ -65,10 +65,13 @@ struct bnpk_timer {
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// grid size for a grid-stride style launch over `work_items` blocks' worth of work
+// The AQL dispatch packet carries the grid size in WORK-ITEMS as a uint32, so gridDim.x * blockDim.x must
+// stay below 2^32: element-wise kernels are grid-stride loops launched with at most BNPK_MAX_BLOCKS
+// workgroups of 256 threads, tile kernels check their tile count against it.
+#define BNPK_MAX_BLOCKS ((int64_t)((1ull << 32) / 256 - 1))
 static inline unsigned grid_for(int64_t blocks) {
   if (blocks < 1) blocks = 1;
-  return (unsigned)(blocks > 0x7fffffffLL ? 0x7fffffffLL : blocks);
+  return (unsigned)(blocks > BNPK_MAX_BLOCKS ? BNPK_MAX_BLOCKS : blocks);
 }
 
 // ------------------------------------------------------------------------------------------ device

@@ -53,10 +53,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void hist_rows_kernel(const int64_t* __
                                                                int64_t n, int64_t n_bins,
                                                                unsigned long long* __restrict__ hist) {
   int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  int64_t row = find_row(off, 0, n_rows - 1, i);
-  int64_t a = v[i];
-  if ((uint64_t)a < (uint64_t)n_bins) atomicAdd(&hist[row * n_bins + a], 1ull);
+  const int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  for (; i < n; i += stride) {
+    int64_t row = find_row(off, 0, n_rows - 1, i);
+    int64_t a = v[i];
+    if ((uint64_t)a < (uint64_t)n_bins) atomicAdd(&hist[row * n_bins + a], 1ull);
+  }
 }
 
 // ------------------------------------------------------------------------------------ runs of equal keys
@@ -124,24 +126,28 @@ __global__ __launch_bounds__(BNPK_BLOCK) void run_heads_kernel(const int64_t* __
 __global__ void run_sums_kernel(const int64_t* __restrict__ run_starts, int64_t n_runs,
                                 const int64_t* __restrict__ prefix, int64_t* __restrict__ counts) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_runs) return;
-  int64_t s = run_starts[j], e = run_starts[j + 1];
-  counts[j] = prefix ? prefix[e] - prefix[s] : e - s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; j < n_runs; j += stride) {
+    int64_t s = run_starts[j], e = run_starts[j + 1];
+    counts[j] = prefix ? prefix[e] - prefix[s] : e - s;
+  }
 }
 
 __global__ void search_sorted_kernel(const int64_t* __restrict__ sorted, int64_t n, const int64_t* __restrict__ q,
                                      int64_t m, int upper, int64_t* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  int64_t key = q[i];
-  int64_t lo = 0, hi = n;
-  while (lo < hi) {
-    int64_t mid = lo + ((hi - lo) >> 1);
-    int64_t v = sorted[mid];
-    bool right = upper ? (v <= key) : (v < key);
-    if (right) lo = mid + 1; else hi = mid;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += stride) {
+    int64_t key = q[i];
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+      int64_t mid = lo + ((hi - lo) >> 1);
+      int64_t v = sorted[mid];
+      bool right = upper ? (v <= key) : (v < key);
+      if (right) lo = mid + 1; else hi = mid;
+    }
+    out[i] = lo;
   }
-  out[i] = lo;
 }
 
 }  // namespace
@@ -179,11 +185,9 @@ int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t*
   if (!ctx || n < 0 || n_rows < 0 || n_bins < 1) return BNPK_ERR_ARG;
   if (n == 0) return BNPK_OK;
   if (!d_values || !d_offsets || !d_hist || n_rows == 0) return BNPK_ERR_ARG;
-  int64_t blocks = ceil_div(n, BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "count_dense_rows", s);
-  hipLaunchKernelGGL(hist_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_values, d_offsets, n_rows, n,
+  hipLaunchKernelGGL(hist_rows_kernel, dim3(grid_for(ceil_div(n, BNPK_BLOCK))), dim3(BNPK_BLOCK), 0, s, d_values, d_offsets, n_rows, n,
                      n_bins, reinterpret_cast<unsigned long long*>(d_hist));
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
@@ -235,7 +239,7 @@ int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_sec
   if (!ctx || n < 0 || !d_tile_offsets || !h_n_runs || (n > 0 && !d_sorted)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t tiles = bnpk_run_tiles(n);
-  if (tiles > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
   {
@@ -258,6 +262,7 @@ int bnpk_run_heads(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_seco
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) return bnpk_fill_i64(ctx, d_run_starts, 1, 0, stream);
   if (!d_sorted || !d_tile_offsets || !d_keys_out || (d_second_out && !d_second)) return BNPK_ERR_ARG;
+  if (bnpk_run_tiles(n) > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "run_heads", s);
   hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)bnpk_run_tiles(n)), dim3(BNPK_BLOCK), 0, s, d_sorted, d_second, n,
                      d_tile_offsets, n_runs, d_keys_out, d_second_out, d_run_starts);

@@ -106,16 +106,18 @@ __global__ void validate_entries_kernel(const uint8_t* __restrict__ buf, const i
                                         int64_t n_entries, int lpe, uint8_t header, int check_plus,
                                         unsigned long long* __restrict__ err) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_entries) return;
-  int64_t hpos = (r == 0) ? 0 : nl[r * lpe - 1] + 1;
-  if (buf[hpos] != header) atomicMin(&err[0], (unsigned long long)r);
-  if (check_plus) {
-    int64_t ppos = nl[r * lpe + 1] + 1;
-    if (buf[ppos] != '+') atomicMin(&err[1], (unsigned long long)r);
-  }
-  if (r < lpe && nl[0] >= 1) {      // _modify_for_carriage_return looks at the first lpe header lines only
-    int64_t e = nl[r * lpe];
-    if (e >= 1 && buf[e - 1] == '\r') err[2] = 1ull;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n_entries; r += stride) {
+    int64_t hpos = (r == 0) ? 0 : nl[r * lpe - 1] + 1;
+    if (buf[hpos] != header) atomicMin(&err[0], (unsigned long long)r);
+    if (check_plus) {
+      int64_t ppos = nl[r * lpe + 1] + 1;
+      if (buf[ppos] != '+') atomicMin(&err[1], (unsigned long long)r);
+    }
+    if (r < lpe && nl[0] >= 1) {      // _modify_for_carriage_return looks at the first lpe header lines only
+      int64_t e = nl[r * lpe];
+      if (e >= 1 && buf[e - 1] == '\r') err[2] = 1ull;
+    }
   }
 }
 
@@ -129,13 +131,15 @@ __global__ void field_table_kernel(const uint8_t* __restrict__ buf, const int64_
                                    int64_t n_entries, int lpe, int field, int line_offset, int strip_cr,
                                    int64_t* __restrict__ starts, int64_t* __restrict__ lens) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_entries) return;
-  int64_t line = r * lpe + field;
-  int64_t s = (line == 0 ? 0 : nl[line - 1] + 1) + line_offset;
-  int64_t e = nl[line];
-  if (strip_cr && e >= 1 && buf[e - 1] == '\r') e -= 1;
-  starts[r] = s;
-  lens[r] = e - s;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n_entries; r += stride) {
+    int64_t line = r * lpe + field;
+    int64_t s = (line == 0 ? 0 : nl[line - 1] + 1) + line_offset;
+    int64_t e = nl[line];
+    if (strip_cr && e >= 1 && buf[e - 1] == '\r') e -= 1;
+    starts[r] = s;
+    lens[r] = e - s;
+  }
 }
 
 }  // namespace
@@ -150,7 +154,7 @@ int bnpk_byte_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t val
   if (((uintptr_t)d_buf & 15) != 0) return BNPK_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   int64_t tiles = bnpk_scan_tiles(n);
-  if (tiles > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
   uint32_t rep = 0x01010101u * value;
@@ -170,6 +174,7 @@ int bnpk_byte_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t 
   if (!ctx || n < 0 || !d_tile_offsets || (n > 0 && !d_buf) || limit < 0) return BNPK_ERR_ARG;
   if (((uintptr_t)d_buf & 15) != 0) return BNPK_ERR_ALIGN;
   int64_t tiles = bnpk_scan_tiles(n);
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   if (tiles == 0 || limit == 0) return BNPK_OK;
   if (!d_pos) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void unpack_kernel(const uint64_t* __re
 __global__ void take_bytes_kernel(const uint8_t* __restrict__ buf, const int64_t* __restrict__ pos, int64_t m,
                                   int64_t delta, uint8_t* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) out[i] = buf[pos[i] + delta];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += stride) out[i] = buf[pos[i] + delta];
 }
 
 }  // namespace
@@ -218,7 +219,7 @@ int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d
   hipStream_t s = (hipStream_t)stream;
   int64_t n_words = (total + 31) / 32;
   int64_t blocks = ceil_div(n_words + 1, BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   auto* err = reinterpret_cast<unsigned long long*>(d_err_offset);
   bnpk_timer t(ctx, "gather_encode_dna", s);
   dim3 g((unsigned)blocks), b(BNPK_BLOCK);
@@ -242,7 +243,7 @@ int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_start
   if (!d_buf || !d_starts || !d_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = ceil_div(total, (int64_t)BNPK_BLOCK * 16);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "gather_rows", s);
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_buf, d_starts, d_offsets,
                      n_rows, total, subtract, d_out);
@@ -255,7 +256,7 @@ int bnpk_encode_dna_flat(bnpk_ctx* ctx, const uint8_t* d_ascii, int64_t n, uint8
   if (!ctx || n < 0 || !d_err_offset || (!d_codes && !d_packed) || (n > 0 && !d_ascii)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = ceil_div((n + 31) / 32 + 1, BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "encode_dna_flat", s);
   hipLaunchKernelGGL((flat_encode_kernel<0>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_ascii, n, d_codes,
                      d_packed, reinterpret_cast<unsigned long long*>(d_err_offset));
@@ -267,7 +268,7 @@ int bnpk_pack_codes(bnpk_ctx* ctx, const uint8_t* d_codes, int64_t n, uint64_t* 
   if (!ctx || n < 0 || !d_packed || (n > 0 && !d_codes)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = ceil_div((n + 31) / 32 + 1, BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "pack_codes", s);
   hipLaunchKernelGGL((flat_encode_kernel<1>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, n,
                      (uint8_t*)nullptr, d_packed, (unsigned long long*)nullptr);
@@ -282,7 +283,7 @@ int bnpk_unpack_codes(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n, int to
   if (!d_packed || !d_out) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = ceil_div((n + 31) / 32, BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "unpack_codes", s);
   hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, n, to_ascii, d_out);
   BNPK_HIP(ctx, hipGetLastError());

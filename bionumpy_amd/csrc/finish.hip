@@ -1,0 +1,214 @@
+// Histogram finishing kernel (A9, sparse path): input = k-mer keys radix-sorted on their TOP `part_bits`
+// bits only (buckets of equal top bits are contiguous, order inside a bucket arbitrary).  One pass
+//   * ranks the distinct keys inside every bucket (buckets are tiny when part_bits ~ log2(n)),
+//   * run-length-counts them,
+//   * and compacts (key, count) into the globally sorted output with a decoupled look-back over tiles,
+// replacing the low radix passes AND the separate run-census / run-heads / run-sums passes:
+// per key it reads 8 B and writes 16 B (all-distinct worst case) — the algorithmic floor of an RLE.
+//
+// A bucket larger than FB_CAP keys (heavy-hitter k-mers, low part_bits) sets the overflow flag; the caller
+// then falls back to the full sort + run kernels of count.hip, so results never depend on this fast path.
+#include "common.h"
+
+namespace {
+
+constexpr int FB_T = 2048;                     // keys owned by one workgroup
+constexpr int FB_CAP = 1024;                   // largest bucket the fast path handles
+constexpr int FB_W = FB_T + FB_CAP;            // LDS window (24 KiB of keys)
+constexpr int FB_WORDS = FB_W / 64;            // 48 bit-mask words
+constexpr int FB_ITERS = FB_W / BNPK_BLOCK;    // 12 slots per lane
+
+// state[] layout (unsigned long long): [0] ticket counter, [1] overflow flag, [2] n_unique, [3 + t] tile t
+constexpr int ST_TICKET = 0, ST_OVERFLOW = 1, ST_UNIQUE = 2, ST_TILES = 3;
+constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VALUE_MASK = (1ull << 62) - 1;
+
+__device__ __forceinline__ int prev_set(const uint64_t* __restrict__ m, int i) {
+  int w = i >> 6;
+  uint64_t v = m[w] & (~0ull >> (63 - (i & 63)));
+  while (v == 0) v = m[--w];
+  return (w << 6) + 63 - __clzll((long long)v);
+}
+
+// next set bit strictly after i, or -1
+__device__ __forceinline__ int next_set(const uint64_t* __restrict__ m, int i) {
+  int w = i >> 6;
+  uint64_t v = ((i & 63) == 63) ? 0ull : (m[w] & (~0ull << ((i & 63) + 1)));
+  while (v == 0) {
+    if (++w >= FB_WORDS) return -1;
+    v = m[w];
+  }
+  return (w << 6) + __ffsll((long long)v) - 1;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void finish_buckets_kernel(const uint64_t* __restrict__ A, int64_t n,
+                                                                    int shift, int64_t n_tiles,
+                                                                    uint64_t* __restrict__ keys_out,
+                                                                    int64_t* __restrict__ counts_out,
+                                                                    unsigned long long* __restrict__ state) {
+  __shared__ uint64_t key[FB_W];
+  __shared__ uint64_t smask[FB_WORDS];          // bucket-start bits
+  __shared__ uint64_t fmask[FB_WORDS];          // first-occurrence bits inside the owned range
+  __shared__ int fprefix[FB_WORDS + 1];
+  __shared__ long long sh_tile, sh_base;
+  __shared__ int sh_s, sh_e;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tickets make "tile id" follow the real dispatch order, so the look-back below can never wait on a
+  // workgroup that has not started (no assumption about blockIdx scheduling).
+  if (tid == 0) sh_tile = (long long)atomicAdd(&state[ST_TICKET], 1ull);
+  __syncthreads();
+  const int64_t t = sh_tile;
+  const int64_t g0 = t * FB_T;
+  const int wlen = (int)min((int64_t)FB_W, n - g0);
+  const uint64_t prev = (g0 > 0) ? A[g0 - 1] : ~0ull;
+#pragma unroll
+  for (int j = 0; j < FB_ITERS; ++j) {
+    int i = tid + BNPK_BLOCK * j;
+    key[i] = (i < wlen) ? A[g0 + i] : ~0ull;    // sentinel: a bucket id no real key (< 2^62) can have
+  }
+  __syncthreads();
+  // bucket-start bits; slot word index (4j + wave) is wave-uniform, so one ballot gives one mask word
+#pragma unroll
+  for (int j = 0; j < FB_ITERS; ++j) {
+    int i = tid + BNPK_BLOCK * j;
+    uint64_t k = key[i];
+    uint64_t kp = (i > 0) ? key[i - 1] : prev;
+    uint64_t m = __ballot((k >> shift) != (kp >> shift));
+    if (lane == 0) smask[4 * j + wave] = m;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // owned range [s, e): the buckets that START inside the tile proper
+    const int tile_end = min(FB_T, wlen);
+    int s = -1, e = -1;
+    for (int w = 0; w < FB_WORDS && (s < 0 || e < 0); ++w) {
+      uint64_t v = smask[w];
+      if (s < 0 && v) s = (w << 6) + __ffsll((long long)v) - 1;
+      if (e < 0) {
+        int lo = tile_end - (w << 6);
+        uint64_t vv = lo <= 0 ? v : (lo >= 64 ? 0ull : (v & (~0ull << lo)));
+        if (vv) e = (w << 6) + __ffsll((long long)vv) - 1;
+      }
+    }
+    if (s < 0 || s >= tile_end) { s = 0; e = 0; }          // whole tile inside a bucket owned by an earlier tile
+    else if (e < 0) { e = wlen; atomicOr(&state[ST_OVERFLOW], 1ull); }   // ran off the window
+    sh_s = s;
+    sh_e = e;
+  }
+  __syncthreads();
+  const int s = sh_s, e = sh_e;
+  // pass 1: bucket bounds + first-occurrence flag of every owned slot
+  unsigned bounds[FB_ITERS];
+  unsigned first_bits = 0;
+  bool too_big = false;
+#pragma unroll
+  for (int j = 0; j < FB_ITERS; ++j) {
+    int i = tid + BNPK_BLOCK * j;
+    bool active = (i >= s) && (i < e);
+    bool first = false;
+    bounds[j] = 0;
+    if (active) {
+      int bs = prev_set(smask, i);
+      int be = next_set(smask, i);
+      if (be < 0 || be > e) be = e;
+      if (be - bs > FB_CAP) too_big = true;
+      bounds[j] = (unsigned)bs | ((unsigned)be << 16);
+      uint64_t x = key[i];
+      first = true;
+      for (int q = bs; q < i; ++q)
+        if (key[q] == x) { first = false; break; }
+    }
+    uint64_t fm = __ballot(first);
+    if (lane == 0) fmask[4 * j + wave] = fm;
+    if (first) first_bits |= 1u << j;
+  }
+  if (too_big) atomicOr(&state[ST_OVERFLOW], 1ull);
+  __syncthreads();
+  if (wave == 0) {                               // exclusive prefix of the popcounts of the 48 mask words
+    int c = (lane < FB_WORDS) ? __popcll(fmask[lane]) : 0;
+    int inc = wave_inclusive_scan(c);
+    if (lane < FB_WORDS) fprefix[lane] = inc - c;
+    if (lane == FB_WORDS - 1) fprefix[FB_WORDS] = inc;
+  }
+  __syncthreads();
+  const long long aggregate = fprefix[FB_WORDS];
+  if (tid == 0) {
+    // decoupled look-back: each tile publishes ONE 64-bit word {flag, value}; no payload ordering needed
+    unsigned long long* mine = &state[ST_TILES + t];
+    long long base = 0;
+    if (t > 0) {
+      __hip_atomic_store(mine, FLAG_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t p = t - 1;
+      while (true) {
+        unsigned long long v = __hip_atomic_load(&state[ST_TILES + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long flag = v & ~VALUE_MASK;
+        if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
+        base += (long long)(v & VALUE_MASK);
+        if (flag == FLAG_INC) break;
+        --p;
+      }
+    }
+    __hip_atomic_store(mine, FLAG_INC | (unsigned long long)(base + aggregate), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    if (t == n_tiles - 1) state[ST_UNIQUE] = (unsigned long long)(base + aggregate);
+    sh_base = base;
+  }
+  __syncthreads();
+  const int64_t out0 = sh_base;
+  // pass 2: every first occurrence writes (key, multiplicity) at its sorted position
+#pragma unroll
+  for (int j = 0; j < FB_ITERS; ++j) {
+    if (!(first_bits & (1u << j))) continue;
+    int i = tid + BNPK_BLOCK * j;
+    int bs = (int)(bounds[j] & 0xffffu), be = (int)(bounds[j] >> 16);
+    uint64_t x = key[i];
+    int cnt = 0, rank = 0;
+    for (int q = bs; q < be; ++q) {
+      uint64_t y = key[q];
+      cnt += (y == x);
+      rank += (y < x) && ((fmask[q >> 6] >> (q & 63)) & 1ull);
+    }
+    int local = fprefix[bs >> 6] + __popcll(fmask[bs >> 6] & ((1ull << (bs & 63)) - 1ull)) + rank;
+    keys_out[out0 + local] = x;
+    counts_out[out0 + local] = cnt;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bnpk_finish_state_words(int64_t n) { return ST_TILES + (n <= 0 ? 0 : ceil_div(n, FB_T)) + 1; }
+
+int bnpk_finish_buckets(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits, int part_bits,
+                        int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state, int64_t* h_n_unique,
+                        int* h_overflow, void* stream) {
+  if (!ctx || n < 0 || key_bits < 1 || key_bits > 62 || part_bits < 1 || part_bits > key_bits || !h_n_unique ||
+      !h_overflow || !d_state)
+    return BNPK_ERR_ARG;
+  *h_n_unique = 0;
+  *h_overflow = 0;
+  if (n == 0) return BNPK_OK;
+  if (!d_part_sorted || !d_keys_out || !d_counts_out) return BNPK_ERR_ARG;
+  if (d_keys_out == d_part_sorted) return BNPK_ERR_ARG;           // tiles re-read their neighbours' keys
+  int64_t n_tiles = ceil_div(n, FB_T);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)bnpk_finish_state_words(n) * sizeof(int64_t), s));
+  {
+    bnpk_timer t(ctx, "finish_buckets", s);
+    hipLaunchKernelGGL(finish_buckets_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s,
+                       reinterpret_cast<const uint64_t*>(d_part_sorted), n, key_bits - part_bits, n_tiles,
+                       reinterpret_cast<uint64_t*>(d_keys_out), d_counts_out,
+                       reinterpret_cast<unsigned long long*>(d_state));
+  }
+  BNPK_HIP(ctx, hipGetLastError());
+  int64_t host[3];
+  BNPK_HIP(ctx, hipMemcpyAsync(host, d_state, sizeof(host), hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  *h_overflow = host[ST_OVERFLOW] != 0;
+  *h_n_unique = host[ST_UNIQUE];
+  return BNPK_OK;
+}
+
+}  // extern "C"

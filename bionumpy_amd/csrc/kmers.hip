@@ -136,7 +136,7 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
   if (n_out == 0) return BNPK_OK;
   if (!d_packed || !d_in_offsets || !d_out_offsets || !d_hashes || n_rows == 0) return BNPK_ERR_ARG;
   int64_t blocks = ceil_div(n_out, TILE_OUT);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "kmers", s);
   hipLaunchKernelGGL((kmer_kernel<false>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
@@ -152,7 +152,7 @@ int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in
   if (n_out == 0) return BNPK_OK;
   if (!d_packed || !d_in_offsets || !d_out_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
   int64_t blocks = ceil_div(n_out, TILE_OUT);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "minimizers", s);
   hipLaunchKernelGGL((kmer_kernel<true>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
@@ -167,7 +167,7 @@ int bnpk_row_ids(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_
   if (n == 0) return BNPK_OK;
   if (!d_offsets || !d_rows || n_rows == 0) return BNPK_ERR_ARG;
   int64_t blocks = ceil_div(n, TILE_OUT);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "row_ids", s);
   hipLaunchKernelGGL(row_ids_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_offsets, n_rows, n, d_rows);

@@ -88,7 +88,7 @@ int bnpk_scan_launch(bnpk_ctx* ctx, const int64_t* d_in, int64_t n, int window, 
     return BNPK_OK;
   }
   int64_t nb = ceil_div(n, TILE);
-  if (nb > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (nb > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   int64_t* partials = nullptr;
   if (nb > 1) {
     partials = d_scratch;

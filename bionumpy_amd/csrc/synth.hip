@@ -94,7 +94,7 @@ int bnpk_synth_fastq(bnpk_ctx* ctx, uint8_t* d_out, int64_t first_read, int64_t 
   if (((uintptr_t)d_out & 15) != 0) return BNPK_ERR_ALIGN;
   int64_t total = n_reads * bnpk_synth_record_bytes(read_len);
   int64_t blocks = ceil_div(ceil_div(total, 16), BNPK_BLOCK);
-  if (blocks > 0x7fffffffLL) return BNPK_ERR_RANGE;
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "synth_fastq", s);
   hipLaunchKernelGGL(synth_fastq_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_out, first_read, n_reads,

@@ -201,7 +201,7 @@ class HipOps:
                                       self._s()))
         return int(n_runs.value), tile_off
 
-    def count_sparse(self, values, key_bits=62, consume=False):
+    def count_sparse(self, values, key_bits=62, consume=False, fast=True):
         """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys)."""
         t = values.dev()
         n = t.numel()
@@ -209,6 +209,21 @@ class HipOps:
             z = self._empty(0, np.int64)
             return HArray(dev=z), HArray(dev=z.clone())
         work = t if consume else t.clone()
+        if fast and key_bits <= 62:
+            # fast path: radix-sort only the top ~log2(n) bits (whole 8-bit passes), then one fused kernel
+            # ranks + run-length-counts + compacts inside the (tiny) buckets of equal top bits
+            part_bits = min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
+            part_t, free_t = self.sort_keys(work, key_bits, begin_bit=key_bits - part_bits)
+            counts = self._empty(n, np.int64)
+            state = self._empty(lib.bnpk_finish_state_words(n), np.int64)
+            n_unique, overflow = C.c_int64(0), C.c_int(0)
+            self._chk(lib.bnpk_finish_buckets(self.ctx, ptr(part_t), n, key_bits, part_bits, ptr(free_t), ptr(counts),
+                                              ptr(state), C.byref(n_unique), C.byref(overflow), self._s()))
+            if not overflow.value:
+                return HArray(dev=free_t[:n_unique.value]), HArray(dev=counts[:n_unique.value])
+            del counts, state
+            work = part_t                                 # heavy-hitter buckets: fall back to the full sort
+            del free_t
         sorted_t, free_t = self.sort_keys(work, key_bits)
         n_runs, tile_off = self._runs(sorted_t)
         keys_out = free_t[:n_runs]                       # the ping-pong buffer is free after the sort

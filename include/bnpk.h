@@ -177,6 +177,18 @@ int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, in
                    int end_bit, int* h_in_alt, void* stream);
 int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t* d_vals,
                     int64_t* d_vals_alt, int64_t n, int key_bits, int* h_in_alt, void* stream);
+/* Fast path of steps 2+3: the keys only need to be sorted on their TOP part_bits bits
+ * (bnpk_sort_keys with begin_bit = key_bits - part_bits; part_bits ~ log2(n) keeps the buckets of equal
+ * top bits tiny).  One kernel ranks the distinct keys inside every bucket, run-length-counts them and
+ * compacts (key, count) into globally sorted order with a decoupled look-back over 2048-key tiles.
+ * Synchronous: returns the number of distinct keys; *h_overflow = 1 means some bucket held more than
+ * 1024 keys (heavy-hitter k-mers) and the outputs must be discarded in favour of the full sort + run
+ * kernels below.  d_state needs bnpk_finish_state_words(n) int64; d_keys_out / d_counts_out need n
+ * entries and must not alias the input. */
+int64_t bnpk_finish_state_words(int64_t n);
+int bnpk_finish_buckets(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits,
+                        int part_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                        int64_t* h_n_unique, int* h_overflow, void* stream);
 /* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */
 int64_t bnpk_run_tiles(int64_t n);
 int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,

@@ -1,0 +1,104 @@
+"""Summarise rocprofv3 rocpd databases (gpurun_out/prof/*/bench_results.db) into small text/JSON files
+under profiles/.
+
+    python scripts/summarize_profile.py gpurun_out/prof profiles/r01
+
+* <out>_kernel_stats.txt : per-kernel calls / total / average / min / max duration (== --stats)
+* <out>_pmc.json         : per-kernel FETCH_SIZE / WRITE_SIZE per launch (KB as reported + corrected
+                           bytes: FETCH_SIZE x 2 on gfx950, MI355X_MICROARCH.md §HBM)
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def _short(name):
+    if "rocprim" in name:
+        if "radix_sort_onesweep_iteration" in name:
+            return "rocprim::onesweep_iteration"
+        if "radix_sort_onesweep_global_offsets" in name:
+            return "rocprim::onesweep_global_offsets" + ("#2" if name.rstrip(")").endswith("#2}") else "#1")
+        return "rocprim::" + name[-50:]
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.split("(")[0]
+    for key in ("byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
+                "gather_encode", "kmer_kernel", "run_census", "run_heads", "run_sums", "synth_fastq", "fill_kernel",
+                "hist_lds", "hist_global", "finish_runs", "partition_scatter", "partition_hist"):
+        if key in name:
+            return key + ("<minimizer>" if "true" in name and key == "kmer_kernel" else "")
+    if "onesweep" in name:
+        return "rocprim::onesweep_iteration" if "iteration" in name else "rocprim::onesweep_histograms"
+    if "rocprim" in name:
+        return "rocprim::" + name.split("::")[-1][:40]
+    return name[-60:]
+
+
+def kernel_stats(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end from kernels").fetchall()
+    agg = {}
+    for name, s, e in rows:
+        a = agg.setdefault(_short(name), [0, 0, 1 << 62, 0])
+        d = e - s
+        a[0] += 1
+        a[1] += d
+        a[2] = min(a[2], d)
+        a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values()) or 1
+    lines = ["%-40s %8s %14s %12s %12s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct")]
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        lines.append("%-40s %8d %14d %12d %12d %12d %6.2f%%" % (k, a[0], a[1], a[1] // a[0], a[2], a[3], 100.0 * a[1] / total))
+    return "\n".join(lines) + "\n"
+
+
+def pmc(db):
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = con.execute("select %s, counter_name, value from counters_collection" % name_col).fetchall()
+    agg = {}
+    for name, counter, value in rows:
+        a = agg.setdefault((_short(name), counter), [0, 0.0])
+        a[0] += 1
+        a[1] += float(value)
+    return {"%s|%s" % k: {"launches": v[0], "sum": v[1], "per_launch": v[1] / v[0]} for k, v in agg.items()}
+
+
+def main():
+    src, out = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    stats_db = os.path.join(src, "stats", "bench_results.db")
+    if os.path.exists(stats_db):
+        text = kernel_stats(stats_db)
+        bench = os.path.join(src, "bench_stats.json")
+        header = "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
+        if os.path.exists(bench):
+            header += "# bench line of the profiled run: " + open(bench).read().strip()[:1500] + "\n"
+        open(out + "_kernel_stats.txt", "w").write(header + text)
+        print(text)
+    merged = {}
+    for sub, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        db = os.path.join(src, sub, "bench_results.db")
+        if os.path.exists(db):
+            merged.update(pmc(db))
+    if merged:
+        table = {}
+        for key, v in merged.items():
+            kern, counter = key.split("|")
+            t = table.setdefault(kern, {})
+            t[counter + "_KB_per_launch"] = round(v["per_launch"], 1)
+            t["launches"] = v["launches"]
+        for kern, t in table.items():
+            f = t.get("FETCH_SIZE_KB_per_launch")
+            w = t.get("WRITE_SIZE_KB_per_launch")
+            if f is not None:
+                t["read_bytes_corrected"] = int(f * 1024 * 2)        # gfx950: FETCH_SIZE reports 1/2 of wide reads
+            if w is not None:
+                t["write_bytes"] = int(w * 1024)
+        json.dump(table, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
+        print(json.dumps(table, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

@@ -150,3 +150,33 @@ def test_full_path_properties_at_scale(ops):
     codes = oracle.encode_dna(oracle.gather_rows(sample, res.field_starts[:, 1], res.field_lens[:, 1]))
     h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], k)
     assert np.array_equal(kmers._flat_data().dev()[:h.size].cpu().numpy(), h)
+
+
+@pytest.mark.parametrize("n,spread", [(1, 10), (2047, 50), (2048, 1000), (2049, 3), (100_000, 70_000),
+                                      (3_000_000, 400_000), (3_000_000, 1 << 40)])
+def test_fast_and_fallback_sparse_paths_agree(ops, n, spread):
+    """fused finishing kernel (top-bits sort + bucket ranking + look-back) vs full sort + run kernels vs numpy"""
+    rng = np.random.default_rng(n + spread)
+    v = (rng.integers(0, spread, size=n).astype(np.int64) * 0x9E3779B97F4A7C15) & ((1 << 62) - 1)
+    ek, ec = oracle.count_sparse(v)
+    for fast in (True, False):
+        keys, counts = ops.count_sparse(_h(v), key_bits=62, fast=fast)
+        assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec), fast
+
+
+def test_heavy_hitters_take_the_fallback(ops):
+    """buckets larger than the fast path's cap (a k-mer repeated 5000 times, a run of near-identical keys)
+    must still give np.unique's answer"""
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 1 << 62, size=50_000).astype(np.int64)
+    hot = np.full(5000, base[17], dtype=np.int64)
+    near = (base[99] & ~np.int64(0xFFFF)) + rng.integers(0, 1 << 16, size=3000)        # share the top 46 bits
+    v = rng.permutation(np.concatenate([base, hot, near])).astype(np.int64)
+    keys, counts = ops.count_sparse(_h(v), key_bits=62)
+    ek, ec = oracle.count_sparse(v)
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+    # small key width (k = 9 -> 18 bits): part_bits == key_bits, buckets are runs of equal keys
+    small = rng.integers(0, 1 << 18, size=400_000).astype(np.int64)
+    keys, counts = ops.count_sparse(_h(small), key_bits=18)
+    ek, ec = oracle.count_sparse(small)
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
