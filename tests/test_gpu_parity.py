@@ -157,7 +157,7 @@ def test_full_path_properties_at_scale(ops):
 def test_fast_and_fallback_sparse_paths_agree(ops, n, spread):
     """fused finishing kernel (top-bits sort + bucket ranking + look-back) vs full sort + run kernels vs numpy"""
     rng = np.random.default_rng(n + spread)
-    v = (rng.integers(0, spread, size=n).astype(np.int64) * 0x9E3779B97F4A7C15) & ((1 << 62) - 1)
+    v = (rng.integers(0, spread, size=n).astype(np.int64) * np.int64(0x1E3779B97F4A7C15)) & ((1 << 62) - 1)
     ek, ec = oracle.count_sparse(v)
     for fast in (True, False):
         keys, counts = ops.count_sparse(_h(v), key_bits=62, fast=fast)
