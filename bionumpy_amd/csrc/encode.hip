@@ -3,6 +3,7 @@
 // 512 contiguous bytes of packed words (and 2 KiB of 1-byte codes); the lane walks the source rows
 // it overlaps, finding its first row by a binary search narrowed to the rows the workgroup touches.
 #include "common.h"
+#include "rows.h"
 
 namespace {
 
@@ -14,20 +15,12 @@ __device__ __forceinline__ uint32_t dna_code(uint32_t b, bool* ok) {
   return ((u >> 1) & 3u) ^ ((u >> 2) & 1u);    // A C G T -> 0 1 2 3
 }
 
-// rows overlapped by the workgroup's flat range [first, last] -> smem[0..1]
-__device__ __forceinline__ void block_row_range(const int64_t* __restrict__ offsets, int64_t n_rows,
-                                                int64_t first, int64_t last, int64_t* smem) {
-  if (threadIdx.x == 0) smem[0] = find_row(offsets, 0, n_rows - 1, first);
-  if (threadIdx.x == 64) smem[1] = find_row(offsets, 0, n_rows - 1, last);
-  __syncthreads();
-}
-
 template <bool WRITE_CODES, bool WRITE_PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
-    int64_t n_rows, int64_t total, uint8_t* __restrict__ codes, uint64_t* __restrict__ packed,
-    unsigned long long* __restrict__ err) {
-  __shared__ int64_t rr[2];
+    int64_t n_rows, int64_t total, const int64_t* __restrict__ tile_rows, int64_t n_tiles,
+    uint8_t* __restrict__ codes, uint64_t* __restrict__ packed, unsigned long long* __restrict__ err) {
+  int64_t rr[2];
   int64_t n_words = (total + BASES_PER_WORD - 1) / BASES_PER_WORD;
   int64_t w0 = (int64_t)blockIdx.x * BNPK_BLOCK;
   int64_t w = w0 + threadIdx.x;
@@ -35,9 +28,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     if (WRITE_PACKED && w <= n_words) packed[w] = 0;
     return;
   }
-  int64_t blk_first = w0 * BASES_PER_WORD;
-  int64_t blk_last = min(blk_first + (int64_t)BNPK_BLOCK * BASES_PER_WORD, total) - 1;
-  block_row_range(offsets, n_rows, blk_first, blk_last, rr);
+  tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, rr[0], rr[1]);
   if (w >= n_words) {
     if (WRITE_PACKED && w == n_words) packed[w] = 0;
     return;
@@ -79,13 +70,13 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
 // plain gather, 16 output bytes per lane
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
-    int64_t n_rows, int64_t total, int subtract, uint8_t* __restrict__ out) {
-  __shared__ int64_t rr[2];
+    int64_t n_rows, int64_t total, int subtract, const int64_t* __restrict__ tile_rows,
+    uint8_t* __restrict__ out) {
+  int64_t rr[2];
   constexpr int PER = 16;
   int64_t blk_first = (int64_t)blockIdx.x * BNPK_BLOCK * PER;
   if (blk_first >= total) return;
-  int64_t blk_last = min(blk_first + (int64_t)BNPK_BLOCK * PER, total) - 1;
-  block_row_range(offsets, n_rows, blk_first, blk_last, rr);
+  tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
   int64_t pos = blk_first + (int64_t)threadIdx.x * PER;
   if (pos >= total) return;
   int64_t end = min(pos + PER, total);
@@ -221,17 +212,24 @@ int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d
   int64_t blocks = ceil_div(n_words + 1, BNPK_BLOCK);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   auto* err = reinterpret_cast<unsigned long long*>(d_err_offset);
+  // tiles of 256 packed words (8192 bases); the launch has extra workgroup(s) for the pad word
+  const int64_t n_tiles = ceil_div(n_words, BNPK_BLOCK);
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
   bnpk_timer t(ctx, "gather_encode_dna", s);
+  if (total > 0)
+    BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 32, (int64_t*)table, s));
+  const int64_t* tr = (const int64_t*)table;
   dim3 g((unsigned)blocks), b(BNPK_BLOCK);
   if (d_codes && d_packed)
     hipLaunchKernelGGL((gather_encode_kernel<true, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       d_codes, d_packed, err);
+                       tr, n_tiles, d_codes, d_packed, err);
   else if (d_packed)
     hipLaunchKernelGGL((gather_encode_kernel<false, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       d_codes, d_packed, err);
+                       tr, n_tiles, d_codes, d_packed, err);
   else
     hipLaunchKernelGGL((gather_encode_kernel<true, false>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       d_codes, d_packed, err);
+                       tr, n_tiles, d_codes, d_packed, err);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
@@ -244,9 +242,12 @@ int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_start
   hipStream_t s = (hipStream_t)stream;
   int64_t blocks = ceil_div(total, (int64_t)BNPK_BLOCK * 16);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
   bnpk_timer t(ctx, "gather_rows", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 16, (int64_t*)table, s));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_buf, d_starts, d_offsets,
-                     n_rows, total, subtract, d_out);
+                     n_rows, total, subtract, (const int64_t*)table, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

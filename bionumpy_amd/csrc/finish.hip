@@ -132,26 +132,39 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_buckets_kernel(const uint64
   }
   __syncthreads();
   const long long aggregate = fprefix[FB_WORDS];
-  if (tid == 0) {
-    // decoupled look-back: each tile publishes ONE 64-bit word {flag, value}; no payload ordering needed
+  if (wave == 0) {
+    // decoupled look-back: each tile publishes ONE 64-bit word {flag, value}; no payload ordering needed.
+    // The whole wavefront inspects 64 predecessors per round (lane 0 = nearest).
     unsigned long long* mine = &state[ST_TILES + t];
     long long base = 0;
     if (t > 0) {
-      __hip_atomic_store(mine, FLAG_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t p = t - 1;
+      if (lane == 0)
+        __hip_atomic_store(mine, FLAG_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t hi = t - 1;
       while (true) {
-        unsigned long long v = __hip_atomic_load(&state[ST_TILES + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t p = hi - lane;
+        unsigned long long v = (p >= 0) ? __hip_atomic_load(&state[ST_TILES + p], __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                        : FLAG_INC;                      // before tile 0: inclusive prefix 0
         unsigned long long flag = v & ~VALUE_MASK;
-        if (flag == 0) { __builtin_amdgcn_s_sleep(1); continue; }
-        base += (long long)(v & VALUE_MASK);
-        if (flag == FLAG_INC) break;
-        --p;
+        uint64_t inc_mask = __ballot(flag == FLAG_INC);
+        uint64_t invalid_mask = __ballot(flag == 0);
+        int first_inc = inc_mask ? (__ffsll((long long)inc_mask) - 1) : 64;
+        uint64_t need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);   // lanes 0..first_inc
+        if (invalid_mask & need) { __builtin_amdgcn_s_sleep(2); continue; }          // not published yet
+        long long contrib = (lane <= first_inc) ? (long long)(v & VALUE_MASK) : 0;
+        contrib = wave_reduce_sum(contrib);
+        base += __shfl(contrib, 0, 64);
+        if (first_inc < 64) break;
+        hi -= 64;
       }
     }
-    __hip_atomic_store(mine, FLAG_INC | (unsigned long long)(base + aggregate), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    if (t == n_tiles - 1) state[ST_UNIQUE] = (unsigned long long)(base + aggregate);
-    sh_base = base;
+    if (lane == 0) {
+      __hip_atomic_store(mine, FLAG_INC | (unsigned long long)(base + aggregate), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (t == n_tiles - 1) state[ST_UNIQUE] = (unsigned long long)(base + aggregate);
+      sh_base = base;
+    }
   }
   __syncthreads();
   const int64_t out0 = sh_base;

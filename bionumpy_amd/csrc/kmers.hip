@@ -3,6 +3,7 @@
 // mapping: every lane produces two adjacent int64 (one 16-byte store, 1 KiB contiguous per wavefront
 // instruction); the packed input words are shared between neighbouring lanes through L1.
 #include "common.h"
+#include "rows.h"
 
 namespace {
 
@@ -51,13 +52,6 @@ __device__ __forceinline__ uint64_t bits_at(const uint64_t* __restrict__ W, int6
   return sh ? (ww.lo >> sh) | (ww.hi << (64 - sh)) : ww.lo;
 }
 
-__device__ __forceinline__ void block_rows(const int64_t* __restrict__ out_off, int64_t n_rows, int64_t first,
-                                           int64_t last, int64_t* smem) {
-  if (threadIdx.x == 0) smem[0] = find_row(out_off, 0, n_rows - 1, first);
-  if (threadIdx.x == 64) smem[1] = find_row(out_off, 0, n_rows - 1, last);
-  __syncthreads();
-}
-
 __device__ __forceinline__ void store_pair(int64_t* __restrict__ out, int64_t o, int64_t n_out, int64_t a,
                                            int64_t b) {
   if (o + 1 < n_out && (((uintptr_t)(out + o)) & 15) == 0) {
@@ -75,11 +69,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void kmer_kernel(const uint64_t* __rest
                                                           const int64_t* __restrict__ in_off,
                                                           const int64_t* __restrict__ out_off, int64_t n_rows,
                                                           int64_t n_out, int k, int n_kmers,
+                                                          const int64_t* __restrict__ tile_rows,
                                                           int64_t* __restrict__ out) {
-  __shared__ int64_t rr[2];
+  int64_t rr[2];
   int64_t tile = (int64_t)blockIdx.x * TILE_OUT;
   if (tile >= n_out) return;
-  block_rows(out_off, n_rows, tile, min(tile + TILE_OUT, n_out) - 1, rr);
+  tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
   const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
@@ -110,11 +105,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void kmer_kernel(const uint64_t* __rest
 }
 
 __global__ __launch_bounds__(BNPK_BLOCK) void row_ids_kernel(const int64_t* __restrict__ off, int64_t n_rows,
-                                                             int64_t n, int64_t* __restrict__ rows) {
-  __shared__ int64_t rr[2];
+                                                             int64_t n, const int64_t* __restrict__ tile_rows,
+                                                             int64_t* __restrict__ rows) {
+  int64_t rr[2];
   int64_t tile = (int64_t)blockIdx.x * TILE_OUT;
   if (tile >= n) return;
-  block_rows(off, n_rows, tile, min(tile + TILE_OUT, n) - 1, rr);
+  tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
 #pragma unroll
   for (int p = 0; p < PAIRS; ++p) {
     int64_t o = tile + (int64_t)p * (BNPK_BLOCK * 2) + 2 * threadIdx.x;
@@ -138,9 +134,12 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
   int64_t blocks = ceil_div(n_out, TILE_OUT);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
   bnpk_timer t(ctx, "kmers", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL((kmer_kernel<false>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
-                     d_out_offsets, n_rows, n_out, k, 1, d_hashes);
+                     d_out_offsets, n_rows, n_out, k, 1, (const int64_t*)table, d_hashes);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
@@ -154,9 +153,12 @@ int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in
   int64_t blocks = ceil_div(n_out, TILE_OUT);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
   bnpk_timer t(ctx, "minimizers", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL((kmer_kernel<true>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
-                     d_out_offsets, n_rows, n_out, k, window_size - k + 1, d_out);
+                     d_out_offsets, n_rows, n_out, k, window_size - k + 1, (const int64_t*)table, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
@@ -169,8 +171,12 @@ int bnpk_row_ids(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_
   int64_t blocks = ceil_div(n, TILE_OUT);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
   bnpk_timer t(ctx, "row_ids", s);
-  hipLaunchKernelGGL(row_ids_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_offsets, n_rows, n, d_rows);
+  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
+  hipLaunchKernelGGL(row_ids_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_offsets, n_rows, n,
+                     (const int64_t*)table, d_rows);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
