@@ -15,6 +15,48 @@ __device__ __forceinline__ uint32_t dna_code(uint32_t b, bool* ok) {
   return ((u >> 1) & 3u) ^ ((u >> 2) & 1u);    // A C G T -> 0 1 2 3
 }
 
+constexpr uint64_t REP01 = 0x0101010101010101ull;
+constexpr uint64_t REP7F = 0x7f7f7f7f7f7f7f7full;
+constexpr uint64_t REP80 = 0x8080808080808080ull;
+
+// 0x80 in every byte of x that equals the byte replicated in rep (exact SWAR compare)
+__device__ __forceinline__ uint64_t eq_bytes(uint64_t x, uint64_t rep) {
+  uint64_t z = x ^ rep;
+  uint64_t t = (z & REP7F) + REP7F;
+  return ~(t | z | REP7F);
+}
+
+// up to 8 source bytes -> byte codes (0..3, invalid -> 0) + mask of invalid bytes (0x80 per bad byte)
+__device__ __forceinline__ uint64_t dna_codes8(uint64_t x, uint64_t lanes, uint64_t* bad) {
+  uint64_t u = x & (0xDFull * REP01);                       // fold lower case onto upper case
+  uint64_t valid = eq_bytes(u, 'A' * REP01) | eq_bytes(u, 'C' * REP01) | eq_bytes(u, 'G' * REP01) |
+                   eq_bytes(u, 'T' * REP01);
+  *bad = ~valid & REP80 & lanes;
+  uint64_t c = ((u >> 1) & (3ull * REP01)) ^ ((u >> 2) & REP01);   // A C G T -> 0 1 2 3
+  return c & ((valid >> 7) * 0xFFull) & lanes;
+}
+
+// eight byte codes (2 significant bits each) -> 16 packed bits
+__device__ __forceinline__ uint64_t compress_codes8(uint64_t c) {
+  uint64_t t = (c | (c >> 6)) & 0x000F000F000F000Full;
+  t = (t | (t >> 12)) & 0x000000FF000000FFull;
+  return (t | (t >> 24)) & 0xFFFFull;
+}
+
+// m (1..8) bytes at src as a little-endian uint64; one unaligned 8-byte load when the row still has 8 bytes
+__device__ __forceinline__ uint64_t load_upto8(const uint8_t* __restrict__ src, int seg, int* m) {
+  uint64_t x;
+  if (seg >= 8) {
+    __builtin_memcpy(&x, src, 8);
+    *m = 8;
+  } else {
+    x = 0;
+    for (int q = 0; q < seg; ++q) x |= (uint64_t)src[q] << (8 * q);
+    *m = seg;
+  }
+  return x;
+}
+
 template <bool WRITE_CODES, bool WRITE_PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
@@ -34,24 +76,39 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     return;
   }
   int64_t pos = w * BASES_PER_WORD;
-  int64_t end = min(pos + BASES_PER_WORD, total);
+  const int64_t end = min(pos + BASES_PER_WORD, total);
   int64_t row = find_row(offsets, rr[0], rr[1], pos);
   int64_t row_end = offsets[row + 1];
   const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
   uint64_t word = 0;
-  uint64_t cw[4] = {0, 0, 0, 0};
+  uint64_t cw[5] = {0, 0, 0, 0, 0};
   unsigned long long bad = (unsigned long long)BNPK_NONE;
-  for (int j = 0; pos < end; ++j, ++pos) {
+  int j = 0;                                    // bases produced so far
+  while (pos < end) {
     while (pos >= row_end) {                    // next non-empty row
       ++row;
       row_end = offsets[row + 1];
       src = buf + starts[row];
     }
-    bool ok;
-    uint32_t c = dna_code(*src++, &ok);
-    if (!ok) { c = 0; if ((unsigned long long)pos < bad) bad = (unsigned long long)pos; }
-    word |= (uint64_t)c << (2 * j);
-    if (WRITE_CODES) cw[j >> 3] |= (uint64_t)c << (8 * (j & 7));
+    int seg = (int)min(row_end - pos, end - pos);
+    while (seg > 0) {
+      int m;
+      uint64_t x = load_upto8(src, seg, &m);
+      uint64_t lanes = (m == 8) ? ~0ull : ((1ull << (8 * m)) - 1ull);
+      uint64_t badm;
+      uint64_t c = dna_codes8(x, lanes, &badm);
+      if (badm) {
+        unsigned long long at = (unsigned long long)(pos + ((__ffsll((long long)badm) - 1) >> 3));
+        if (at < bad) bad = at;
+      }
+      if (WRITE_CODES) {
+        int sh = 8 * (j & 7);
+        cw[j >> 3] |= c << sh;
+        if (sh) cw[(j >> 3) + 1] |= c >> (64 - sh);
+      }
+      word |= compress_codes8(c) << (2 * j);
+      j += m; src += m; pos += m; seg -= m;
+    }
   }
   if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
   if (WRITE_PACKED) packed[w] = word;
@@ -62,12 +119,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
       dst[0] = make_uint4((uint32_t)cw[0], (uint32_t)(cw[0] >> 32), (uint32_t)cw[1], (uint32_t)(cw[1] >> 32));
       dst[1] = make_uint4((uint32_t)cw[2], (uint32_t)(cw[2] >> 32), (uint32_t)cw[3], (uint32_t)(cw[3] >> 32));
     } else {
-      for (int j = 0; p0 + j < total; ++j) codes[p0 + j] = (uint8_t)(cw[j >> 3] >> (8 * (j & 7)));
+      for (int q = 0; p0 + q < total; ++q) codes[p0 + q] = (uint8_t)(cw[q >> 3] >> (8 * (q & 7)));
     }
   }
 }
 
-// plain gather, 16 output bytes per lane
+// plain gather (optionally subtracting a constant from every byte), 16 output bytes per lane
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
     int64_t n_rows, int64_t total, int subtract, const int64_t* __restrict__ tile_rows,
@@ -79,25 +136,38 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
   tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
   int64_t pos = blk_first + (int64_t)threadIdx.x * PER;
   if (pos >= total) return;
-  int64_t end = min(pos + PER, total);
+  const int64_t end = min(pos + PER, total);
   int64_t row = find_row(offsets, rr[0], rr[1], pos);
   int64_t row_end = offsets[row + 1];
   const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
-  uint64_t lo = 0, hi = 0;
-  int64_t p0 = pos;
-  for (int j = 0; pos < end; ++j, ++pos) {
+  uint64_t v[3] = {0, 0, 0};
+  const int64_t p0 = pos;
+  const uint64_t sub = (uint64_t)(subtract & 0xff) * REP01;
+  int j = 0;
+  while (pos < end) {
     while (pos >= row_end) {
       ++row;
       row_end = offsets[row + 1];
       src = buf + starts[row];
     }
-    uint64_t b = (uint8_t)(*src++ - subtract);
-    if (j < 8) lo |= b << (8 * j); else hi |= b << (8 * (j - 8));
+    int seg = (int)min(row_end - pos, end - pos);
+    while (seg > 0) {
+      int m;
+      uint64_t x = load_upto8(src, seg, &m);
+      // per-byte wrap-around subtraction without borrows between bytes
+      x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
+      if (m < 8) x &= (1ull << (8 * m)) - 1ull;
+      int sh = 8 * (j & 7);
+      v[j >> 3] |= x << sh;
+      if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
+      j += m; src += m; pos += m; seg -= m;
+    }
   }
   if (p0 + PER <= total && (((uintptr_t)(out + p0)) & 15) == 0) {
-    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    *reinterpret_cast<uint4*>(out + p0) =
+        make_uint4((uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
   } else {
-    for (int j = 0; p0 + j < total; ++j) out[p0 + j] = (uint8_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))));
+    for (int q = 0; p0 + q < total; ++q) out[p0 + q] = (uint8_t)(v[q >> 3] >> (8 * (q & 7)));
   }
 }
 

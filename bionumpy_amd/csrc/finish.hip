@@ -8,6 +8,8 @@
 //
 // A bucket larger than FB_CAP keys (heavy-hitter k-mers, low part_bits) sets the overflow flag; the caller
 // then falls back to the full sort + run kernels of count.hip, so results never depend on this fast path.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -44,7 +46,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_buckets_kernel(const uint64
                                                                     int shift, int64_t n_tiles,
                                                                     uint64_t* __restrict__ keys_out,
                                                                     int64_t* __restrict__ counts_out,
-                                                                    unsigned long long* __restrict__ state) {
+                                                                    unsigned long long* __restrict__ state,
+                                                                    int ablate) {
   __shared__ uint64_t key[FB_W];
   __shared__ uint64_t smask[FB_WORDS];          // bucket-start bits
   __shared__ uint64_t fmask[FB_WORDS];          // first-occurrence bits inside the owned range
@@ -137,7 +140,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_buckets_kernel(const uint64
     // The whole wavefront inspects 64 predecessors per round (lane 0 = nearest).
     unsigned long long* mine = &state[ST_TILES + t];
     long long base = 0;
-    if (t > 0) {
+    if (ablate & 1) base = g0;                    // timing ablation only (BNPK_ABLATE): skip the look-back
+    else if (t > 0) {
       if (lane == 0)
         __hip_atomic_store(mine, FLAG_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int64_t hi = t - 1;
@@ -182,6 +186,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_buckets_kernel(const uint64
       rank += (y < x) && ((fmask[q >> 6] >> (q & 63)) & 1ull);
     }
     int local = fprefix[bs >> 6] + __popcll(fmask[bs >> 6] & ((1ull << (bs & 63)) - 1ull)) + rank;
+    if (ablate & 2) continue;                    // timing ablation only: skip the stores
     keys_out[out0 + local] = x;
     counts_out[out0 + local] = cnt;
   }
@@ -207,13 +212,15 @@ int bnpk_finish_buckets(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, 
   int64_t n_tiles = ceil_div(n, FB_T);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
+  const char* ab = getenv("BNPK_ABLATE");        // kernel-timing experiments only; results are invalid when set
+  const int ablate = ab ? atoi(ab) : 0;
   BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)bnpk_finish_state_words(n) * sizeof(int64_t), s));
   {
     bnpk_timer t(ctx, "finish_buckets", s);
     hipLaunchKernelGGL(finish_buckets_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s,
                        reinterpret_cast<const uint64_t*>(d_part_sorted), n, key_bits - part_bits, n_tiles,
                        reinterpret_cast<uint64_t*>(d_keys_out), d_counts_out,
-                       reinterpret_cast<unsigned long long*>(d_state));
+                       reinterpret_cast<unsigned long long*>(d_state), ablate);
   }
   BNPK_HIP(ctx, hipGetLastError());
   int64_t host[3];
