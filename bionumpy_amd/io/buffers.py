@@ -29,7 +29,14 @@ def _chunk_to_harray(chunk):
         return chunk
     if isinstance(chunk, EncodedArray):
         return chunk._harray()
-    return HArray(host=np.asarray(chunk, dtype=np.uint8))
+    chunk = np.asarray(chunk, dtype=np.uint8)
+    ops = get_ops()
+    if not getattr(ops, "host_only", False):
+        from .pinned import pool
+        owner = pool().owner_of(chunk)
+        if owner is not None:                        # page-locked staging buffer -> hipMemcpyAsync into HBM
+            return ops.upload_pinned(chunk, owner)
+    return HArray(host=chunk)
 
 
 class FileBuffer:

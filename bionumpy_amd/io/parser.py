@@ -9,6 +9,7 @@ and reports how many bytes the complete entries cover (``buff.size``).
 import numpy as np
 
 from ..exceptions import FormatException
+from ..ops import get_ops
 
 
 class NumpyFileReader:
@@ -108,7 +109,10 @@ class NumpyFileReader:
         return chunk, bytes_read
 
     def _get_buffer(self, min_chunk_size=5000000, max_chunk_size=None):
-        # parser.py:192-206
+        # parser.py:192-206; on the GPU the bytes land in a pinned staging buffer (io/pinned.py) so that the
+        # upload in from_raw_buffer is one hipMemcpyAsync out of page-locked memory
+        if hasattr(self._file_obj, "readinto") and not getattr(get_ops(), "host_only", False):
+            return self._get_pinned_buffer(min_chunk_size)
         a = np.frombuffer(self._file_obj.read(min_chunk_size), dtype="uint8")
         bytes_read = a.size
         self._is_finished = bytes_read < min_chunk_size
@@ -117,3 +121,19 @@ class NumpyFileReader:
         if self._is_finished:
             a, bytes_read = self.__add_newline_to_end(a, bytes_read)
         return a[:bytes_read]
+
+    def _get_pinned_buffer(self, min_chunk_size):
+        from .pinned import read_into_pinned
+        a, buf = read_into_pinned(self._file_obj, min_chunk_size, headroom=2)
+        bytes_read = a.size
+        self._is_finished = bytes_read < min_chunk_size
+        if bytes_read == 0:
+            return None
+        if self._is_finished:                       # same rule as __add_newline_to_end, written in place
+            if buf.array[bytes_read - 1] != ord("\n"):
+                buf.array[bytes_read] = ord("\n")
+                bytes_read += 1
+            if hasattr(self._buffer_type, "_new_entry_marker"):
+                buf.array[bytes_read] = ord(self._buffer_type._new_entry_marker)
+                bytes_read += 1
+        return buf.array[:bytes_read]

@@ -38,6 +38,18 @@ class HipOps:
     def _empty(self, n, dtype):
         return self.device.empty(n, dtype)
 
+    # -- host staging --------------------------------------------------------------------------------
+    def upload_pinned(self, array, pinned_buffer):
+        """hipMemcpyAsync of a numpy view of a pinned staging buffer into a fresh HBM tensor"""
+        n = array.size
+        t = self._empty(n, np.uint8)
+        src = C.c_void_p(array.__array_interface__["data"][0])
+        stream = self._s()
+        self._chk(lib.bnpk_copy_h2d_async(ptr(t), src, n, stream))
+        pinned_buffer.in_flight = True
+        pinned_buffer.stream = stream                # the reader syncs this stream before reusing the buffer
+        return HArray(dev=t)
+
     # -- A2 + A3: newline scan and entry validation --------------------------------------------------
     def newline_positions(self, buf, n, limit_multiple=1):
         """positions of '\\n' in buf[:n], truncated to a multiple of ``limit_multiple`` lines"""

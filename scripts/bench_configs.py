@@ -1,0 +1,92 @@
+"""Measure the non-headline BASELINE.json configs on one MI355X and print one JSON object.
+
+  config 3: 150 bp x N reads, k=31 minimizers (window_size 40 == w=10 k-mers)
+  config 5: sacCer3.fa.gz KmerIndex build (k=31) + lookup of every 31-mer of big.fq.gz
+  stream  : bnp.open(<synthetic .fq file>).read_chunks(256 MB) -> count_kmers(k=31), pinned H2D path included
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import bionumpy_amd as bnp
+from bionumpy_amd import synth
+from bionumpy_amd.device import Device, HArray
+from bionumpy_amd.ops import get_ops
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+reads = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+ops = get_ops()
+dev = Device.get()
+out = {}
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ---- config 3: minimizers ----------------------------------------------------------------------------------
+text = ops.synth_fastq(reads, 150, 20260925, 0, 0, 0)
+sync()
+def minimizer_step():
+    buf = bnp.FastQBuffer.from_raw_buffer(text)
+    seqs = bnp.change_encoding(buf.get_field_by_number(1), bnp.DNAEncoding)
+    m = bnp.get_minimizers(seqs, 31, 40)
+    return m
+m = minimizer_step(); n_out = m.total(); del m
+sync(); dev.prof_enable(True); dev.prof_reset()
+t0 = time.perf_counter()
+for _ in range(2):
+    m = minimizer_step(); del m
+sync(); dt = (time.perf_counter() - t0) / 2
+prof = dev.prof_report(); dev.prof_enable(False)
+out["config3_minimizers"] = {"reads": reads, "k": 31, "window_size": 40, "n_minimizers": n_out,
+                             "ms_per_step": round(dt * 1e3, 2), "gbases_per_s": round(reads * 150 / dt / 1e9, 2),
+                             "minimizers_kernel_ms": round(prof["minimizers"]["total_ms"] / 2, 2),
+                             "minimizers_kernel_gbs": round((8 * n_out + reads * 150 / 4) / (prof["minimizers"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
+del text
+
+# ---- config 5: sacCer3 index + big.fq.gz lookups ---------------------------------------------------------------
+t0 = time.perf_counter()
+genome = bnp.open(os.path.join(GOLD, "sacCer3.fa.gz")).read()
+seqs = bnp.change_encoding(genome.sequence, bnp.DNAEncoding)
+sync(); t_read = time.perf_counter() - t0
+t0 = time.perf_counter()
+index = bnp.KmerIndex.create_index(seqs, k=31)
+sync(); t_build = time.perf_counter() - t0
+t0 = time.perf_counter()
+index = bnp.KmerIndex.create_index(seqs, k=31)
+sync(); t_build2 = time.perf_counter() - t0
+reads_fq = bnp.open(os.path.join(GOLD, "big.fq.gz")).read()
+q = bnp.get_kmers(bnp.change_encoding(reads_fq.sequence, bnp.DNAEncoding), 31)
+q._compact()
+t0 = time.perf_counter()
+lo, hi = index.get_indices_batch(q._flat_data())
+sync(); t_lookup = time.perf_counter() - t0
+hits = int((hi.dev() > lo.dev()).sum().item())
+out["config5_kmer_index"] = {"genome_rows": len(genome), "genome_bases": int(seqs.total()), "index_pairs": index._keys.size,
+                             "read_decode_s": round(t_read, 3), "build_s_first": round(t_build, 4),
+                             "build_s": round(t_build2, 4), "queries": int(q.total()),
+                             "lookup_s": round(t_lookup, 5), "queries_with_hit": hits}
+
+# ---- streamed file -> 31-mer histogram (host file read + pinned H2D included) ----------------------------------------
+n_file = min(reads, 4_000_000)
+path = "/tmp/bnpk_stream_test.fq"
+synth.fastq_bytes(n_file, 150, 7, 1, 5_000_000).tofile(path)
+def stream_count():
+    total = None
+    for chunk in bnp.open(path).read_chunks(min_chunk_size=256_000_000):
+        c = bnp.sequence.count_kmers(chunk.sequence, 31)
+        total = c if total is None else total + c
+    return total
+c = stream_count(); sync()
+t0 = time.perf_counter(); c = stream_count(); sync(); dt = time.perf_counter() - t0
+out["stream_file_to_histogram"] = {"reads": n_file, "file_bytes": os.path.getsize(path), "chunk_bytes": 256_000_000,
+                                   "seconds": round(dt, 3), "gbases_per_s": round(n_file * 150 / dt / 1e9, 3),
+                                   "distinct": len(c), "file_gb_per_s": round(os.path.getsize(path) / dt / 1e9, 2)}
+os.remove(path)
+print(json.dumps(out))
