@@ -58,6 +58,8 @@ class NumpyFileReader:
         made_buffer = None
         chunk = None
         while not complete_entry_found:
+            # chunks that must outlive the next read cannot stay views of a (recycled) pinned staging buffer
+            temp_chunks = [self._detach(c) for c in temp_chunks]
             chunk = self._get_buffer(min_chunk_size, max_chunk_size)
             if chunk is None:
                 return None
@@ -85,7 +87,7 @@ class NumpyFileReader:
             if not self._do_prepend:
                 self._file_obj.seek(buff.size - chunk.size, 1)
             else:
-                self._prepend = chunk[buff.size:]
+                self._prepend = self._detach(chunk[buff.size:])
         if chunk is not None and chunk.size:
             self.n_bytes_read += buff.size
             self.n_lines_read += buff.n_lines
@@ -121,6 +123,13 @@ class NumpyFileReader:
         if self._is_finished:
             a, bytes_read = self.__add_newline_to_end(a, bytes_read)
         return a[:bytes_read]
+
+    @staticmethod
+    def _detach(chunk):
+        from .pinned import pool
+        if isinstance(chunk, np.ndarray) and pool().owner_of(chunk) is not None:
+            return chunk.copy()
+        return chunk
 
     def _get_pinned_buffer(self, min_chunk_size):
         from .pinned import read_into_pinned
