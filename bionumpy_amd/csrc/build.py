@@ -14,8 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbnpk.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "scan.hip", "decode.hip", "encode.hip", "kmers.hip", "count.hip", "finish.hip", "synth.hip"]
-HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"),
+SOURCES = ["api.hip", "scan.hip", "decode.hip", "encode.hip", "kmers.hip", "partition.hip", "count.hip", "finish.hip", "synth.hip"]
+HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"), os.path.join(HERE, "rows.h"),
+           os.path.join(HERE, "kmer_gen.h"),
            os.path.join(ROOT, "include", "bnpk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result"]

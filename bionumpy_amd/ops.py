@@ -213,8 +213,24 @@ class HipOps:
                                       self._s()))
         return int(n_runs.value), tile_off
 
-    def count_sparse(self, values, key_bits=62, consume=False, fast=True):
-        """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys)."""
+    @staticmethod
+    def sparse_part_bits(n, key_bits):
+        """how many top bits the radix sort must order before finish_buckets takes over: ~log2(n) - 1,
+        rounded up to whole 8-bit passes"""
+        return min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
+
+    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, digit_shift):
+        """bnpk_kmers_partition: the k-mer hashes written once, partitioned by the 8-bit digit at digit_shift"""
+        out = self._empty(n_out, np.int64)
+        self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
+                                           n_rows, n_out, k, digit_shift, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def count_sparse(self, values, key_bits=62, consume=False, fast=True, first_digit_done=False):
+        """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys).
+
+        first_digit_done: ``values`` came from kmers_partitioned(digit_shift = key_bits - sparse_part_bits(n)),
+        i.e. the lowest of the radix passes has already happened."""
         t = values.dev()
         n = t.numel()
         if n == 0:
@@ -224,8 +240,12 @@ class HipOps:
         if fast and key_bits <= 62:
             # fast path: radix-sort only the top ~log2(n) bits (whole 8-bit passes), then one fused kernel
             # ranks + run-length-counts + compacts inside the (tiny) buckets of equal top bits
-            part_bits = min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
-            part_t, free_t = self.sort_keys(work, key_bits, begin_bit=key_bits - part_bits)
+            part_bits = self.sparse_part_bits(n, key_bits)
+            begin = key_bits - part_bits + (8 if first_digit_done else 0)
+            if begin < key_bits:
+                part_t, free_t = self.sort_keys(work, key_bits, begin_bit=begin)
+            else:
+                part_t, free_t = work, self._empty(n, np.int64)
             counts = self._empty(n, np.int64)
             state = self._empty(lib.bnpk_finish_state_words(n), np.int64)
             n_unique, overflow = C.c_int64(0), C.c_int(0)

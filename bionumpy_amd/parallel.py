@@ -51,17 +51,23 @@ def rank_of_bucket(world):
     return (np.arange(1 << FINE_BITS, dtype=np.int64) * world) >> FINE_BITS
 
 
-def exchange_by_key_range(hashes, key_bits, group=None):
+def exchange_by_key_range(hashes, key_bits, group=None, already_partitioned=False):
     """all-to-all of raw k-mer hashes so that every rank ends up with exactly the keys of its own range.
 
-    ``hashes`` (HArray int64, consumed) -> HArray int64 of the received keys (unsorted within the range)."""
+    ``hashes`` (HArray int64, consumed) -> HArray int64 of the received keys (unsorted within the range).
+    already_partitioned: the hashes are grouped by their top FINE_BITS bits (bnpk_kmers_partition)."""
     ops = get_ops()
     dist = _dist()
     world = dist.get_world_size(group)
     if world == 1:
         return hashes
     import torch
-    part, cuts = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
+    if already_partitioned:
+        part = hashes
+        bounds = np.arange(1 << FINE_BITS, dtype=np.int64) << (key_bits - FINE_BITS)
+        cuts = np.append(ops.search_sorted(part, HArray(host=bounds), upper=False).host(), part.size).astype(np.int64)
+    else:
+        part, cuts = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
     owner = rank_of_bucket(world)
     bucket_sizes = np.diff(cuts)
     send_counts = np.bincount(owner, weights=bucket_sizes, minlength=world).astype(np.int64)
@@ -76,8 +82,8 @@ def exchange_by_key_range(hashes, key_bits, group=None):
     return _from_tensor(recv_t, ops)
 
 
-def count_sparse_distributed(hashes, key_bits, group=None):
+def count_sparse_distributed(hashes, key_bits, group=None, already_partitioned=False):
     """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range"""
     ops = get_ops()
-    mine = exchange_by_key_range(hashes, key_bits, group)
+    mine = exchange_by_key_range(hashes, key_bits, group, already_partitioned)
     return ops.count_sparse(mine, key_bits=key_bits, consume=True)

@@ -6,8 +6,10 @@ docs_source/topics/kmers.rst:42-62):
     for chunk in bnp.open(fq).read_chunks(): counts += count_kmers(change_encoding(chunk.sequence, DNA), k)
 
 but on one batch sized for 288 GB of HBM (tens of millions of reads) instead of 5 MB chunks, and with
-every intermediate released as soon as the next stage has consumed it.  bench.py times exactly this
-function; __graft_entry__.smoke() and the tests check it against the oracle.
+every intermediate released as soon as the next stage has consumed it.  For the sparse histogram the
+k-mer hashes are never materialised in read order: ``bnpk_kmers_partition`` generates them straight
+into the first radix pass of the sort.  bench.py times exactly this function; __graft_entry__.smoke()
+and the tests check it against the oracle.
 """
 from collections import namedtuple
 
@@ -20,7 +22,7 @@ DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB; above that the histogra
 BatchStats = namedtuple("BatchStats", "n_reads n_bases n_kmers n_bytes")
 
 
-def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer):
+def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=True):
     """text: HArray uint8 holding complete FASTQ records.  Returns (histogram, BatchStats) where the
     histogram is a dense int64 HArray (k <= 13; summed over ranks if ``group``) or a (keys, counts) pair
     of HArrays (k > 13; range-partitioned over ranks if ``group``)."""
@@ -37,19 +39,30 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer):
     del starts
     out_offsets, n_kmers = ops.row_offsets(lens, k)
     del lens
-    hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)                                   # A8
-    del packed, offsets, out_offsets
     stats = BatchStats(n, n_bases, n_kmers, n_bytes)
     distributed = group is not None or _world_size() > 1
-    if k <= DENSE_MAX_K:                                                                              # A9 dense
+    key_bits = 2 * k
+    if k <= DENSE_MAX_K:                                                                              # A8 + A9 dense
+        hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
+        del packed, offsets, out_offsets
         hist = ops.count_dense(hashes, 4 ** k)
         del hashes
         if distributed:
             hist = parallel.allreduce_dense(hist, group)
         return hist, stats
-    if distributed:                                                                                   # A9 sparse
-        return parallel.count_sparse_distributed(hashes, 2 * k, group), stats
-    return ops.count_sparse(hashes, key_bits=2 * k, consume=True), stats
+    if distributed:                                                                                   # A9 sparse, N GPUs
+        # generate the hashes already partitioned by their top 8 bits == by owning rank
+        part = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, key_bits - parallel.FINE_BITS)
+        del packed, offsets, out_offsets
+        return parallel.count_sparse_distributed(part, key_bits, group, already_partitioned=True), stats
+    if fused:                                                                                         # A8 + A9 sparse
+        part_bits = ops.sparse_part_bits(n_kmers, key_bits)
+        hashes = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, key_bits - part_bits)
+        del packed, offsets, out_offsets
+        return ops.count_sparse(hashes, key_bits=key_bits, consume=True, first_digit_done=True), stats
+    hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
+    del packed, offsets, out_offsets
+    return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
 
 
 def _world_size():

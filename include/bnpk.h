@@ -148,6 +148,14 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
                const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
                int64_t* d_hashes, void* stream);
 
+/* Same hashes, but never materialised in row order: written exactly once, already partitioned (not
+ * stably) by the 8-bit digit at bit `digit_shift` — the first pass of the histogram's radix sort
+ * fused into the generation (bionumpy/sequence/kmers.py:121-126 + the np.unique of SURVEY §3.5).
+ * The multiset of values equals bnpk_kmers'; only the order differs. */
+int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
+                         const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
+                         int digit_shift, int64_t* d_out, void* stream);
+
 /* ---- A11: minimizers -----------------------------------------------------------------------------
  * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every
  * window of `window_size` bases the minimum raw hash of its window_size-k+1 k-mers.

@@ -46,6 +46,14 @@ class OracleOps:
         cuts = np.searchsorted(bucket[order], np.arange((1 << top_bits) + 1))
         return _h(v[order]), cuts.astype(np.int64)
 
+    @staticmethod
+    def sparse_part_bits(n, key_bits):
+        return min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
+
+    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, digit_shift):
+        h = self.kmers(packed, in_offsets, out_offsets, n_rows, n_out, k).host()
+        return _h(h[np.argsort((h >> digit_shift) & 255, kind="stable")])
+
     # -- decode -----------------------------------------------------------------------------------
     def newline_positions(self, buf, n, limit_multiple=1):
         pos = np.flatnonzero(buf.host()[:n] == NEWLINE).astype(np.int64)
@@ -143,7 +151,7 @@ class OracleOps:
         return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins) for r in range(n_rows)],
                            dtype=np.int64).reshape(-1))
 
-    def count_sparse(self, values, key_bits=62, consume=False):
+    def count_sparse(self, values, key_bits=62, consume=False, fast=True, first_digit_done=False):
         k, c = oracle.count_sparse(values.host())
         return _h(k), _h(c)
 

@@ -180,3 +180,28 @@ def test_heavy_hitters_take_the_fallback(ops):
     keys, counts = ops.count_sparse(_h(small), key_bits=18)
     ek, ec = oracle.count_sparse(small)
     assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+
+
+@pytest.mark.parametrize("seed,n_rows,max_len,k", [(5, 1, 40, 5), (6, 3000, 200, 31), (7, 40_000, 300, 31),
+                                                   (8, 17, 100_000, 21), (9, 5000, 60, 13)])
+def test_fused_kmer_partition(ops, seed, n_rows, max_len, k):
+    """bnpk_kmers_partition == bnpk_kmers as a multiset, grouped by the requested 8-bit digit"""
+    text, starts, lengths = _random_reads(seed, n_rows, max_len)
+    offsets, total = ops.row_offsets(_h(lengths), 1)
+    _, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total)
+    out_off, n_out = ops.row_offsets(_h(lengths), k)
+    plain = ops.kmers(packed, offsets, out_off, n_rows, n_out, k).host()
+    for shift in (0, max(0, 2 * k - 8), max(0, 2 * k - 24)):
+        part = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, shift).host()
+        digits = (part >> shift) & 255
+        assert np.all(np.diff(digits) >= 0)
+        assert np.array_equal(np.sort(part), np.sort(plain))
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    # whole pipeline, fused vs unfused vs oracle
+    if n_rows >= 3000 and k == 31:
+        codes = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
+        ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lengths, k)[0])
+        part_bits = ops.sparse_part_bits(n_out, 2 * k)
+        hashes = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, 2 * k - part_bits)
+        keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True, first_digit_done=True)
+        assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
