@@ -73,6 +73,7 @@ SIGNATURES = {
     "bnpk_sort_keys": (_int, [_p, _p, _p, _i64, _int, _int, C.POINTER(_int), _p]),
     "bnpk_sort_pairs": (_int, [_p, _p, _p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
     "bnpk_finish_state_words": (_i64, [_i64]),
+    "bnpk_finish_small": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
     "bnpk_finish_buckets": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
     "bnpk_run_tiles": (_i64, [_i64]),
     "bnpk_run_census": (_int, [_p, _p, _p, _i64, _p, C.POINTER(_i64), _p]),

@@ -249,10 +249,12 @@ class HipOps:
             counts = self._empty(n, np.int64)
             state = self._empty(lib.bnpk_finish_state_words(n), np.int64)
             n_unique, overflow = C.c_int64(0), C.c_int(0)
-            self._chk(lib.bnpk_finish_buckets(self.ctx, ptr(part_t), n, key_bits, part_bits, ptr(free_t), ptr(counts),
-                                              ptr(state), C.byref(n_unique), C.byref(overflow), self._s()))
-            if not overflow.value:
-                return HArray(dev=free_t[:n_unique.value]), HArray(dev=counts[:n_unique.value])
+            # tier 1: register/shuffle kernel for buckets <= ~32 keys; tier 2: LDS-window kernel (<= 1024)
+            for finish in (lib.bnpk_finish_small, lib.bnpk_finish_buckets):
+                self._chk(finish(self.ctx, ptr(part_t), n, key_bits, part_bits, ptr(free_t), ptr(counts),
+                                 ptr(state), C.byref(n_unique), C.byref(overflow), self._s()))
+                if not overflow.value:
+                    return HArray(dev=free_t[:n_unique.value]), HArray(dev=counts[:n_unique.value])
             del counts, state
             work = part_t                                 # heavy-hitter buckets: fall back to the full sort
             del free_t

@@ -194,6 +194,11 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  * kernels below.  d_state needs bnpk_finish_state_words(n) int64; d_keys_out / d_counts_out need n
  * entries and must not alias the input. */
 int64_t bnpk_finish_state_words(int64_t n);
+/* Tier 1 of the same operation for buckets of at most ~32 keys: wave-synchronous (registers + lane
+ * shuffles, no LDS window, no workgroup barrier), same contract; on overflow try bnpk_finish_buckets. */
+int bnpk_finish_small(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits,
+                      int part_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                      int64_t* h_n_unique, int* h_overflow, void* stream);
 int bnpk_finish_buckets(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits,
                         int part_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                         int64_t* h_n_unique, int* h_overflow, void* stream);
