@@ -220,6 +220,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_small_kernel(const uint64_t
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * (BNPK_BLOCK / 64) + (threadIdx.x >> 6);
   if (chunk >= n_chunks) return;
+  // an oversized bucket anywhere voids the whole tier: later wavefronts leave at once
+  if (!WRITE && __hip_atomic_load(&flags[ST_OVERFLOW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
   const int64_t g0 = chunk * FS_CHUNK;
   const uint64_t le_mask = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);     // bits 0..lane
   uint64_t before = (g0 > 0) ? A[g0 - 1] : ~0ull;                               // key just before the window
@@ -241,6 +243,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void finish_small_kernel(const uint64_t
     const uint64_t above = smask & ~le_mask;
     const int be = above ? __ffsll((long long)above) - 1 : 64;
     if (owned && be == 64) overflow = true;                                     // bucket runs off the window
+    if (!WRITE && __any(overflow)) {
+      if (lane == 0) atomicOr(&flags[ST_OVERFLOW], 1ull);
+      return;
+    }
     bool first = owned;                                                         // first occurrence in its bucket?
     for (int d = 1; __any(owned && (lane - d >= bs)); ++d) {
       uint64_t y = __shfl(key, (lane - d) & 63, 64);
