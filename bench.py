@@ -40,8 +40,13 @@ def algorithmic_bytes(name, s, read_len, k):
         "row_offsets": 8 * n + 8 * n,                         # lens in, offsets out
         "gather_encode_dna": bases + 16 * n + bases / 4,      # sequence bytes + start/offset + packed out
         "kmers": bases / 4 + 16 * n + 8 * kmers,              # packed in, offsets, 8 B per k-mer out
+        "kmers_partition_hist": bases / 4 + 16 * n,           # packed reads + offsets in, 256 counters/slab out
+        "kmers_partition_scatter": bases / 4 + 16 * n + 8 * kmers,   # same input, every hash written once
         "sort_keys": 16 * kmers,                              # read every key once, write it once sorted
         "partition_keys": 16 * kmers,
+        "finish_small_count": 8 * kmers,                      # read the bucket-sorted keys
+        "finish_small_write": 8 * kmers + 16 * kmers,         # read them again, write key + count (all distinct)
+        "finish_buckets": 8 * kmers + 16 * kmers,
         "run_census": 8 * kmers,                              # read sorted keys
         "run_heads": 8 * kmers + 16 * kmers,                  # read keys, write key + run start (all distinct)
         "run_sums": 16 * kmers,

@@ -66,15 +66,17 @@ SIGNATURES = {
     "bnpk_pack_codes": (_int, [_p, _p, _i64, _p, _p]),
     "bnpk_unpack_codes": (_int, [_p, _p, _i64, _int, _p, _p]),
     "bnpk_kmers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
-    "bnpk_kmers_partition": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
+    "bnpk_kmers_partition": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _int, _p, _p, _p]),
     "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
     "bnpk_count_dense": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "bnpk_count_dense_rows": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "bnpk_sort_keys": (_int, [_p, _p, _p, _i64, _int, _int, C.POINTER(_int), _p]),
     "bnpk_sort_pairs": (_int, [_p, _p, _p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
+    "bnpk_radix_max_bits": (_i64, []),
+    "bnpk_finish_capacity": (_i64, []),
+    "bnpk_radix_partition": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
     "bnpk_finish_state_words": (_i64, [_i64]),
-    "bnpk_finish_small": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
-    "bnpk_finish_buckets": (_int, [_p, _p, _i64, _int, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
+    "bnpk_finish_sorted": (_int, [_p, _p, _i64, _p, _i64, _int, _p, _p, _p, C.POINTER(_i64), C.POINTER(_int), _p]),
     "bnpk_run_tiles": (_i64, [_i64]),
     "bnpk_run_census": (_int, [_p, _p, _p, _i64, _p, C.POINTER(_i64), _p]),
     "bnpk_run_heads": (_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p]),

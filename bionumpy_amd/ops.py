@@ -195,13 +195,10 @@ class HipOps:
         return (alt, keys_t) if in_alt.value else (keys_t, alt)
 
     def partition_by_top_bits(self, values, key_bits, top_bits):
-        """stable partition of the keys by their top ``top_bits`` bits (of ``key_bits``); consumes ``values``.
+        """partition of the keys by their top ``top_bits`` bits (of ``key_bits``), one MSD radix level.
         Returns the partitioned keys and the bucket boundaries (2^top_bits + 1 offsets, host numpy)."""
-        t = values.dev()
-        part, _ = self.sort_keys(t, key_bits, begin_bit=key_bits - top_bits)
-        bounds = np.arange(1 << top_bits, dtype=np.int64) << (key_bits - top_bits)
-        cuts = self.search_sorted(HArray(dev=part), HArray(host=bounds), upper=False).host()
-        return HArray(dev=part), np.append(cuts, part.numel()).astype(np.int64)
+        out, child = self.radix_partition(values.dev(), None, 1, key_bits - top_bits, top_bits)
+        return HArray(dev=out), child.cpu().numpy()
 
     def _runs(self, sorted_t, second_t=None):
         """run boundaries of a sorted tensor (optionally of (sorted, second) pairs): n_runs, tile offsets"""
@@ -213,51 +210,83 @@ class HipOps:
                                       self._s()))
         return int(n_runs.value), tile_off
 
-    @staticmethod
-    def sparse_part_bits(n, key_bits):
-        """how many top bits the radix sort must order before finish_buckets takes over: ~log2(n) - 1,
-        rounded up to whole 8-bit passes"""
-        return min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
+    # -- sparse histogram: MSD radix partition (write-combining scatter) + in-LDS finishing sort -------------
+    FINISH_TARGET = 6000          # average bucket size the plan aims for (bnpk_finish_capacity() is 8192)
 
-    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, digit_shift):
-        """bnpk_kmers_partition: the k-mer hashes written once, partitioned by the 8-bit digit at digit_shift"""
+    @classmethod
+    def radix_plan(cls, n, key_bits, done=0):
+        """digit widths of the MSD levels still to run so that the buckets average <= FINISH_TARGET keys,
+        given that the top ``done`` bits are already resolved"""
+        need = 0
+        while need < key_bits and (n >> need) > cls.FINISH_TARGET:
+            need += 1
+        rest = max(0, need - done)
+        if rest == 0:
+            return []
+        max_bits = 10                                    # bnpk_radix_max_bits()
+        levels = -(-rest // max_bits)
+        base, extra = divmod(rest, levels)
+        return [base + (1 if i < extra else 0) for i in range(levels)]
+
+    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, bits):
+        """bnpk_kmers_partition: the k-mer hashes written once, partitioned by their top ``bits`` bits.
+        Returns (hashes, bucket offsets[2^bits + 1])"""
         out = self._empty(n_out, np.int64)
+        child = self._empty((1 << bits) + 1, np.int64)
         self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
-                                           n_rows, n_out, k, digit_shift, ptr(out), self._s()))
-        return HArray(dev=out)
+                                           n_rows, n_out, k, 2 * k - bits, bits, ptr(out), ptr(child), self._s()))
+        return HArray(dev=out), HArray(dev=child)
 
-    def count_sparse(self, values, key_bits=62, consume=False, fast=True, first_digit_done=False):
+    def radix_partition(self, keys_t, seg_offsets_t, n_seg, shift, bits, out_t=None):
+        """one MSD level over torch tensors: returns (partitioned keys, child offsets[n_seg * 2^bits + 1])"""
+        n = keys_t.numel()
+        out = out_t if out_t is not None else self._empty(n, np.int64)
+        child = self._empty(n_seg * (1 << bits) + 1, np.int64)
+        self._chk(lib.bnpk_radix_partition(self.ctx, ptr(keys_t), n, ptr(seg_offsets_t), n_seg, shift, bits, ptr(out),
+                                           ptr(child), self._s()))
+        return out, child
+
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True):
         """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys).
 
-        first_digit_done: ``values`` came from kmers_partitioned(digit_shift = key_bits - sparse_part_bits(n)),
-        i.e. the lowest of the radix passes has already happened."""
+        partition: (bucket_offsets, bits) if ``values`` is already grouped by its top ``bits`` bits
+        (kmers_partitioned).  key_range: (lo, hi) if all values are known to lie in [lo, hi) (the key range a
+        rank owns after the multi-GPU exchange) — the shared leading bits are then skipped by the partition.
+        fast=False forces the fallback (rocPRIM sort + run kernels) that heavy-hitter buckets take."""
         t = values.dev()
         n = t.numel()
         if n == 0:
             z = self._empty(0, np.int64)
             return HArray(dev=z), HArray(dev=z.clone())
-        work = t if consume else t.clone()
+        cur, owned = t, consume                          # owned: may ``cur`` be overwritten / handed out?
+        spare = None
         if fast and key_bits <= 62:
-            # fast path: radix-sort only the top ~log2(n) bits (whole 8-bit passes), then one fused kernel
-            # ranks + run-length-counts + compacts inside the (tiny) buckets of equal top bits
-            part_bits = self.sparse_part_bits(n, key_bits)
-            begin = key_bits - part_bits + (8 if first_digit_done else 0)
-            if begin < key_bits:
-                part_t, free_t = self.sort_keys(work, key_bits, begin_bit=begin)
-            else:
-                part_t, free_t = work, self._empty(n, np.int64)
+            skip, n_plan = 0, n
+            if key_range is not None and partition is None:
+                lo, hi = int(key_range[0]), int(key_range[1])
+                skip = key_bits - (lo ^ (hi - 1)).bit_length()
+                n_plan = int(n * (1 << (key_bits - skip)) / max(hi - lo, 1))
+            offsets, done = (partition[0].dev(), partition[1]) if partition is not None else (None, 0)
+            n_seg = 1 << done
+            for bits in self.radix_plan(n_plan, key_bits - skip, done):
+                out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
+                spare = cur if owned else None
+                cur, owned = out, True
+                done += bits
+                n_seg <<= bits
+            if offsets is None:
+                offsets = self.device.upload(np.array([0, n], dtype=np.int64))
+            keys_out = spare if spare is not None else self._empty(n, np.int64)
             counts = self._empty(n, np.int64)
-            state = self._empty(lib.bnpk_finish_state_words(n), np.int64)
+            state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
             n_unique, overflow = C.c_int64(0), C.c_int(0)
-            # tier 1: register/shuffle kernel for buckets <= ~32 keys; tier 2: LDS-window kernel (<= 1024)
-            for finish in (lib.bnpk_finish_small, lib.bnpk_finish_buckets):
-                self._chk(finish(self.ctx, ptr(part_t), n, key_bits, part_bits, ptr(free_t), ptr(counts),
-                                 ptr(state), C.byref(n_unique), C.byref(overflow), self._s()))
-                if not overflow.value:
-                    return HArray(dev=free_t[:n_unique.value]), HArray(dev=counts[:n_unique.value])
-            del counts, state
-            work = part_t                                 # heavy-hitter buckets: fall back to the full sort
-            del free_t
+            self._chk(lib.bnpk_finish_sorted(self.ctx, ptr(cur), n, ptr(offsets), n_seg, key_bits - skip - done,
+                                             ptr(keys_out), ptr(counts), ptr(state), C.byref(n_unique),
+                                             C.byref(overflow), self._s()))
+            if not overflow.value:
+                return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
+            del counts, state, keys_out, spare          # heavy-hitter buckets: fall back to the full sort
+        work = cur if owned else cur.clone()
         sorted_t, free_t = self.sort_keys(work, key_bits)
         n_runs, tile_off = self._runs(sorted_t)
         keys_out = free_t[:n_runs]                       # the ping-pong buffer is free after the sort

@@ -51,24 +51,27 @@ def rank_of_bucket(world):
     return (np.arange(1 << FINE_BITS, dtype=np.int64) * world) >> FINE_BITS
 
 
-def exchange_by_key_range(hashes, key_bits, group=None, already_partitioned=False):
+def exchange_by_key_range(hashes, key_bits, group=None, cuts=None):
     """all-to-all of raw k-mer hashes so that every rank ends up with exactly the keys of its own range.
 
-    ``hashes`` (HArray int64, consumed) -> HArray int64 of the received keys (unsorted within the range).
-    already_partitioned: the hashes are grouped by their top FINE_BITS bits (bnpk_kmers_partition)."""
+    ``hashes`` (HArray int64, consumed) -> (HArray int64 of the received keys, unsorted within the range,
+    (lo, hi) key range this rank owns).
+    cuts: bucket boundaries if the hashes are already grouped by their top FINE_BITS bits
+    (bnpk_kmers_partition); otherwise one radix level partitions them here."""
     ops = get_ops()
     dist = _dist()
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    owner = rank_of_bucket(world)
+    mine = np.flatnonzero(owner == rank)
+    key_range = (int(mine[0]) << (key_bits - FINE_BITS), (int(mine[-1]) + 1) << (key_bits - FINE_BITS))
     if world == 1:
-        return hashes
+        return hashes, key_range
     import torch
-    if already_partitioned:
-        part = hashes
-        bounds = np.arange(1 << FINE_BITS, dtype=np.int64) << (key_bits - FINE_BITS)
-        cuts = np.append(ops.search_sorted(part, HArray(host=bounds), upper=False).host(), part.size).astype(np.int64)
+    if cuts is not None:
+        part, cuts = hashes, np.asarray(cuts.host(), dtype=np.int64)
     else:
         part, cuts = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
-    owner = rank_of_bucket(world)
     bucket_sizes = np.diff(cuts)
     send_counts = np.bincount(owner, weights=bucket_sizes, minlength=world).astype(np.int64)
     send_t = _as_tensor(part, ops)
@@ -79,11 +82,11 @@ def exchange_by_key_range(hashes, key_bits, group=None, already_partitioned=Fals
     recv_t = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=send_t.device)
     dist.all_to_all_single(recv_t, send_t, output_split_sizes=recv_counts.tolist(),
                            input_split_sizes=send_counts.tolist(), group=group)
-    return _from_tensor(recv_t, ops)
+    return _from_tensor(recv_t, ops), key_range
 
 
-def count_sparse_distributed(hashes, key_bits, group=None, already_partitioned=False):
+def count_sparse_distributed(hashes, key_bits, group=None, cuts=None):
     """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range"""
     ops = get_ops()
-    mine = exchange_by_key_range(hashes, key_bits, group, already_partitioned)
-    return ops.count_sparse(mine, key_bits=key_bits, consume=True)
+    mine, key_range = exchange_by_key_range(hashes, key_bits, group, cuts)
+    return ops.count_sparse(mine, key_bits=key_bits, consume=True, key_range=key_range)

@@ -8,7 +8,7 @@ docs_source/topics/kmers.rst:42-62):
 but on one batch sized for 288 GB of HBM (tens of millions of reads) instead of 5 MB chunks, and with
 every intermediate released as soon as the next stage has consumed it.  For the sparse histogram the
 k-mer hashes are never materialised in read order: ``bnpk_kmers_partition`` generates them straight
-into the first radix pass of the sort.  bench.py times exactly this function; __graft_entry__.smoke()
+into the first level of the MSD radix partition.  bench.py times exactly this function; __graft_entry__.smoke()
 and the tests check it against the oracle.
 """
 from collections import namedtuple
@@ -51,15 +51,16 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
             hist = parallel.allreduce_dense(hist, group)
         return hist, stats
     if distributed:                                                                                   # A9 sparse, N GPUs
-        # generate the hashes already partitioned by their top 8 bits == by owning rank
-        part = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, key_bits - parallel.FINE_BITS)
+        # generate the hashes already partitioned by their top 8 bits == grouped by owning rank
+        part, cuts = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, parallel.FINE_BITS)
         del packed, offsets, out_offsets
-        return parallel.count_sparse_distributed(part, key_bits, group, already_partitioned=True), stats
+        return parallel.count_sparse_distributed(part, key_bits, group, cuts=cuts), stats
     if fused:                                                                                         # A8 + A9 sparse
-        part_bits = ops.sparse_part_bits(n_kmers, key_bits)
-        hashes = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, key_bits - part_bits)
-        del packed, offsets, out_offsets
-        return ops.count_sparse(hashes, key_bits=key_bits, consume=True, first_digit_done=True), stats
+        levels = ops.radix_plan(n_kmers, key_bits)
+        if levels:
+            hashes, cuts = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, levels[0])
+            del packed, offsets, out_offsets
+            return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0])), stats
     hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
     del packed, offsets, out_offsets
     return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats

@@ -149,12 +149,13 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
                int64_t* d_hashes, void* stream);
 
 /* Same hashes, but never materialised in row order: written exactly once, already partitioned (not
- * stably) by the 8-bit digit at bit `digit_shift` — the first pass of the histogram's radix sort
- * fused into the generation (bionumpy/sequence/kmers.py:121-126 + the np.unique of SURVEY §3.5).
- * The multiset of values equals bnpk_kmers'; only the order differs. */
+ * stably) by the `bits`-bit digit at bit `shift` (bits <= bnpk_radix_max_bits()) — level 1 of the MSD radix
+ * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the
+ * np.unique of SURVEY §3.5).  The multiset of values equals bnpk_kmers'; d_child_offsets (2^bits + 1 entries,
+ * optional) receives the bucket boundaries. */
 int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
-                         const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
-                         int digit_shift, int64_t* d_out, void* stream);
+                         const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k, int shift, int bits,
+                         int64_t* d_out, int64_t* d_child_offsets, void* stream);
 
 /* ---- A11: minimizers -----------------------------------------------------------------------------
  * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every
@@ -185,23 +186,28 @@ int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, in
                    int end_bit, int* h_in_alt, void* stream);
 int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t* d_vals,
                     int64_t* d_vals_alt, int64_t n, int key_bits, int* h_in_alt, void* stream);
-/* Fast path of steps 2+3: the keys only need to be sorted on their TOP part_bits bits
- * (bnpk_sort_keys with begin_bit = key_bits - part_bits; part_bits ~ log2(n) keeps the buckets of equal
- * top bits tiny).  One kernel ranks the distinct keys inside every bucket, run-length-counts them and
- * compacts (key, count) into globally sorted order with a decoupled look-back over 2048-key tiles.
- * Synchronous: returns the number of distinct keys; *h_overflow = 1 means some bucket held more than
- * 1024 keys (heavy-hitter k-mers) and the outputs must be discarded in favour of the full sort + run
- * kernels below.  d_state needs bnpk_finish_state_words(n) int64; d_keys_out / d_counts_out need n
- * entries and must not alias the input. */
-int64_t bnpk_finish_state_words(int64_t n);
-/* Tier 1 of the same operation for buckets of at most ~32 keys: wave-synchronous (registers + lane
- * shuffles, no LDS window, no workgroup barrier), same contract; on overflow try bnpk_finish_buckets. */
-int bnpk_finish_small(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits,
-                      int part_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
-                      int64_t* h_n_unique, int* h_overflow, void* stream);
-int bnpk_finish_buckets(bnpk_ctx* ctx, const int64_t* d_part_sorted, int64_t n, int key_bits,
-                        int part_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
-                        int64_t* h_n_unique, int* h_overflow, void* stream);
+/* Hand-written path of the same operation (the one the pipeline uses; the rocPRIM sort + run kernels are the
+ * fallback for inputs with heavy-hitter buckets):
+ *   bnpk_radix_partition  one MSD level: the keys of every segment [d_seg_offsets[p], d_seg_offsets[p+1]) are
+ *                         partitioned (not stably) by the `bits`-bit digit at bit `shift` with an LDS
+ *                         write-combining scatter (whole 128-byte lines only); d_child_offsets gets the
+ *                         n_seg * 2^bits + 1 boundaries of the child buckets, which are the segments of the next
+ *                         level.  d_seg_offsets may be NULL when n_seg == 1.  d_out must not alias d_keys.
+ *                         Keys must be < 2^63; n < 2^36.
+ *   bnpk_finish_sorted    every bucket [d_bucket_offsets[b], d_bucket_offsets[b+1]) (keys equal above bit
+ *                         `low_bits`, at most bnpk_finish_capacity() of them, any order) is sorted in LDS,
+ *                         run-length-counted and written as sorted distinct keys + multiplicities.  Synchronous:
+ *                         returns the number of distinct keys; *h_overflow = 1 means a bucket exceeded the
+ *                         capacity and the outputs must be discarded (fall back to bnpk_sort_keys + run kernels).
+ *                         d_state needs bnpk_finish_state_words(n_buckets) int64. */
+int64_t bnpk_radix_max_bits(void);
+int64_t bnpk_finish_capacity(void);
+int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
+                         int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
+int64_t bnpk_finish_state_words(int64_t n_buckets);
+int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
+                       int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                       int64_t* h_n_unique, int* h_overflow, void* stream);
 /* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */
 int64_t bnpk_run_tiles(int64_t n);
 int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,

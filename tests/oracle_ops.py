@@ -47,12 +47,16 @@ class OracleOps:
         return _h(v[order]), cuts.astype(np.int64)
 
     @staticmethod
-    def sparse_part_bits(n, key_bits):
-        return min(key_bits, max(8, -(-(max(n - 1, 1).bit_length() - 1) // 8) * 8))
+    def radix_plan(n, key_bits, done=0):
+        from bionumpy_amd.ops import HipOps
+        return HipOps.radix_plan(n, key_bits, done)
 
-    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, digit_shift):
+    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, bits):
         h = self.kmers(packed, in_offsets, out_offsets, n_rows, n_out, k).host()
-        return _h(h[np.argsort((h >> digit_shift) & 255, kind="stable")])
+        digit = h >> (2 * k - bits)
+        order = np.argsort(digit, kind="stable")
+        cuts = np.searchsorted(digit[order], np.arange((1 << bits) + 1)).astype(np.int64)
+        return _h(h[order]), _h(cuts)
 
     # -- decode -----------------------------------------------------------------------------------
     def newline_positions(self, buf, n, limit_multiple=1):
@@ -151,7 +155,7 @@ class OracleOps:
         return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins) for r in range(n_rows)],
                            dtype=np.int64).reshape(-1))
 
-    def count_sparse(self, values, key_bits=62, consume=False, fast=True, first_digit_done=False):
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True):
         k, c = oracle.count_sparse(values.host())
         return _h(k), _h(c)
 

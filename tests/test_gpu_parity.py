@@ -155,7 +155,7 @@ def test_full_path_properties_at_scale(ops):
 @pytest.mark.parametrize("n,spread", [(1, 10), (2047, 50), (2048, 1000), (2049, 3), (100_000, 70_000),
                                       (3_000_000, 400_000), (3_000_000, 1 << 40)])
 def test_fast_and_fallback_sparse_paths_agree(ops, n, spread):
-    """fused finishing kernel (top-bits sort + bucket ranking + look-back) vs full sort + run kernels vs numpy"""
+    """radix partition + LDS finishing kernel vs full sort + run kernels vs numpy"""
     rng = np.random.default_rng(n + spread)
     v = (rng.integers(0, spread, size=n).astype(np.int64) * np.int64(0x1E3779B97F4A7C15)) & ((1 << 62) - 1)
     ek, ec = oracle.count_sparse(v)
@@ -165,11 +165,11 @@ def test_fast_and_fallback_sparse_paths_agree(ops, n, spread):
 
 
 def test_heavy_hitters_take_the_fallback(ops):
-    """buckets larger than the fast path's cap (a k-mer repeated 5000 times, a run of near-identical keys)
+    """buckets larger than the finishing kernel's capacity (a k-mer repeated 20000 times, a run of near-identical keys)
     must still give np.unique's answer"""
     rng = np.random.default_rng(9)
     base = rng.integers(0, 1 << 62, size=50_000).astype(np.int64)
-    hot = np.full(5000, base[17], dtype=np.int64)
+    hot = np.full(20_000, base[17], dtype=np.int64)
     near = (base[99] & ~np.int64(0xFFFF)) + rng.integers(0, 1 << 16, size=3000)        # share the top 46 bits
     v = rng.permutation(np.concatenate([base, hot, near])).astype(np.int64)
     keys, counts = ops.count_sparse(_h(v), key_bits=62)
@@ -185,23 +185,72 @@ def test_heavy_hitters_take_the_fallback(ops):
 @pytest.mark.parametrize("seed,n_rows,max_len,k", [(5, 1, 40, 5), (6, 3000, 200, 31), (7, 40_000, 300, 31),
                                                    (8, 17, 100_000, 21), (9, 5000, 60, 13)])
 def test_fused_kmer_partition(ops, seed, n_rows, max_len, k):
-    """bnpk_kmers_partition == bnpk_kmers as a multiset, grouped by the requested 8-bit digit"""
+    """bnpk_kmers_partition == bnpk_kmers as a multiset, grouped by the requested top bits, with exact
+    bucket boundaries"""
     text, starts, lengths = _random_reads(seed, n_rows, max_len)
     offsets, total = ops.row_offsets(_h(lengths), 1)
     _, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total)
     out_off, n_out = ops.row_offsets(_h(lengths), k)
     plain = ops.kmers(packed, offsets, out_off, n_rows, n_out, k).host()
-    for shift in (0, max(0, 2 * k - 8), max(0, 2 * k - 24)):
-        part = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, shift).host()
-        digits = (part >> shift) & 255
+    for bits in (0, 1, 5, 8, 10):
+        if bits > 2 * k:
+            continue
+        part, cuts = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, bits)
+        part, cuts = part.host(), cuts.host()
+        digits = part >> (2 * k - bits)
         assert np.all(np.diff(digits) >= 0)
+        assert np.array_equal(cuts, np.searchsorted(digits, np.arange((1 << bits) + 1)))
         assert np.array_equal(np.sort(part), np.sort(plain))
-    from bionumpy_amd.pipeline import fastq_kmer_histogram
-    # whole pipeline, fused vs unfused vs oracle
+    # whole sparse path, fused first level vs oracle
     if n_rows >= 3000 and k == 31:
         codes = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
         ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lengths, k)[0])
-        part_bits = ops.sparse_part_bits(n_out, 2 * k)
-        hashes = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, 2 * k - part_bits)
-        keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True, first_digit_done=True)
-        assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+        for bits in (3, 10):
+            hashes, cuts = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, bits)
+            keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True, partition=(cuts, bits))
+            assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+
+
+@pytest.mark.parametrize("seed,n,key_bits,levels", [(1, 1, 62, [3]), (2, 1000, 62, [4, 4]), (3, 300_000, 62, [10, 10]),
+                                                    (4, 2_000_000, 40, [7, 6]), (5, 100_000, 12, [10]),
+                                                    (6, 50_000, 62, [0, 2]), (7, 700_000, 62, [10, 10, 10])])
+def test_radix_partition_levels(ops, seed, n, key_bits, levels):
+    """MSD levels of bnpk_radix_partition: multiset preserved, keys grouped by the resolved top bits, child offsets
+    exact (including empty buckets and skewed digits)"""
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, 1 << key_bits, size=n, dtype=np.int64)
+    if n > 1000:                                   # skew: a heavy hitter and a dense cluster
+        keys[rng.integers(0, n, size=n // 10)] = keys[0]
+        keys[rng.integers(0, n, size=n // 10)] = keys[1] ^ rng.integers(0, 1 << min(key_bits, 20), size=n // 10)
+    cur = _h(keys).dev()
+    offsets, done, n_seg = None, 0, 1
+    for bits in levels:
+        cur, offsets = ops.radix_partition(cur, offsets, n_seg, key_bits - done - bits, bits)
+        done += bits
+        n_seg <<= bits
+        got = cur.cpu().numpy()
+        top = got >> (key_bits - done)
+        assert np.all(np.diff(top) >= 0)
+        assert np.array_equal(offsets.cpu().numpy(), np.searchsorted(top, np.arange(n_seg + 1)))
+    assert np.array_equal(np.sort(got), np.sort(keys))
+
+
+@pytest.mark.parametrize("seed,n,key_bits,dup", [(1, 1, 62, 1), (2, 5000, 62, 1), (3, 8192, 62, 3), (4, 400_000, 62, 1),
+                                                 (5, 400_000, 62, 50), (6, 3_000_000, 62, 2), (7, 200_000, 30, 7),
+                                                 (8, 100_000, 8, 1), (9, 1_000_000, 20, 1)])
+def test_count_sparse_radix_path(ops, seed, n, key_bits, dup):
+    """np.unique(return_counts=True) through partition levels + finish_sorted (and the fallback when a bucket of
+    equal top bits exceeds the LDS capacity)"""
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, 1 << key_bits, size=max(1, n // dup), dtype=np.int64)
+    keys = keys[rng.integers(0, keys.size, size=n)]
+    ek, ec = oracle.count_sparse(keys)
+    gk, gc = ops.count_sparse(_h(keys), key_bits=key_bits)
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+    # a key range hint (the multi-GPU exchange hands every rank one slice of the key space)
+    lo, hi = (3 << (key_bits - 2)) if key_bits >= 2 else 0, 1 << key_bits
+    sub = keys[keys >= lo]
+    if sub.size:
+        ek, ec = oracle.count_sparse(sub)
+        gk, gc = ops.count_sparse(_h(sub), key_bits=key_bits, key_range=(lo, hi))
+        assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
