@@ -115,6 +115,22 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* smem, T* total) {
   return base + inc - v;
 }
 
+// 32-bit inclusive scan in six DPP moves (row_shr 1,2,4,8 inside the rows of 16 lanes, then row_bcast:15 / :31
+// across rows) instead of six LDS-latency ds_bpermute round trips.  All 64 lanes must be active.
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v) { return (int)wave_inclusive_scan((unsigned)v); }
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {          // total of the 64 lanes, in every lane
+  return (unsigned)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
 #pragma unroll

@@ -11,6 +11,8 @@
 // in read order) before the buckets (~6 K keys) fit the finishing kernel, which sorts them in LDS (12-bit
 // counting sort + exact ranking inside the ~1.4-key bins), run-length-counts the duplicates and writes
 // (key, count) at the final sorted position.  MSD ranks need no stability, so they come from plain LDS atomics.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <type_traits>
 
@@ -22,21 +24,35 @@
 namespace {
 
 constexpr int RP_THREADS = 1024;
-constexpr int RP_MAXB = 1024;                         // buckets per level
-constexpr int RP_STAGE = 16384;                       // keys staged in LDS (128 KiB)
+constexpr int RP_MAXBITS = 11;
 constexpr int RP_TILE = 8192;                         // new keys per round (at most)
 constexpr int RP_MAXITEMS = RP_TILE / RP_THREADS;     // 8
 constexpr int RP_GRAN = 1024;                         // granularity of the tile -> row table of the fused source
 constexpr uint64_t RP_PHANTOM = 1ull << 63;           // placeholder for the slots before a bucket's first key
+constexpr int RP_CACHE_ROWS = 256;                    // rows of a tile whose offsets the fused source caches in LDS
+constexpr size_t RP_CACHE_BYTES = (size_t)RP_CACHE_ROWS * 2 * 8;
 
-// LDS carve-up of the partition kernels (dynamic, 16-byte aligned pieces)
-constexpr size_t RP_OFF_META = (size_t)RP_STAGE * 8;
-constexpr size_t RP_OFF_CNT = RP_OFF_META + (size_t)RP_MAXB * 8;
-constexpr size_t RP_OFF_LINE = RP_OFF_CNT + (size_t)RP_MAXB * 4;
-constexpr size_t RP_OFF_WSUM = RP_OFF_LINE + (size_t)RP_MAXB * 4;
-constexpr size_t RP_OFF_SLAB = RP_OFF_WSUM + 32 * 4;
-constexpr size_t RP_LDS = RP_OFF_SLAB + 8 * 8;
-constexpr size_t RP_HIST_LDS = (size_t)RP_MAXB * 4 + 8 * 8;
+// Two shapes of the scatter kernel: digits up to 10 bits flush whole 128-byte lines (16 keys); 11-bit digits
+// (2048 buckets) flush 64-byte half lines, because the carried keys (< LINE per bucket) have to fit LDS.
+template <int LINE_>
+struct rp_cfg {
+  static constexpr int LINE = LINE_;
+  static constexpr int LOG_LINE = LINE_ == 16 ? 4 : 3;
+  static constexpr int MAXB = LINE_ == 16 ? 1024 : 2048;
+  static constexpr int NBT = MAXB / RP_THREADS;              // buckets owned by one lane
+  static constexpr int CARRY = LINE_ - 1;                    // most keys a bucket carries into the next round
+  static constexpr int STAGE = LINE_ == 16 ? 16384 : 15360;  // keys staged in LDS
+  // LDS carve-up (dynamic, 16-byte aligned pieces)
+  static constexpr size_t OFF_META = (size_t)STAGE * 8;
+  static constexpr size_t OFF_CNT = OFF_META + (size_t)MAXB * 8;
+  static constexpr size_t OFF_LINE = OFF_CNT + (size_t)MAXB * 4;
+  static constexpr size_t OFF_WSUM = OFF_LINE + (size_t)MAXB * 4;
+  static constexpr size_t OFF_SLAB = OFF_WSUM + 32 * 4;
+  static constexpr size_t OFF_CACHE = OFF_SLAB + 8 * 8;
+  static constexpr size_t LDS = OFF_CACHE + RP_CACHE_BYTES;
+};
+constexpr int RP_HIST_BINS = 1 << RP_MAXBITS;
+constexpr size_t RP_HIST_LDS = (size_t)RP_HIST_BINS * 4 + 8 * 8 + RP_CACHE_BYTES;
 
 struct slab_t {
   int64_t lo, hi;        // key range of the slab (inside one parent segment)
@@ -77,9 +93,10 @@ __device__ __forceinline__ bool find_slab(const int64_t* __restrict__ seg_off, c
 
 // ---- key sources ---------------------------------------------------------------------------------------------
 // load(): up to `items` keys of the tile [t0, t0 + items*RP_THREADS) ∩ [.., hi) for this lane; returns how many.
+// Called by every lane of the workgroup (it may synchronise); `cache` is RP_CACHE_BYTES of LDS scratch.
 struct mem_source {
   const uint64_t* __restrict__ keys;
-  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS]) const {
+  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS], int64_t*) const {
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
@@ -91,7 +108,8 @@ struct mem_source {
 };
 
 // the k-mer hashes of the ragged read set, generated on the fly from the packed 2-bit reads (A8); key index ==
-// flat output index of bnpk_kmers
+// flat output index of bnpk_kmers.  Every lane produces `items` consecutive k-mers; the row offsets the tile
+// touches are first copied to LDS (one coalesced load instead of a chain of dependent binary-search loads).
 struct kmer_source {
   const uint64_t* __restrict__ W;
   const int64_t* __restrict__ in_off;
@@ -99,23 +117,41 @@ struct kmer_source {
   const int64_t* __restrict__ tile_rows;   // row containing output t*RP_GRAN
   int64_t n_rows, n_tiles;
   uint64_t mask;
-  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS]) const {
-    const int64_t o = t0 + (int64_t)threadIdx.x * items;
-    if (o >= hi) return 0;
-    const int64_t t_first = t0 / RP_GRAN, t_last = (min(t0 + (int64_t)items * RP_THREADS, hi) - 1) / RP_GRAN;
-    const int64_t rlo = tile_rows[t_first];
-    const int64_t rhi = (t_last + 1 < n_tiles) ? tile_rows[t_last + 1] : n_rows - 1;
-    row_cursor c = seek_row(in_off, out_off, rlo, rhi, o);
+
+  __device__ __forceinline__ int gen(const int64_t* __restrict__ ioff, const int64_t* __restrict__ ooff, int64_t rlo,
+                                     int64_t rhi, int64_t o, int64_t end, int items, uint64_t k[RP_MAXITEMS]) const {
+    row_cursor c = seek_row(ioff, ooff, rlo, rhi, o);
     word_window ww;
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
       const int64_t oo = o + q;
-      if (q >= items || oo >= hi) break;
-      if (q) next_output(c, in_off, out_off, oo);
+      if (q >= items || oo >= end) break;
+      if (q) next_output(c, ioff, ooff, oo);
       k[q] = bits_at(W, c.in_pos, ww) & mask;
       ++cnt;
     }
+    return cnt;
+  }
+
+  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS], int64_t* cache) const {
+    const int64_t end = min(t0 + (int64_t)items * RP_THREADS, hi);              // uniform
+    if (t0 >= end) return 0;
+    const int64_t t_first = t0 / RP_GRAN, t_last = (end - 1) / RP_GRAN;
+    const int64_t rlo = tile_rows[t_first];
+    const int64_t rhi = (t_last + 1 < n_tiles) ? tile_rows[t_last + 1] : n_rows - 1;
+    const int64_t span = rhi - rlo + 1;                                         // rows the tile can touch
+    const int64_t o = t0 + (int64_t)threadIdx.x * items;
+    if (span + 1 > RP_CACHE_ROWS) return o < end ? gen(in_off, out_off, rlo, rhi, o, end, items, k) : 0;
+    int64_t* c_out = cache;
+    int64_t* c_in = cache + RP_CACHE_ROWS;
+    for (int64_t i = threadIdx.x; i <= span; i += RP_THREADS) {
+      c_out[i] = out_off[rlo + i];
+      if (i < span) c_in[i] = in_off[rlo + i];
+    }
+    __syncthreads();
+    const int cnt = o < end ? gen(c_in, c_out, 0, span - 1, o, end, items, k) : 0;
+    __syncthreads();                                                            // the cache is reused by the next tile
     return cnt;
   }
 };
@@ -128,86 +164,93 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
                                                              int64_t* __restrict__ H) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* h = reinterpret_cast<unsigned*>(smem);
-  int64_t* sh = reinterpret_cast<int64_t*>(smem + (size_t)RP_MAXB * 4);
+  int64_t* sh = reinterpret_cast<int64_t*>(smem + (size_t)RP_HIST_BINS * 4);
+  int64_t* cache = sh + 8;
   const int B = 1 << bits;
   slab_t sl;
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
-  if (threadIdx.x < B) h[threadIdx.x] = 0;
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) h[c] = 0;
   __syncthreads();
   for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += RP_TILE) {
     uint64_t k[RP_MAXITEMS];
-    const int cnt = src.load(t0, sl.hi, RP_MAXITEMS, k);
+    const int cnt = src.load(t0, sl.hi, RP_MAXITEMS, k, cache);
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q)
       if (q < cnt) atomicAdd(&h[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
   }
   __syncthreads();
-  if (threadIdx.x < B) H[sl.hbase + (int64_t)threadIdx.x * sl.nsl + sl.local] = h[threadIdx.x];
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) H[sl.hbase + (int64_t)c * sl.nsl + sl.local] = h[c];
 }
 
 // ---- pass 2 of a level: write-combining scatter ------------------------------------------------------------------
 // One round = one tile of new keys merged with the keys carried over from the previous round:
 //   rank   every new key takes a rank inside its bucket from an LDS counter (done right after the tile is loaded,
 //          i.e. at the end of the previous round, so the loads / the k-mer generation overlap the store drain)
-//   layout per bucket: nfl = keys that complete whole 128-byte lines, the rest is carried; one packed scan gives
-//          every bucket a slice of the FLUSH region (a multiple of 16 keys, 128-byte aligned in LDS) and a slice of
-//          the CARRY region behind it
+//   layout per bucket: nfl = keys that complete whole lines, the rest is carried; one packed scan gives every
+//          bucket a slice of the FLUSH region (a multiple of LINE keys, line-aligned in LDS) and a slice of the
+//          CARRY region behind it
 //   stage  carried + new keys are written to their slices
 //   flush  the FLUSH region leaves the CU as aligned 16-byte-per-lane stores (whole lines only); the CARRY region is
 //          read back into the owning lanes' registers
-__device__ __forceinline__ unsigned rp_tile_size(unsigned carried) {
-  return min((unsigned)RP_TILE, (RP_STAGE - carried) & ~(unsigned)(RP_THREADS - 1));     // >= RP_THREADS
-}
-
-template <typename Source>
+template <typename Source, int LINE>
 __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, const int64_t* __restrict__ seg_off,
                                                                 const int64_t* __restrict__ seg_slabs, int64_t n_seg,
                                                                 int64_t slab_keys, int shift, int bits,
                                                                 const int64_t* __restrict__ offs,
                                                                 uint64_t* __restrict__ out) {
+  using C = rp_cfg<LINE>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
-  uint64_t* meta = reinterpret_cast<uint64_t*>(smem + RP_OFF_META);   // {flush start:16 | nfl:16 | carry start:16 | rem:16}
-  unsigned* newcnt = reinterpret_cast<unsigned*>(smem + RP_OFF_CNT);
-  unsigned* line = reinterpret_cast<unsigned*>(smem + RP_OFF_LINE);   // write cursor of the bucket / 16
-  unsigned* wsum = reinterpret_cast<unsigned*>(smem + RP_OFF_WSUM);
-  int64_t* sh = reinterpret_cast<int64_t*>(smem + RP_OFF_SLAB);
+  uint64_t* meta = reinterpret_cast<uint64_t*>(smem + C::OFF_META);   // {flush start:16 | nfl:16 | carry start:16 | rem:16}
+  unsigned* newcnt = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);
+  unsigned* line = reinterpret_cast<unsigned*>(smem + C::OFF_LINE);   // write cursor of the bucket / LINE
+  unsigned* wsum = reinterpret_cast<unsigned*>(smem + C::OFF_WSUM);
+  int64_t* sh = reinterpret_cast<int64_t*>(smem + C::OFF_SLAB);
+  int64_t* cache = reinterpret_cast<int64_t*>(smem + C::OFF_CACHE);
   const int B = 1 << bits;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   slab_t sl;
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   if (sl.lo >= sl.hi) return;
+  auto tile_size = [](unsigned carried) {
+    return min((unsigned)RP_TILE, ((unsigned)C::STAGE - carried) & ~(unsigned)(RP_THREADS - 1));   // >= RP_THREADS
+  };
 
-  // lane t owns bucket t: its write cursor (kept 16-key aligned; the slots between the aligned cursor and the
-  // bucket's true first position are phantom keys that are staged like real ones but never stored), the
-  // number of carried keys and those keys themselves.
-  int64_t cursor = 0;
-  unsigned rem = 0;
-  uint64_t left[15];
-  if (tid < B) {
-    const int64_t c0 = offs[sl.hbase + (int64_t)tid * sl.nsl + sl.local];
-    cursor = c0 & ~15ll;
-    rem = (unsigned)(c0 & 15);
-    newcnt[tid] = 0;
-  }
-  const uint64_t phantom = RP_PHANTOM | ((uint64_t)tid << shift);
-#pragma unroll
-  for (int j = 0; j < 15; ++j) left[j] = phantom;
-  {
-    unsigned s = wave_reduce_sum(rem);
-    if (lane == 0) wsum[wave] = s;
-  }
-  __syncthreads();
+  // A lane owns buckets tid, tid + 1024, ..: their write cursors (kept LINE-aligned; the slots between the aligned
+  // cursor and the bucket's true first position are phantom keys that are staged like real ones but never
+  // stored), the number of carried keys and those keys themselves.
+  int64_t cursor[C::NBT];
+  unsigned rem[C::NBT];
+  uint64_t left[C::NBT][C::CARRY];
   unsigned carried = 0;
+#pragma unroll
+  for (int b = 0; b < C::NBT; ++b) {
+    const int d = tid + b * RP_THREADS;
+    cursor[b] = 0;
+    rem[b] = 0;
+    if (d < B) {
+      const int64_t c0 = offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
+      cursor[b] = c0 & ~(int64_t)(LINE - 1);
+      rem[b] = (unsigned)(c0 & (LINE - 1));
+      newcnt[d] = 0;
+    }
+    carried += rem[b];
+#pragma unroll
+    for (int j = 0; j < C::CARRY; ++j) left[b][j] = RP_PHANTOM | ((uint64_t)d << shift);
+  }
+  carried = wave_sum(carried);
+  if (lane == 0) wsum[wave] = carried;
+  __syncthreads();
+  carried = 0;
 #pragma unroll
   for (int w = 0; w < RP_THREADS / 64; ++w) carried += wsum[w];
   __syncthreads();
 
   int64_t t0 = sl.lo;
-  unsigned T = rp_tile_size(carried);
+  unsigned T = tile_size(carried);
   uint64_t k[RP_MAXITEMS];
   unsigned r[RP_MAXITEMS];
-  int cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k);
+  int cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k, cache);
 #pragma unroll
   for (int q = 0; q < RP_MAXITEMS; ++q)
     if (q < cnt) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
@@ -216,11 +259,16 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   while (true) {
     const bool last = t0 + T >= sl.hi;
     // layout of the round
-    unsigned tot = 0;
-    if (tid < B) { tot = rem + newcnt[tid]; newcnt[tid] = 0; }
-    const unsigned nfl = last ? tot : (tot & ~15u);          // whole lines only, except in the slab's last round
-    const unsigned nrem = tot - nfl;
-    const unsigned packed = nfl | (nrem << 16);
+    unsigned nfl[C::NBT], nrem[C::NBT], packed = 0;
+#pragma unroll
+    for (int b = 0; b < C::NBT; ++b) {
+      const int d = tid + b * RP_THREADS;
+      unsigned tot = 0;
+      if (d < B) { tot = rem[b] + newcnt[d]; newcnt[d] = 0; }
+      nfl[b] = last ? tot : (tot & ~(unsigned)(LINE - 1));     // whole lines only, except in the slab's last round
+      nrem[b] = tot - nfl[b];
+      packed += nfl[b] | (nrem[b] << 16);
+    }
     const unsigned inc = wave_inclusive_scan(packed);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
@@ -231,16 +279,23 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       if (w < wave) wbase += x;
       total += x;
     }
-    const unsigned ex = wbase + inc - packed;
+    unsigned ex = wbase + inc - packed;
     const unsigned total_f = total & 0xffffu;
-    const unsigned fpos = ex & 0xffffu, cpos = total_f + (ex >> 16);
-    if (tid < B) {
-      meta[tid] = (uint64_t)fpos | ((uint64_t)nfl << 16) | ((uint64_t)cpos << 32) | ((uint64_t)rem << 48);
-      line[tid] = (unsigned)(cursor >> 4);
-      const unsigned base = nfl ? fpos : cpos;               // carried keys precede the new ones (rem < 16 <= nfl)
+    unsigned cpos[C::NBT];
 #pragma unroll
-      for (int j = 0; j < 15; ++j)
-        if (j < (int)rem) stage[base + j] = left[j];
+    for (int b = 0; b < C::NBT; ++b) {
+      const int d = tid + b * RP_THREADS;
+      const unsigned fpos = ex & 0xffffu;
+      cpos[b] = total_f + (ex >> 16);
+      ex += nfl[b] | (nrem[b] << 16);
+      if (d < B) {
+        meta[d] = (uint64_t)fpos | ((uint64_t)nfl[b] << 16) | ((uint64_t)cpos[b] << 32) | ((uint64_t)rem[b] << 48);
+        line[d] = (unsigned)(cursor[b] >> C::LOG_LINE);
+        const unsigned base = nfl[b] ? fpos : cpos[b];         // carried keys precede the new ones (rem < LINE <= nfl)
+#pragma unroll
+        for (int j = 0; j < C::CARRY; ++j)
+          if (j < (int)rem[b]) stage[base + j] = left[b][j];
+      }
     }
     __syncthreads();
     // stage the new keys behind the carried ones
@@ -253,13 +308,13 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       }
     }
     __syncthreads();
-    // flush: whole 128-byte lines, 16 bytes per lane
+    // flush: whole lines, 16 bytes per lane
     if (!last) {
       for (unsigned i = 2 * tid; i < total_f; i += 2 * RP_THREADS) {
         const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(stage + i);
         const unsigned d = (unsigned)(kk.x >> shift) & (B - 1);
         const unsigned f = (unsigned)meta[d] & 0xffffu;
-        uint64_t* dst = out + (((int64_t)line[d] << 4) + (i - f));
+        uint64_t* dst = out + (((int64_t)line[d] << C::LOG_LINE) + (i - f));
         if (!((kk.x | kk.y) >> 63)) {
           *reinterpret_cast<ulonglong2*>(dst) = kk;
         } else {                                             // phantom slots before the bucket's first key
@@ -271,21 +326,24 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       for (unsigned i = tid; i < total_f; i += RP_THREADS) {
         const uint64_t key = stage[i];
         const unsigned d = (unsigned)(key >> shift) & (B - 1);
-        if (!(key >> 63)) out[((int64_t)line[d] << 4) + (i - ((unsigned)meta[d] & 0xffffu))] = key;
+        if (!(key >> 63)) out[((int64_t)line[d] << C::LOG_LINE) + (i - ((unsigned)meta[d] & 0xffffu))] = key;
       }
       break;
     }
-    if (tid < B) {
 #pragma unroll
-      for (int j = 0; j < 15; ++j)
-        if (j < (int)nrem) left[j] = stage[cpos + j];
-      cursor += nfl;
-      rem = nrem;
+    for (int b = 0; b < C::NBT; ++b) {
+      if (tid + b * RP_THREADS < B) {
+#pragma unroll
+        for (int j = 0; j < C::CARRY; ++j)
+          if (j < (int)nrem[b]) left[b][j] = stage[cpos[b] + j];
+        cursor[b] += nfl[b];
+        rem[b] = nrem[b];
+      }
     }
     // next tile: load / generate and rank now, so that its latency overlaps the drain of the stores above
     t0 += T;
-    T = rp_tile_size(total >> 16);
-    cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k);
+    T = tile_size(total >> 16);
+    cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k, cache);
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q)
       if (q < cnt) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
@@ -366,8 +424,10 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   static bool attr_set[2] = {false, false};
   constexpr int which = std::is_same<Source, mem_source>::value ? 0 : 1;
   if (!attr_set[which]) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)RP_LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 16>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<16>::LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 8>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<8>::LDS));
     attr_set[which] = true;
   }
   if (!d_seg_off) {
@@ -387,9 +447,14 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
                          (const int64_t*)H, (const int64_t*)seg_slabs, n_seg, B, n, d_child_off);
   }
   bnpk_timer t(ctx, scatter_name, s);
-  hipLaunchKernelGGL((rp_scatter_kernel<Source>), dim3((unsigned)bound), dim3(RP_THREADS), RP_LDS, s, src, d_seg_off,
-                     (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, (const int64_t*)H,
-                     reinterpret_cast<uint64_t*>(d_out));
+  if (bits <= 10)
+    hipLaunchKernelGGL((rp_scatter_kernel<Source, 16>), dim3((unsigned)bound), dim3(RP_THREADS), rp_cfg<16>::LDS, s, src,
+                       d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, (const int64_t*)H,
+                       reinterpret_cast<uint64_t*>(d_out));
+  else
+    hipLaunchKernelGGL((rp_scatter_kernel<Source, 8>), dim3((unsigned)bound), dim3(RP_THREADS), rp_cfg<8>::LDS, s, src,
+                       d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, (const int64_t*)H,
+                       reinterpret_cast<uint64_t*>(d_out));
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
@@ -397,66 +462,173 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
 // ===================================================================================================================
 // Finishing kernel: every bucket of the partitioned keys (equal top bits, <= FN_CAP keys, arbitrary order inside)
 // is sorted in LDS, its duplicates are counted and the distinct (key, count) pairs are written in sorted order.
-// Two launches of the same kernel: COUNT stores the number of distinct keys per bucket, a device scan turns that
-// into output offsets, WRITE repeats the LDS sort and stores at the final positions (no inter-workgroup waiting).
+// Single pass: buckets are handed out in ticket order; the output offset of a bucket (= number of distinct keys
+// in all earlier buckets) comes from a decoupled look-back over one 64-bit {flag, value} word per bucket, walked
+// by wavefront 0 (128 predecessors per round) while the other wavefronts rank the bucket's keys, so its latency
+// is hidden.  The next bucket's keys are loaded while the current one is processed.
 constexpr int FN_THREADS = 1024;
 constexpr int FN_CAP = 8192;
 constexpr int FN_ITEMS = FN_CAP / FN_THREADS;
 constexpr int FN_MAXBITS = 12;
 constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
-constexpr int FN_WORDS = FN_CAP / 64;
+constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask words
+constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
 constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
-constexpr int FS_OVERFLOW = 0;                       // d_state words: [0] overflow flag, [8 ..] per-bucket counts -> offsets
+constexpr int FN_LB = 2;                             // look-back: status words read per lane and round (window 128)
+static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
+// d_state words: [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
+// [2] number of distinct keys, [8 + b] status word of bucket b
+constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_BUCKETS = 8;
+constexpr unsigned long long FN_AGG = 1ull << 62, FN_INC = 2ull << 62, FN_VALUE = (1ull << 62) - 1;
+constexpr unsigned FN_SPIN_LIMIT = 1u << 24;
 
 constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;
 constexpr size_t FN_OFF_CNT = FN_OFF_BINS + (size_t)(FN_MAXBINS + 4) * 4;
 constexpr size_t FN_OFF_MASK = FN_OFF_CNT + (size_t)FN_CAP * 2;
-constexpr size_t FN_OFF_PREFIX = FN_OFF_MASK + (size_t)FN_WORDS * 8;
-constexpr size_t FN_OFF_WSUM = FN_OFF_PREFIX + (size_t)(FN_WORDS + 4) * 4;
-constexpr size_t FN_LDS = FN_OFF_WSUM + 32 * 4;
+constexpr size_t FN_OFF_WSUM = FN_OFF_MASK + (size_t)FN_WORDS * 8;
+constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
+constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
 
-template <bool WRITE>
+struct fn_bucket {
+  int64_t b, lo;
+  int nb;          // keys in the bucket; 0 = nothing to sort (empty, past the end, or over capacity)
+  bool over;
+};
+
+__device__ __forceinline__ fn_bucket fn_open(const int64_t* __restrict__ bucket_off, int64_t n_buckets, int64_t b) {
+  fn_bucket x;
+  x.b = b;
+  x.lo = 0;
+  x.nb = 0;
+  x.over = false;
+  if (b < n_buckets) {
+    x.lo = bucket_off[b];
+    const int64_t m = bucket_off[b + 1] - x.lo;
+    x.over = m > FN_CAP;
+    x.nb = x.over ? 0 : (int)m;
+  }
+  return x;
+}
+
 __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_t* __restrict__ A,
                                                                    const int64_t* __restrict__ bucket_off,
                                                                    int64_t n_buckets, int sshift, int sbits,
-                                                                   int64_t* __restrict__ bucket_counts,
+                                                                   unsigned long long* __restrict__ state,
                                                                    uint64_t* __restrict__ keys_out,
-                                                                   int64_t* __restrict__ counts_out,
-                                                                   unsigned long long* __restrict__ flags) {
+                                                                   int64_t* __restrict__ counts_out, int ablate) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);
   unsigned short* cnt16 = reinterpret_cast<unsigned short*>(smem + FN_OFF_CNT);
   unsigned long long* fmask = reinterpret_cast<unsigned long long*>(smem + FN_OFF_MASK);
-  unsigned* fprefix = reinterpret_cast<unsigned*>(smem + FN_OFF_PREFIX);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
+  long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned SB = 1u << sbits;
-  for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
-    const int64_t lo = bucket_off[b], hi = bucket_off[b + 1];
-    const int nb = (int)min(hi - lo, (int64_t)FN_CAP + 1);
-    if (nb <= 0 || nb > FN_CAP) {                       // uniform per workgroup
-      if (!WRITE && tid == 0) {
-        bucket_counts[b] = 0;
-        if (nb > FN_CAP) atomicOr(&flags[FS_OVERFLOW], 1ull);
+
+  unsigned* fmask32 = reinterpret_cast<unsigned*>(fmask);
+  constexpr uint64_t KEYMASK = ~(1ull << 63);
+
+  // publish the bucket's distinct count, return the number of distinct keys in all earlier buckets (wavefront 0)
+  auto look_back = [&](int64_t b, unsigned D) -> long long {
+    unsigned long long* mine = &state[FS_BUCKETS + b];
+    long long base = 0;
+    if (b > 0) {
+      if (lane == 0)
+        __hip_atomic_store(mine, FN_AGG | (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t top = b - 1;
+      unsigned spins = 0;
+      while (true) {
+        // lane l reads the words at distance l, 64 + l, ... behind `top` (distance 0 = nearest predecessor)
+        unsigned long long v[FN_LB];
+        uint64_t incm[FN_LB], badm[FN_LB];
+#pragma unroll
+        for (int m = 0; m < FN_LB; ++m) {
+          const int64_t pp = top - 64 * m - lane;
+          v[m] = (pp >= 0) ? __hip_atomic_load(&state[FS_BUCKETS + pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FN_INC;
+        }
+        int first_inc = 64 * FN_LB;                    // distance of the nearest inclusive word in the window
+#pragma unroll
+        for (int m = FN_LB - 1; m >= 0; --m) {
+          incm[m] = __ballot((v[m] & ~FN_VALUE) == FN_INC);
+          badm[m] = __ballot((v[m] & ~FN_VALUE) == 0);
+          if (incm[m]) first_inc = 64 * m + __ffsll((long long)incm[m]) - 1;
+        }
+        bool blocked = false;                          // a needed predecessor has not published yet
+#pragma unroll
+        for (int m = 0; m < FN_LB; ++m) {
+          const int rel = first_inc - 64 * m;
+          const uint64_t need = rel >= 63 ? ~0ull : (rel < 0 ? 0ull : ((2ull << rel) - 1ull));
+          blocked |= (badm[m] & need) != 0;
+        }
+        if (blocked) {
+          if (++spins > FN_SPIN_LIMIT) { if (lane == 0) atomicOr(&state[FS_FLAGS], 2ull); break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        long long contrib = 0;
+#pragma unroll
+        for (int m = 0; m < FN_LB; ++m)
+          if (64 * m + lane <= first_inc) contrib += (long long)(v[m] & FN_VALUE);
+        contrib = wave_reduce_sum(contrib);
+        base += __shfl(contrib, 0, 64);
+        if (first_inc < 64 * FN_LB) break;
+        top -= 64 * FN_LB;
       }
-      continue;
     }
-    for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
-    if (tid < FN_WORDS) fmask[tid] = 0;
-    __syncthreads();
+    if (lane == 0) {
+      __hip_atomic_store(mine, FN_INC | (unsigned long long)(base + D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (b == n_buckets - 1) state[FS_UNIQUE] = (unsigned long long)(base + D);
+    }
+    return base;
+  };
+
+  for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
+  if (tid < FN_WORDS) fmask[tid] = 0;
+  if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
+  __syncthreads();
+  fn_bucket nxt = fn_open(bucket_off, n_buckets, sh[0]);
+  uint64_t kn[FN_ITEMS];
+#pragma unroll
+  for (int q = 0; q < FN_ITEMS; ++q) {
+    const int i = tid + q * FN_THREADS;
+    if (i < nxt.nb) kn[q] = A[nxt.lo + i];
+  }
+  __syncthreads();                                    // everybody has read sh[0]
+
+  while (nxt.b < n_buckets) {
+    const fn_bucket cur = nxt;
+    const int nb = cur.nb;
+    if (tid == 0) {
+      sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);       // tickets follow the dispatch order: a bucket
+      if (cur.over) atomicOr(&state[FS_FLAGS], 1ull);              // only ever waits for workgroups that started
+    }
     // counting sort on the next sbits bits: rank inside the bin from an LDS counter
     uint64_t k[FN_ITEMS];
     unsigned r[FN_ITEMS];
+    unsigned valid = 0;
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
       const int i = tid + q * FN_THREADS;
       if (i < nb) {
-        k[q] = A[lo + i];
+        k[q] = kn[q];
         r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
+        valid |= 1u << q;
       }
     }
     __syncthreads();
+    // prefetch the next bucket while this one is sorted
+    nxt = fn_open(bucket_off, n_buckets, sh[0]);
+#pragma unroll
+    for (int q = 0; q < FN_ITEMS; ++q) {
+      const int i = tid + q * FN_THREADS;
+      if (i < nxt.nb) kn[q] = A[nxt.lo + i];
+    }
+    if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
+      if (wave == 0) look_back(cur.b, 0u);
+      __syncthreads();
+      continue;
+    }
     {
       unsigned c[FN_BINS_PER_LANE], s = 0;
 #pragma unroll
@@ -479,86 +651,100 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       if (tid == 0) bins[SB] = (unsigned)nb;
     }
     __syncthreads();
-    unsigned p[FN_ITEMS];
+    unsigned p[FN_ITEMS], bs[FN_ITEMS];
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tid + q * FN_THREADS;
-      if (i < nb) {
-        p[q] = bins[(unsigned)(k[q] >> sshift) & (SB - 1)] + r[q];
+      p[q] = bs[q] = 0;
+      if ((valid >> q) & 1u) {
+        bs[q] = bins[(unsigned)(k[q] >> sshift) & (SB - 1)];
+        p[q] = bs[q] + r[q];
         stage[p[q]] = k[q];
       }
     }
     __syncthreads();
-    // first occurrence of every distinct key inside its (tiny) bin
-    unsigned first_bits = 0, dcount = 0;
+    // First occurrence of every distinct key inside its (tiny) bin: walk the bin from its start up to the key's own
+    // slot.  The eight keys of a lane advance together (eight independent LDS reads per step instead of eight
+    // latency-bound loops); a key that finds an earlier equal one marks its slot (bit 63) and drops out.
+    unsigned active = 0, dup = 0;
 #pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tid + q * FN_THREADS;
-      if (i < nb) {
-        const unsigned s = bins[(unsigned)(k[q] >> sshift) & (SB - 1)];
-        bool first = true;
-        for (unsigned j = s; j < p[q]; ++j)
-          if (stage[j] == k[q]) { first = false; break; }
-        if (first) {
-          first_bits |= 1u << q;
-          ++dcount;
-          if (WRITE) atomicOr(&fmask[p[q] >> 6], 1ull << (p[q] & 63));
+    for (int q = 0; q < FN_ITEMS; ++q)
+      if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
+    if (ablate & 8) active = 0;
+    for (unsigned step = 0; __any(active != 0); ++step) {
+#pragma unroll
+      for (int q = 0; q < FN_ITEMS; ++q) {
+        if ((active >> q) & 1u) {
+          const unsigned j = bs[q] + step;
+          const uint64_t y = stage[j] & KEYMASK;
+          if (y == k[q]) { dup |= 1u << q; active &= ~(1u << q); }
+          else if (j + 1 >= p[q]) active &= ~(1u << q);
         }
       }
     }
-    if (!WRITE) {
-      const unsigned d = wave_reduce_sum(dcount);
-      if (lane == 0) wsum[wave] = d;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned t = 0;
-        for (int w = 0; w < FN_THREADS / 64; ++w) t += wsum[w];
-        bucket_counts[b] = t;
-      }
-      __syncthreads();
-      continue;
-    }
-    __syncthreads();
-    if (tid < 64) {                                    // exclusive prefix of the popcounts of the mask words
-      const unsigned c0 = __popcll(fmask[2 * tid]), c1 = __popcll(fmask[2 * tid + 1]);
-      const unsigned inc = wave_inclusive_scan(c0 + c1);
-      fprefix[2 * tid] = inc - c0 - c1;
-      fprefix[2 * tid + 1] = inc - c1;
-      if (tid == 63) fprefix[FN_WORDS] = inc;
-    }
-    __syncthreads();
-    unsigned idx[FN_ITEMS], mult[FN_ITEMS];
+    const unsigned first_bits = valid & ~dup;
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
-      if (first_bits & (1u << q)) {
-        const unsigned bin = (unsigned)(k[q] >> sshift) & (SB - 1);
-        const unsigned s = bins[bin], e = bins[bin + 1];
-        unsigned cnt = 0, rank = 0;
-        for (unsigned j = s; j < e; ++j) {
-          const uint64_t y = stage[j];
-          cnt += (y == k[q]);
-          rank += (y < k[q]) && ((fmask[j >> 6] >> (j & 63)) & 1ull);
+      if ((dup >> q) & 1u) stage[p[q]] = k[q] | ~KEYMASK;
+      if ((first_bits >> q) & 1u) atomicOr(&fmask32[p[q] >> 5], 1u << (p[q] & 31));
+    }
+    __syncthreads();
+    // every wavefront scans the popcounts of the mask words in its own registers (lane l: words FN_WPL*l ..)
+    const unsigned c0 = __popcll(fmask[FN_WPL * lane]);
+    const unsigned c1 = FN_WPL == 2 ? __popcll(fmask[FN_WPL * lane + 1]) : 0u;
+    const unsigned pinc = wave_inclusive_scan(c0 + c1);
+    const unsigned pex = pinc - c0 - c1;
+    const unsigned D = (unsigned)__builtin_amdgcn_readlane((int)pinc, 63);      // distinct keys of the bucket
+    if (wave == 0) {
+      const long long base = (ablate & 1) ? cur.lo : look_back(cur.b, D);
+      if (lane == 0) sh[1] = base;
+    }
+    // multiplicity and sorted position of every distinct key (the lane shuffles run with all lanes active)
+    unsigned idx[FN_ITEMS], mult[FN_ITEMS], len[FN_ITEMS];
+    unsigned todo = 0;
+#pragma unroll
+    for (int q = 0; q < FN_ITEMS; ++q) {
+      const bool is_first = (first_bits >> q) & 1u;
+      unsigned e = 0;
+      if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
+      const unsigned s = bs[q];
+      const unsigned w = s >> 6;                       // distinct keys before the bin = prefix of mask word w + bits below s
+      const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
+      idx[q] = mult[q] = len[q] = 0;
+      if (is_first) {
+        idx[q] = pw + ((FN_WPL == 2 && (w & 1)) ? cw : 0u) + __popcll(fmask[w] & ((1ull << (s & 63)) - 1ull));
+        len[q] = e - s;
+        todo |= 1u << q;
+      }
+    }
+    if (ablate & 4) todo = 0;
+    for (unsigned step = 0; __any(todo != 0); ++step) {
+#pragma unroll
+      for (int q = 0; q < FN_ITEMS; ++q) {
+        if ((todo >> q) & 1u) {
+          const uint64_t y = stage[bs[q] + step];
+          mult[q] += ((y & KEYMASK) == k[q]);
+          idx[q] += (y < k[q]);                        // marked duplicates (bit 63) compare greater: not counted
+          if (step + 1 >= len[q]) todo &= ~(1u << q);
         }
-        mult[q] = cnt;
-        idx[q] = fprefix[s >> 6] + __popcll(fmask[s >> 6] & ((1ull << (s & 63)) - 1ull)) + rank;
       }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
-      if (first_bits & (1u << q)) {
+      if ((first_bits >> q) & 1u) {
         stage[idx[q]] = k[q];
         cnt16[idx[q]] = (unsigned short)mult[q];
       }
     }
+    for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;      // ready for the next bucket
+    if (tid < FN_WORDS) fmask[tid] = 0;
     __syncthreads();
-    const unsigned D = fprefix[FN_WORDS];
-    const int64_t base = bucket_counts[b];
+    const int64_t base = sh[1];
+    if (ablate & 2) continue;
     for (unsigned i = tid; i < D; i += FN_THREADS) {
       keys_out[base + i] = stage[i];
       counts_out[base + i] = cnt16[i];
     }
-    __syncthreads();
   }
 }
 
@@ -566,13 +752,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 
 extern "C" {
 
-int64_t bnpk_radix_max_bits(void) { return 10; }
+int64_t bnpk_radix_max_bits(void) { return RP_MAXBITS; }
 int64_t bnpk_finish_capacity(void) { return FN_CAP; }
 
 int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
                          int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream) {
-  if (!ctx || n < 0 || n_seg < 1 || bits < 0 || bits > 10 || shift < 0 || shift + bits > 63) return BNPK_ERR_ARG;
-  if (n >= (1ll << 36)) return BNPK_ERR_RANGE;
+  if (!ctx || n < 0 || n_seg < 1 || bits < 0 || bits > RP_MAXBITS || shift < 0 || shift + bits > 63) return BNPK_ERR_ARG;
+  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
   if (n > 0 && (!d_keys || !d_out || d_keys == d_out)) return BNPK_ERR_ARG;
   if (n_seg > 1 && !d_seg_offsets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -586,9 +772,9 @@ int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const 
 int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
                          const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k, int shift, int bits,
                          int64_t* d_out, int64_t* d_child_offsets, void* stream) {
-  if (!ctx || k < 1 || k > 31 || n_rows < 0 || n_out < 0 || bits < 0 || bits > 10 || shift < 0 || shift + bits > 2 * k)
+  if (!ctx || k < 1 || k > 31 || n_rows < 0 || n_out < 0 || bits < 0 || bits > RP_MAXBITS || shift < 0 || shift + bits > 2 * k)
     return BNPK_ERR_ARG;
-  if (n_out >= (1ll << 36)) return BNPK_ERR_RANGE;
+  if (n_out >= (1ll << 35)) return BNPK_ERR_RANGE;
   if (n_out > 0 && (!d_packed || !d_in_offsets || !d_out_offsets || !d_out || n_rows == 0)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = ceil_div(std::max<int64_t>(n_out, 1), RP_GRAN);
@@ -602,7 +788,7 @@ int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t*
                   "kmers_partition_hist", "kmers_partition_scatter", s);
 }
 
-int64_t bnpk_finish_state_words(int64_t n_buckets) { return 8 + std::max<int64_t>(n_buckets, 0) + 1; }
+int64_t bnpk_finish_state_words(int64_t n_buckets) { return FS_BUCKETS + std::max<int64_t>(n_buckets, 0) + 1; }
 
 int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
@@ -617,39 +803,30 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
   hipStream_t s = (hipStream_t)stream;
   const int sbits = std::min(low_bits, FN_MAXBITS);
   const int sshift = low_bits - sbits;
-  unsigned long long* flags = reinterpret_cast<unsigned long long*>(d_state);
-  int64_t* counts = d_state + 8;
-  void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scratch));
   static bool attr_set = false;
   if (!attr_set) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)FN_LDS));
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)FN_LDS));
     attr_set = true;
   }
-  BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, 8 * sizeof(int64_t), s));
-  const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units * 16);
-  const uint64_t* A = reinterpret_cast<const uint64_t*>(d_part);
+  BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)bnpk_finish_state_words(n_buckets) * sizeof(int64_t), s));
+  const char* ab = getenv("BNPK_ABLATE");        // kernel-timing experiments only; results are invalid when set
+  const int ablate = ab ? atoi(ab) : 0;
+  // one workgroup per CU fits (LDS); the ticket order keeps the look-back deadlock-free for any grid size
+  const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
   {
-    bnpk_timer t(ctx, "finish_sorted_count", s);
-    hipLaunchKernelGGL((finish_sorted_kernel<false>), dim3(grid), dim3(FN_THREADS), FN_LDS, s, A, d_bucket_offsets,
-                       n_buckets, sshift, sbits, counts, (uint64_t*)nullptr, (int64_t*)nullptr, flags);
+    bnpk_timer t(ctx, "finish_sorted", s);
+    hipLaunchKernelGGL(finish_sorted_kernel, dim3(grid), dim3(FN_THREADS), FN_LDS, s,
+                       reinterpret_cast<const uint64_t*>(d_part), d_bucket_offsets, n_buckets, sshift, sbits,
+                       reinterpret_cast<unsigned long long*>(d_state), reinterpret_cast<uint64_t*>(d_keys_out),
+                       d_counts_out, ablate);
     BNPK_HIP(ctx, hipGetLastError());
-    BNPK_CHECK(bnpk_scan_launch(ctx, counts, n_buckets, 1, counts, true, (int64_t*)scratch, s));
   }
-  int64_t host_flag = 0, total = 0;
-  BNPK_HIP(ctx, hipMemcpyAsync(&host_flag, d_state, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-  BNPK_HIP(ctx, hipMemcpyAsync(&total, counts + n_buckets, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  int64_t host[3] = {0, 0, 0};
+  BNPK_HIP(ctx, hipMemcpyAsync(host, d_state, sizeof(host), hipMemcpyDeviceToHost, s));
   BNPK_HIP(ctx, hipStreamSynchronize(s));
-  *h_overflow = host_flag != 0;
-  if (*h_overflow) return BNPK_OK;
-  *h_n_unique = total;
-  bnpk_timer t(ctx, "finish_sorted_write", s);
-  hipLaunchKernelGGL((finish_sorted_kernel<true>), dim3(grid), dim3(FN_THREADS), FN_LDS, s, A, d_bucket_offsets,
-                     n_buckets, sshift, sbits, counts, reinterpret_cast<uint64_t*>(d_keys_out), d_counts_out, flags);
-  BNPK_HIP(ctx, hipGetLastError());
+  *h_overflow = host[FS_FLAGS] != 0;
+  *h_n_unique = host[FS_UNIQUE];
   return BNPK_OK;
 }
 

@@ -223,7 +223,7 @@ class HipOps:
         rest = max(0, need - done)
         if rest == 0:
             return []
-        max_bits = 10                                    # bnpk_radix_max_bits()
+        max_bits = 10                                    # bnpk_radix_max_bits() is 11; 10-bit digits flush whole 128-B lines
         levels = -(-rest // max_bits)
         base, extra = divmod(rest, levels)
         return [base + (1 if i < extra else 0) for i in range(levels)]

@@ -193,7 +193,7 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  *                         write-combining scatter (whole 128-byte lines only); d_child_offsets gets the
  *                         n_seg * 2^bits + 1 boundaries of the child buckets, which are the segments of the next
  *                         level.  d_seg_offsets may be NULL when n_seg == 1.  d_out must not alias d_keys.
- *                         Keys must be < 2^63; n < 2^36.
+ *                         Keys must be < 2^63; n < 2^35.
  *   bnpk_finish_sorted    every bucket [d_bucket_offsets[b], d_bucket_offsets[b+1]) (keys equal above bit
  *                         `low_bits`, at most bnpk_finish_capacity() of them, any order) is sorted in LDS,
  *                         run-length-counted and written as sorted distinct keys + multiplicities.  Synchronous:

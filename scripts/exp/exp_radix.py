@@ -30,7 +30,7 @@ for rep in range(reps + 1):
     nu, ov = C.c_int64(0), C.c_int(0)
     lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 62 - b1 - b2, ptr(a), ptr(counts), ptr(state), C.byref(nu), C.byref(ov), dev.stream())
     torch.cuda.synchronize()
-    if rep == 0:
+    if rep == 0 and not os.environ.get("BNPK_ABLATE"):
         print("n_unique", nu.value, "overflow", ov.value, "sorted", bool((a[1:nu.value] > a[:nu.value - 1]).all().item()))
     del a, b, counts, state, off1, off2
 rep_ = dev.prof_report()
