@@ -81,9 +81,41 @@ __global__ __launch_bounds__(BNPK_BLOCK) void row_ids_kernel(const int64_t* __re
   }
 }
 
+// bits [off[r], off[r+1] - (k-1)) of the mask for every row r with at least k bases: the positions of the flat
+// packed stream at which a k-mer starts.  One lane per row; a row touches a handful of 32-bit words.
+__global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t n_rows, int k,
+                                       unsigned* __restrict__ mask32) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n_rows; r += stride) {
+    const int64_t s = off[r], e = off[r + 1] - (k - 1);
+    for (int64_t p = s; p < e;) {
+      const int64_t w = p >> 5;
+      const int lo = (int)(p & 31);
+      const int hi = (int)min((int64_t)32, e - (w << 5));              // bits [lo, hi) of word w
+      const unsigned bits = (hi >= 32 ? ~0u : ((1u << hi) - 1u)) & ~((1u << lo) - 1u);
+      if (bits == ~0u) mask32[w] = bits; else atomicOr(&mask32[w], bits);   // a full word belongs to one row
+      p = (w + 1) << 5;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t total, int k,
+                         uint64_t* d_mask, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || k < 1 || !d_mask || (n_rows > 0 && !d_offsets)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "kmer_start_mask", s);
+  BNPK_HIP(ctx, hipMemsetAsync(d_mask, 0, (size_t)(total / 64 + 2) * 8, s));
+  if (n_rows > 0)
+    hipLaunchKernelGGL(kmer_start_mask_kernel, dim3(grid_for(ceil_div(n_rows, 256))), dim3(256), 0, s, d_offsets,
+                       n_rows, k, reinterpret_cast<unsigned*>(d_mask));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
 
 int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
                int64_t n_rows, int64_t n_out, int k, int64_t* d_hashes, void* stream) {

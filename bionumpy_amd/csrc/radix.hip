@@ -18,7 +18,6 @@
 
 #include "common.h"
 #include "kmer_gen.h"
-#include "rows.h"
 #include "scan.h"
 
 namespace {
@@ -27,10 +26,8 @@ constexpr int RP_THREADS = 1024;
 constexpr int RP_MAXBITS = 11;
 constexpr int RP_TILE = 8192;                         // new keys per round (at most)
 constexpr int RP_MAXITEMS = RP_TILE / RP_THREADS;     // 8
-constexpr int RP_GRAN = 1024;                         // granularity of the tile -> row table of the fused source
 constexpr uint64_t RP_PHANTOM = 1ull << 63;           // placeholder for the slots before a bucket's first key
-constexpr int RP_CACHE_ROWS = 256;                    // rows of a tile whose offsets the fused source caches in LDS
-constexpr size_t RP_CACHE_BYTES = (size_t)RP_CACHE_ROWS * 2 * 8;
+constexpr size_t RP_CACHE_BYTES = 0;                  // LDS scratch handed to the key sources (none needs it now)
 
 // Two shapes of the scatter kernel: digits up to 10 bits flush whole 128-byte lines (16 keys); 11-bit digits
 // (2048 buckets) flush 64-byte half lines, because the carried keys (< LINE per bucket) have to fit LDS.
@@ -92,67 +89,76 @@ __device__ __forceinline__ bool find_slab(const int64_t* __restrict__ seg_off, c
 }
 
 // ---- key sources ---------------------------------------------------------------------------------------------
-// load(): up to `items` keys of the tile [t0, t0 + items*RP_THREADS) ∩ [.., hi) for this lane; returns how many.
-// Called by every lane of the workgroup (it may synchronise); `cache` is RP_CACHE_BYTES of LDS scratch.
+// A tile is the item range [t0, t0 + T) ∩ [.., hi), T = items * RP_THREADS <= RP_TILE.  issue() starts the global
+// loads of a whole RP_TILE-sized tile into registers (no use of the values, so nothing waits), finish() turns the
+// first T items' worth of them into keys: k[q] for every bit q of the returned mask.  The partition kernels issue two tiles ahead of the one they
+// finish, so a full round of LDS work hides the HBM latency.
 struct mem_source {
   const uint64_t* __restrict__ keys;
-  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS], int64_t*) const {
-    int cnt = 0;
+  struct raw_t { uint64_t v[RP_MAXITEMS]; };
+  __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
-      int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
-      if (q < items && i < hi) { k[q] = keys[i]; ++cnt; }
+      const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
+      if (i < hi) raw.v[q] = keys[i];
     }
-    return cnt;
+  }
+  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[RP_MAXITEMS]) const {
+    unsigned vm = 0;
+#pragma unroll
+    for (int q = 0; q < RP_MAXITEMS; ++q) {
+      const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
+      if (q < items && i < hi) { k[q] = raw.v[q]; vm |= 1u << q; }
+    }
+    return vm;
   }
 };
 
-// the k-mer hashes of the ragged read set, generated on the fly from the packed 2-bit reads (A8); key index ==
-// flat output index of bnpk_kmers.  Every lane produces `items` consecutive k-mers; the row offsets the tile
-// touches are first copied to LDS (one coalesced load instead of a chain of dependent binary-search loads).
+// The k-mer hashes of the ragged read set, generated on the fly from the packed 2-bit reads (A8).  Items are the
+// flat BASE positions of the packed stream, not output indices: a bit mask (one bit per base, bnpk_kmer_start_mask)
+// says at which positions a k-mer starts, so the generation needs no row lookup at all — four coalesced word
+// loads per lane, one funnel shift for the first k-mer and a 2-bit roll for each of the next seven.  A lane owns
+// eight consecutive positions; a tile of T positions yields at most T keys.
 struct kmer_source {
-  const uint64_t* __restrict__ W;
-  const int64_t* __restrict__ in_off;
-  const int64_t* __restrict__ out_off;
-  const int64_t* __restrict__ tile_rows;   // row containing output t*RP_GRAN
-  int64_t n_rows, n_tiles;
-  uint64_t mask;
-
-  __device__ __forceinline__ int gen(const int64_t* __restrict__ ioff, const int64_t* __restrict__ ooff, int64_t rlo,
-                                     int64_t rhi, int64_t o, int64_t end, int items, uint64_t k[RP_MAXITEMS]) const {
-    row_cursor c = seek_row(ioff, ooff, rlo, rhi, o);
-    word_window ww;
-    int cnt = 0;
+  const uint64_t* __restrict__ W;          // 2 bits per base
+  const uint8_t* __restrict__ V;           // 1 bit per base: a k-mer starts here (positions are multiples of 8 per lane)
+  int64_t n_words;                         // words of W
+  int k;
+  struct raw_t { uint64_t w0, w1, w2; unsigned v; };
+  __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
+    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
+    if (o < hi) {
+      const int64_t wi = o >> 5;
+      raw.w0 = W[wi];
+      raw.w1 = W[wi + 1];
+      raw.w2 = wi + 2 < n_words ? W[wi + 2] : 0;
+      raw.v = V[o >> 3];
+    }
+  }
+  // the 64 bits at bit offset sh (< 128) of the 192-bit window
+  __device__ __forceinline__ static uint64_t window(const raw_t& raw, int sh) {
+    const uint64_t lo = sh < 64 ? raw.w0 : raw.w1, hi = sh < 64 ? raw.w1 : raw.w2;
+    const int s6 = sh & 63;
+    return s6 ? (lo >> s6) | (hi << (64 - s6)) : lo;
+  }
+  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t kk[RP_MAXITEMS]) const {
+    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
+    const int64_t end = min(t0 + (int64_t)items * RP_THREADS, hi);
+    if (o >= end) return 0;
+    unsigned valid = raw.v;
+    if (end - o < RP_MAXITEMS) valid &= (1u << (int)(end - o)) - 1u;
+    if (valid == 0) return 0;
+    const int sh0 = 2 * (int)(o & 31);
+    const uint64_t mask = (1ull << (2 * k)) - 1ull;
+    uint64_t h = window(raw, sh0) & mask;                      // k-mer at position o
+    const uint64_t next = window(raw, sh0 + 2 * k);            // the bases that enter at positions o+1 .. o+7 (14 bits)
+    const int top = 2 * k - 2;
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
-      const int64_t oo = o + q;
-      if (q >= items || oo >= end) break;
-      if (q) next_output(c, ioff, ooff, oo);
-      k[q] = bits_at(W, c.in_pos, ww) & mask;
-      ++cnt;
+      if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
+      kk[q] = h;                                               // slots of invalid positions are never read
     }
-    return cnt;
-  }
-
-  __device__ __forceinline__ int load(int64_t t0, int64_t hi, int items, uint64_t k[RP_MAXITEMS], int64_t* cache) const {
-    const int64_t end = min(t0 + (int64_t)items * RP_THREADS, hi);              // uniform
-    if (t0 >= end) return 0;
-    const int64_t t_first = t0 / RP_GRAN, t_last = (end - 1) / RP_GRAN;
-    const int64_t rlo = tile_rows[t_first];
-    const int64_t rhi = (t_last + 1 < n_tiles) ? tile_rows[t_last + 1] : n_rows - 1;
-    const int64_t span = rhi - rlo + 1;                                         // rows the tile can touch
-    const int64_t o = t0 + (int64_t)threadIdx.x * items;
-    if (span + 1 > RP_CACHE_ROWS) return o < end ? gen(in_off, out_off, rlo, rhi, o, end, items, k) : 0;
-    int64_t* c_out = cache;
-    int64_t* c_in = cache + RP_CACHE_ROWS;
-    for (int64_t i = threadIdx.x; i <= span; i += RP_THREADS) {
-      c_out[i] = out_off[rlo + i];
-      if (i < span) c_in[i] = in_off[rlo + i];
-    }
-    __syncthreads();
-    const int cnt = o < end ? gen(c_in, c_out, 0, span - 1, o, end, items, k) : 0;
-    __syncthreads();                                                            // the cache is reused by the next tile
-    return cnt;
+    return valid;
   }
 };
 
@@ -165,18 +171,21 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* h = reinterpret_cast<unsigned*>(smem);
   int64_t* sh = reinterpret_cast<int64_t*>(smem + (size_t)RP_HIST_BINS * 4);
-  int64_t* cache = sh + 8;
   const int B = 1 << bits;
   slab_t sl;
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   for (int c = threadIdx.x; c < B; c += RP_THREADS) h[c] = 0;
   __syncthreads();
+  typename Source::raw_t raw, raw_next;
+  src.issue(sl.lo, sl.hi, raw);
   for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += RP_TILE) {
+    if (t0 + RP_TILE < sl.hi) src.issue(t0 + RP_TILE, sl.hi, raw_next);      // one tile ahead
     uint64_t k[RP_MAXITEMS];
-    const int cnt = src.load(t0, sl.hi, RP_MAXITEMS, k, cache);
+    const unsigned vm = src.finish(t0, sl.hi, RP_MAXITEMS, raw, k);
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q)
-      if (q < cnt) atomicAdd(&h[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+      if ((vm >> q) & 1u) atomicAdd(&h[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+    raw = raw_next;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < B; c += RP_THREADS) H[sl.hbase + (int64_t)c * sl.nsl + sl.local] = h[c];
@@ -189,7 +198,8 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
 //   layout per bucket: nfl = keys that complete whole lines, the rest is carried; one packed scan gives every
 //          bucket a slice of the FLUSH region (a multiple of LINE keys, line-aligned in LDS) and a slice of the
 //          CARRY region behind it
-//   stage  carried + new keys are written to their slices
+//   stage  carried + new keys are written to their slices; every flush slice is rotated by a bucket-dependent even
+//          offset, otherwise all slices start on LDS bank 0 and equal ranks collide 16-way
 //   flush  the FLUSH region leaves the CU as aligned 16-byte-per-lane stores (whole lines only); the CARRY region is
 //          read back into the owning lanes' registers
 template <typename Source, int LINE>
@@ -206,7 +216,6 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   unsigned* line = reinterpret_cast<unsigned*>(smem + C::OFF_LINE);   // write cursor of the bucket / LINE
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + C::OFF_WSUM);
   int64_t* sh = reinterpret_cast<int64_t*>(smem + C::OFF_SLAB);
-  int64_t* cache = reinterpret_cast<int64_t*>(smem + C::OFF_CACHE);
   const int B = 1 << bits;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   slab_t sl;
@@ -248,12 +257,14 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
 
   int64_t t0 = sl.lo;
   unsigned T = tile_size(carried);
+  typename Source::raw_t raw;                     // loads of the next tile, in flight while this one is staged + flushed
+  src.issue(t0, sl.hi, raw);
   uint64_t k[RP_MAXITEMS];
   unsigned r[RP_MAXITEMS];
-  int cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k, cache);
+  unsigned vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
 #pragma unroll
   for (int q = 0; q < RP_MAXITEMS; ++q)
-    if (q < cnt) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+    if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
   __syncthreads();
 
   while (true) {
@@ -291,35 +302,70 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       if (d < B) {
         meta[d] = (uint64_t)fpos | ((uint64_t)nfl[b] << 16) | ((uint64_t)cpos[b] << 32) | ((uint64_t)rem[b] << 48);
         line[d] = (unsigned)(cursor[b] >> C::LOG_LINE);
-        const unsigned base = nfl[b] ? fpos : cpos[b];         // carried keys precede the new ones (rem < LINE <= nfl)
+        // carried keys precede the new ones (rem < LINE <= nfl): in-bucket indices 0 .. rem-1
+        const unsigned rot = last ? 0u : 2u * ((unsigned)d & (unsigned)(LINE / 2 - 1));
 #pragma unroll
-        for (int j = 0; j < C::CARRY; ++j)
-          if (j < (int)rem[b]) stage[base + j] = left[b][j];
+        for (int j = 0; j < C::CARRY; ++j) {
+          if (j < (int)rem[b]) {
+            unsigned m = j + rot;
+            if (m >= nfl[b]) m -= nfl[b];
+            stage[nfl[b] ? fpos + m : cpos[b] + j] = left[b][j];
+          }
+        }
       }
     }
     __syncthreads();
+    // the next tile's extent is known: start its loads now, they land while this tile is staged and flushed
+    const unsigned T_next = tile_size(total >> 16);
+    if (!last) src.issue(t0 + T, sl.hi, raw);
     // stage the new keys behind the carried ones
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
-      if (q < cnt) {
-        const uint64_t m = meta[(unsigned)(k[q] >> shift) & (B - 1)];
+      if ((vm >> q) & 1u) {
+        const unsigned d = (unsigned)(k[q] >> shift) & (B - 1);
+        const uint64_t m = meta[d];
         const unsigned j = (unsigned)(m >> 48) + r[q], f = (unsigned)(m >> 16) & 0xffffu;
-        stage[j < f ? ((unsigned)m & 0xffffu) + j : ((unsigned)(m >> 32) & 0xffffu) + j - f] = k[q];
+        unsigned jr = j + (last ? 0u : 2u * (d & (unsigned)(LINE / 2 - 1)));            // slot inside the (rotated) flush slice
+        if (jr >= f) jr -= f;
+        stage[j < f ? ((unsigned)m & 0xffffu) + jr : ((unsigned)(m >> 32) & 0xffffu) + j - f] = k[q];
       }
     }
     __syncthreads();
-    // flush: whole lines, 16 bytes per lane
+    // flush: whole lines, 16 bytes per lane; two independent LDS -> HBM chains per lane and iteration
     if (!last) {
-      for (unsigned i = 2 * tid; i < total_f; i += 2 * RP_THREADS) {
-        const ulonglong2 kk = *reinterpret_cast<const ulonglong2*>(stage + i);
-        const unsigned d = (unsigned)(kk.x >> shift) & (B - 1);
-        const unsigned f = (unsigned)meta[d] & 0xffffu;
-        uint64_t* dst = out + (((int64_t)line[d] << C::LOG_LINE) + (i - f));
-        if (!((kk.x | kk.y) >> 63)) {
-          *reinterpret_cast<ulonglong2*>(dst) = kk;
-        } else {                                             // phantom slots before the bucket's first key
-          if (!(kk.x >> 63)) dst[0] = kk.x;
-          if (!(kk.y >> 63)) dst[1] = kk.y;
+      for (unsigned i0 = 2 * tid; i0 < total_f; i0 += 4 * RP_THREADS) {
+        ulonglong2 kk[2];
+        unsigned d[2], f[2], nf[2], ln[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned i = i0 + u * 2 * RP_THREADS;
+          if (i < total_f) kk[u] = *reinterpret_cast<const ulonglong2*>(stage + i);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned i = i0 + u * 2 * RP_THREADS;
+          if (i < total_f) {
+            d[u] = (unsigned)(kk[u].x >> shift) & (B - 1);
+            const unsigned m = (unsigned)meta[d[u]];
+            f[u] = m & 0xffffu;
+            nf[u] = m >> 16;
+            ln[u] = line[d[u]];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const unsigned i = i0 + u * 2 * RP_THREADS;
+          if (i < total_f) {
+            unsigned j = i - f[u], rot = 2u * (d[u] & (unsigned)(LINE / 2 - 1));      // undo the rotation of the slice
+            j = j >= rot ? j - rot : j + nf[u] - rot;
+            uint64_t* dst = out + (((int64_t)ln[u] << C::LOG_LINE) + j);
+            if (!((kk[u].x | kk[u].y) >> 63)) {
+              *reinterpret_cast<ulonglong2*>(dst) = kk[u];
+            } else {                                           // phantom slots before the bucket's first key
+              if (!(kk[u].x >> 63)) dst[0] = kk[u].x;
+              if (!(kk[u].y >> 63)) dst[1] = kk[u].y;
+            }
+          }
         }
       }
     } else {
@@ -340,13 +386,13 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
         rem[b] = nrem[b];
       }
     }
-    // next tile: load / generate and rank now, so that its latency overlaps the drain of the stores above
+    // next tile (its loads were issued before the staging): keys + ranks
     t0 += T;
-    T = tile_size(total >> 16);
-    cnt = src.load(t0, sl.hi, (int)(T / RP_THREADS), k, cache);
+    T = T_next;
+    vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q)
-      if (q < cnt) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+      if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
     __syncthreads();
   }
 }
@@ -382,7 +428,7 @@ __global__ void rp_single_segment_kernel(int64_t n, int64_t* seg_off) {
 
 // child_off[p*B + c] = first output position of child bucket c of segment p (scanned histogram at slab 0)
 __global__ void rp_child_offsets_kernel(const int64_t* __restrict__ scanned, const int64_t* __restrict__ seg_slabs,
-                                        int64_t n_seg, int B, int64_t n, int64_t* __restrict__ child_off) {
+                                        int64_t n_seg, int B, int64_t hn, int64_t* __restrict__ child_off) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x, m = n_seg * B;
   for (; i < m; i += stride) {
@@ -390,7 +436,7 @@ __global__ void rp_child_offsets_kernel(const int64_t* __restrict__ scanned, con
     const int64_t first = seg_slabs[p], nsl = seg_slabs[p + 1] - first;
     child_off[i] = scanned[first * B + c * nsl];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) child_off[m] = n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) child_off[m] = scanned[hn];      // == number of keys
 }
 
 int64_t rp_slab_keys(int64_t n) {
@@ -444,7 +490,7 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
     BNPK_CHECK(bnpk_scan_launch(ctx, H, hn, 1, H, true, scan_scratch, s));
     if (d_child_off)
       hipLaunchKernelGGL(rp_child_offsets_kernel, dim3(grid_for(ceil_div(n_seg * B, 256))), dim3(256), 0, s,
-                         (const int64_t*)H, (const int64_t*)seg_slabs, n_seg, B, n, d_child_off);
+                         (const int64_t*)H, (const int64_t*)seg_slabs, n_seg, B, hn, d_child_off);
   }
   bnpk_timer t(ctx, scatter_name, s);
   if (bits <= 10)
@@ -769,22 +815,17 @@ int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const 
                   "radix_hist", "radix_scatter", s);
 }
 
-int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
-                         const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k, int shift, int bits,
-                         int64_t* d_out, int64_t* d_child_offsets, void* stream) {
-  if (!ctx || k < 1 || k > 31 || n_rows < 0 || n_out < 0 || bits < 0 || bits > RP_MAXBITS || shift < 0 || shift + bits > 2 * k)
+int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_kmer_starts, int64_t n_bases, int k,
+                         int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream) {
+  if (!ctx || k < 1 || k > 31 || n_bases < 0 || bits < 0 || bits > RP_MAXBITS || shift < 0 || shift + bits > 2 * k)
     return BNPK_ERR_ARG;
-  if (n_out >= (1ll << 35)) return BNPK_ERR_RANGE;
-  if (n_out > 0 && (!d_packed || !d_in_offsets || !d_out_offsets || !d_out || n_rows == 0)) return BNPK_ERR_ARG;
+  if (n_bases >= (1ll << 35)) return BNPK_ERR_RANGE;
+  if (n_bases > 0 && (!d_packed || !d_kmer_starts || !d_out)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t n_tiles = ceil_div(std::max<int64_t>(n_out, 1), RP_GRAN);
-  const size_t table_bytes = align64(tile_rows_bytes(n_tiles));
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, table_bytes + rp_level_scratch(n_out, 1, bits), &scratch));
-  int64_t* table = (int64_t*)scratch;
-  if (n_out > 0) BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, RP_GRAN, table, s));
-  kmer_source src{d_packed, d_in_offsets, d_out_offsets, table, n_rows, n_tiles, (1ull << (2 * k)) - 1ull};
-  return rp_level(ctx, src, n_out, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch + table_bytes,
+  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n_bases, 1, bits), &scratch));
+  kmer_source src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
+  return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
                   "kmers_partition_hist", "kmers_partition_scatter", s);
 }
 

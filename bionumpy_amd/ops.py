@@ -228,13 +228,19 @@ class HipOps:
         base, extra = divmod(rest, levels)
         return [base + (1 if i < extra else 0) for i in range(levels)]
 
-    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, bits):
+    def kmer_start_mask(self, offsets, n_rows, total, k):
+        """one bit per base, set where a k-mer starts (bnpk_kmer_start_mask)"""
+        mask = self._empty(total // 64 + 2, np.int64)
+        self._chk(lib.bnpk_kmer_start_mask(self.ctx, ptr(offsets.dev()), n_rows, total, k, ptr(mask), self._s()))
+        return HArray(dev=mask)
+
+    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits):
         """bnpk_kmers_partition: the k-mer hashes written once, partitioned by their top ``bits`` bits.
         Returns (hashes, bucket offsets[2^bits + 1])"""
         out = self._empty(n_out, np.int64)
         child = self._empty((1 << bits) + 1, np.int64)
-        self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
-                                           n_rows, n_out, k, 2 * k - bits, bits, ptr(out), ptr(child), self._s()))
+        self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(starts_mask.dev()), n_bases, k, 2 * k - bits,
+                                           bits, ptr(out), ptr(child), self._s()))
         return HArray(dev=out), HArray(dev=child)
 
     def radix_partition(self, keys_t, seg_offsets_t, n_seg, shift, bits, out_t=None):

@@ -52,14 +52,18 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
         return hist, stats
     if distributed:                                                                                   # A9 sparse, N GPUs
         # generate the hashes already partitioned by their top 8 bits == grouped by owning rank
-        part, cuts = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, parallel.FINE_BITS)
-        del packed, offsets, out_offsets
+        ends = ops.kmer_start_mask(offsets, n, n_bases, k)
+        del offsets, out_offsets
+        part, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, parallel.FINE_BITS)
+        del packed, ends
         return parallel.count_sparse_distributed(part, key_bits, group, cuts=cuts), stats
     if fused:                                                                                         # A8 + A9 sparse
         levels = ops.radix_plan(n_kmers, key_bits)
         if levels:
-            hashes, cuts = ops.kmers_partitioned(packed, offsets, out_offsets, n, n_kmers, k, levels[0])
-            del packed, offsets, out_offsets
+            ends = ops.kmer_start_mask(offsets, n, n_bases, k)
+            del offsets, out_offsets
+            hashes, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, levels[0])
+            del packed, ends
             return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0])), stats
     hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
     del packed, offsets, out_offsets

@@ -148,14 +148,20 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
                const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
                int64_t* d_hashes, void* stream);
 
-/* Same hashes, but never materialised in row order: written exactly once, already partitioned (not
+/* One bit per base of the flat packed stream, set where a k-mer starts: bits [offsets[r], offsets[r+1]-(k-1)) of
+ * every row with at least k bases (d_mask needs total/64 + 2 words) — the ragged trim `ragged[..., :-(k-1)]`
+ * (bionumpy/sequence/kmers.py:100) as a mask, so that the fused generator below needs no row lookup. */
+int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t total, int k,
+                         uint64_t* d_mask, void* stream);
+
+/* Same hashes as bnpk_kmers, but never materialised in row order: written exactly once, already partitioned (not
  * stably) by the `bits`-bit digit at bit `shift` (bits <= bnpk_radix_max_bits()) — level 1 of the MSD radix
  * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the
  * np.unique of SURVEY §3.5).  The multiset of values equals bnpk_kmers'; d_child_offsets (2^bits + 1 entries,
- * optional) receives the bucket boundaries. */
-int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
-                         const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k, int shift, int bits,
-                         int64_t* d_out, int64_t* d_child_offsets, void* stream);
+ * optional) receives the bucket boundaries, its last entry the number of k-mers.  d_out needs one entry per
+ * k-mer (bnpk_row_offsets(lens, window=k) total). */
+int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_kmer_starts, int64_t n_bases, int k,
+                         int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
 
 /* ---- A11: minimizers -----------------------------------------------------------------------------
  * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every

@@ -51,8 +51,22 @@ class OracleOps:
         from bionumpy_amd.ops import HipOps
         return HipOps.radix_plan(n, key_bits, done)
 
-    def kmers_partitioned(self, packed, in_offsets, out_offsets, n_rows, n_out, k, bits):
-        h = self.kmers(packed, in_offsets, out_offsets, n_rows, n_out, k).host()
+    def kmer_start_mask(self, offsets, n_rows, total, k):
+        off = offsets.host()
+        bits = np.zeros((total // 64 + 2) * 64, dtype=np.uint8)
+        for s, e in zip(off[:-1], off[1:]):
+            if e - (k - 1) > s:
+                bits[s:e - (k - 1)] = 1
+        return _h(np.packbits(bits, bitorder="little").view(np.int64))
+
+    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits):
+        flags = np.unpackbits(starts_mask.host().view(np.uint8), bitorder="little")[:n_bases]
+        pos = np.flatnonzero(flags)
+        codes = _unpack(packed, n_bases).astype(np.int64)
+        h = np.zeros(pos.size, dtype=np.int64)
+        for j in range(k):
+            h |= codes[pos + j] << (2 * j)
+        assert h.size == n_out
         digit = h >> (2 * k - bits)
         order = np.argsort(digit, kind="stable")
         cuts = np.searchsorted(digit[order], np.arange((1 << bits) + 1)).astype(np.int64)

@@ -192,10 +192,18 @@ def test_fused_kmer_partition(ops, seed, n_rows, max_len, k):
     _, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total)
     out_off, n_out = ops.row_offsets(_h(lengths), k)
     plain = ops.kmers(packed, offsets, out_off, n_rows, n_out, k).host()
-    for bits in (0, 1, 5, 8, 10):
+    ends = ops.kmer_start_mask(offsets, n_rows, total, k)
+    flags = np.unpackbits(ends.host().view(np.uint8), bitorder="little")
+    expect = np.zeros(flags.size, dtype=np.uint8)
+    row_start = np.cumsum(lengths) - lengths
+    for s0, ln in zip(row_start, lengths):
+        if ln >= k:
+            expect[s0:s0 + ln - k + 1] = 1
+    assert np.array_equal(flags, expect)
+    for bits in (0, 1, 5, 8, 10, 11):
         if bits > 2 * k:
             continue
-        part, cuts = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, bits)
+        part, cuts = ops.kmers_partitioned(packed, ends, total, n_out, k, bits)
         part, cuts = part.host(), cuts.host()
         digits = part >> (2 * k - bits)
         assert np.all(np.diff(digits) >= 0)
@@ -206,7 +214,7 @@ def test_fused_kmer_partition(ops, seed, n_rows, max_len, k):
         codes = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
         ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lengths, k)[0])
         for bits in (3, 10):
-            hashes, cuts = ops.kmers_partitioned(packed, offsets, out_off, n_rows, n_out, k, bits)
+            hashes, cuts = ops.kmers_partitioned(packed, ends, total, n_out, k, bits)
             keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True, partition=(cuts, bits))
             assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
 
