@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the whole hot path (newline scan + validation, field table, ragged gather + 2-bit
-encode, 31-mer hashes, sort + run-length histogram; for N > 1 plus the key-range all-to-all over RCCL)
+encode, 31-mer hashes generated straight into an MSD radix partition, in-LDS finishing sort + run-length
+histogram; for N > 1 plus the key-range all-to-all over RCCL)
 over one HBM-resident batch of synthetic FASTQ: ``--reads`` reads of ``--read-len`` bp PER GPU (weak
 scaling; default 50 M x 150 bp = BASELINE config 2, 15.8 GB of text, 7.5 Gbases, 6.0 G 31-mers per GPU).
 The input is generated on the device before the timed region; nothing is cached between steps.
@@ -30,8 +31,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
 
 # algorithmic HBM bytes per launch of each kernel, as a function of the batch
-def algorithmic_bytes(name, s, read_len, k):
+def algorithmic_bytes(name, s, read_len, k, n_distinct=None):
     n, bases, kmers, text = s.n_reads, s.n_bases, s.n_kmers, s.n_bytes
+    distinct = kmers if n_distinct is None else n_distinct
     return {
         "byte_census": text,                                  # read the text once
         "byte_positions": text + 8 * 4 * n,                   # read it again, write 4 newline offsets/read
@@ -39,16 +41,16 @@ def algorithmic_bytes(name, s, read_len, k):
         "field_table": 2 * 8 * n + 2 * 8 * n,                 # two offsets in, start+len out
         "row_offsets": 8 * n + 8 * n,                         # lens in, offsets out
         "gather_encode_dna": bases + 16 * n + bases / 4,      # sequence bytes + start/offset + packed out
+        "kmer_start_mask": 8 * n + bases / 8,                 # offsets in, one bit per base out
         "kmers": bases / 4 + 16 * n + 8 * kmers,              # packed in, offsets, 8 B per k-mer out
-        "kmers_partition_hist": bases / 4 + 16 * n,           # packed reads + offsets in, 256 counters/slab out
-        "kmers_partition_scatter": bases / 4 + 16 * n + 8 * kmers,   # same input, every hash written once
-        "sort_keys": 16 * kmers,                              # read every key once, write it once sorted
-        "partition_keys": 16 * kmers,
-        "finish_small_count": 8 * kmers,                      # read the bucket-sorted keys
-        "finish_small_write": 8 * kmers + 16 * kmers,         # read them again, write key + count (all distinct)
-        "finish_buckets": 8 * kmers + 16 * kmers,
-        "run_census": 8 * kmers,                              # read sorted keys
-        "run_heads": 8 * kmers + 16 * kmers,                  # read keys, write key + run start (all distinct)
+        "kmers_partition_hist": bases / 4 + bases / 8,        # packed reads + start mask in, digit counts out
+        "kmers_partition_scatter": bases / 4 + bases / 8 + 8 * kmers,   # same input, every hash written once
+        "radix_hist": 8 * kmers,                              # read every key
+        "radix_scatter": 16 * kmers,                          # read every key, write it to its bucket
+        "finish_sorted": 8 * kmers + 16 * distinct,           # read the bucketed keys, write key + count per distinct key
+        "sort_keys": 16 * kmers,                              # (fallback path) read every key once, write it once sorted
+        "run_census": 8 * kmers,
+        "run_heads": 8 * kmers + 16 * kmers,
         "run_sums": 16 * kmers,
         "count_dense_lds": 8 * kmers,
         "count_dense_global": 8 * kmers,
@@ -183,13 +185,13 @@ def main():
     kernels = {}
     for name, p in prof.items():
         avg_ms = p["total_ms"] / max(p["launches"], 1)
-        b = algorithmic_bytes(name, stats, args.read_len, args.k)
+        b = algorithmic_bytes(name, stats, args.read_len, args.k, n_distinct)
         kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
                          "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
     if dom is not None:
         p = prof[dom]
         avg_ms = p["total_ms"] / max(p["launches"], 1)
-        b = algorithmic_bytes(dom, stats, args.read_len, args.k)
+        b = algorithmic_bytes(dom, stats, args.read_len, args.k, n_distinct)
         achieved = b / (avg_ms * 1e-3) / 1e9 if b else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",

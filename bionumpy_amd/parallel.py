@@ -88,5 +88,9 @@ def exchange_by_key_range(hashes, key_bits, group=None, cuts=None):
 def count_sparse_distributed(hashes, key_bits, group=None, cuts=None):
     """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range"""
     ops = get_ops()
+    if isinstance(hashes, list):              # [HArray]: the caller gave its only reference away
+        held = hashes
+        hashes = held.pop()
     mine, key_range = exchange_by_key_range(hashes, key_bits, group, cuts)
+    del hashes
     return ops.count_sparse(mine, key_bits=key_bits, consume=True, key_range=key_range)

@@ -56,7 +56,9 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
         del offsets, out_offsets
         part, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, parallel.FINE_BITS)
         del packed, ends
-        return parallel.count_sparse_distributed(part, key_bits, group, cuts=cuts), stats
+        holder = [part]                       # hand the 8 B/k-mer buffer over: it is freed right after the exchange
+        del part
+        return parallel.count_sparse_distributed(holder, key_bits, group, cuts=cuts), stats
     if fused:                                                                                         # A8 + A9 sparse
         levels = ops.radix_plan(n_kmers, key_bits)
         if levels:

@@ -22,7 +22,11 @@ def _short(name):
         return "rocprim::" + name[-50:]
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = name.split("(")[0]
-    for key in ("byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
+    if "rp_scatter_kernel" in name or "rp_hist_kernel" in name:
+        kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
+        src = "kmer_source" if "kmer_source" in name else "mem_source"
+        return "%s<%s>" % (kind, src)
+    for key in ("finish_sorted", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
                 "gather_encode", "kmer_kernel", "run_census", "run_heads", "run_sums", "synth_fastq", "fill_kernel",
                 "hist_lds", "hist_global", "finish_runs", "partition_scatter", "partition_hist"):
         if key in name:
