@@ -541,15 +541,16 @@ struct fn_bucket {
   bool over;
 };
 
-__device__ __forceinline__ fn_bucket fn_open(const int64_t* __restrict__ bucket_off, int64_t n_buckets, int64_t b) {
+// bucket b from its two offsets (loaded one iteration earlier, so nothing waits on them here)
+__device__ __forceinline__ fn_bucket fn_open(int64_t n_buckets, int64_t b, int64_t lo, int64_t hi) {
   fn_bucket x;
   x.b = b;
   x.lo = 0;
   x.nb = 0;
   x.over = false;
   if (b < n_buckets) {
-    x.lo = bucket_off[b];
-    const int64_t m = bucket_off[b + 1] - x.lo;
+    x.lo = lo;
+    const int64_t m = hi - lo;
     x.over = m > FN_CAP;
     x.nb = x.over ? 0 : (int)m;
   }
@@ -631,16 +632,24 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 
   for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
   if (tid < FN_WORDS) fmask[tid] = 0;
-  if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
+  // Software pipeline over tickets: `cur` is sorted while the keys of `nxt` are in flight and the offsets of the
+  // bucket after that (ticket nn_b) are being loaded.
+  if (tid == 0) { sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull); sh[2] = (long long)atomicAdd(&state[FS_TICKET], 1ull); }
   __syncthreads();
-  fn_bucket nxt = fn_open(bucket_off, n_buckets, sh[0]);
+  int64_t nn_b = sh[2], nn_lo = 0, nn_hi = 0;
+  fn_bucket nxt;
+  {
+    const int64_t b0 = sh[0];
+    nxt = fn_open(n_buckets, b0, b0 < n_buckets ? bucket_off[b0] : 0, b0 < n_buckets ? bucket_off[b0 + 1] : 0);
+  }
+  if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
   uint64_t kn[FN_ITEMS];
 #pragma unroll
   for (int q = 0; q < FN_ITEMS; ++q) {
     const int i = tid + q * FN_THREADS;
     if (i < nxt.nb) kn[q] = A[nxt.lo + i];
   }
-  __syncthreads();                                    // everybody has read sh[0]
+  __syncthreads();                                    // everybody has read sh[0], sh[2]
 
   while (nxt.b < n_buckets) {
     const fn_bucket cur = nxt;
@@ -663,13 +672,16 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       }
     }
     __syncthreads();
-    // prefetch the next bucket while this one is sorted
-    nxt = fn_open(bucket_off, n_buckets, sh[0]);
+    // prefetch the next bucket's keys (its offsets arrived during the previous bucket) and the offsets of the
+    // bucket after it
+    nxt = fn_open(n_buckets, nn_b, nn_lo, nn_hi);
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
       const int i = tid + q * FN_THREADS;
       if (i < nxt.nb) kn[q] = A[nxt.lo + i];
     }
+    nn_b = sh[0];
+    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
     if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
       if (wave == 0) look_back(cur.b, 0u);
       __syncthreads();

@@ -282,6 +282,19 @@ class HipOps:
                 n_seg <<= bits
             if offsets is None:
                 offsets = self.device.upload(np.array([0, n], dtype=np.int64))
+            # the plan assumes well-spread keys; real bucket sizes decide: a bucket over the finishing kernel's
+            # capacity gets (at most two) extra levels sized from the largest bucket
+            cap = int(lib.bnpk_finish_capacity())
+            for _ in range(2):
+                largest = int((offsets[1:] - offsets[:-1]).max().item())
+                bits = min(11, key_bits - skip - done, max(1, (2 * largest // cap).bit_length()))
+                if largest <= cap or bits <= 0:
+                    break
+                out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
+                spare = cur if owned else None
+                cur, owned = out, True
+                done += bits
+                n_seg <<= bits
             keys_out = spare if spare is not None else self._empty(n, np.int64)
             counts = self._empty(n, np.int64)
             state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
