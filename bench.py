@@ -35,6 +35,9 @@ def algorithmic_bytes(name, s, read_len, k, n_distinct=None):
     n, bases, kmers, text = s.n_reads, s.n_bases, s.n_kmers, s.n_bytes
     distinct = kmers if n_distinct is None else n_distinct
     return {
+        "fastq_census": text,                                 # fused decode, pass 1: read the text once
+        "fastq_encode": text + bases / 4 + bases / 8,         # pass 2: read it again, write packed bases + read-end mask
+        "kmer_starts_from_ends": bases / 8 + bases / 8,       # read-end mask in, k-mer start mask out
         "byte_census": text,                                  # read the text once
         "byte_positions": text + 8 * 4 * n,                   # read it again, write 4 newline offsets/read
         "validate_entries": 2 * 8 * n + 2 * n,                # two offsets + two probe bytes per read

@@ -58,6 +58,11 @@ SIGNATURES = {
     "bnpk_byte_positions": (_int, [_p, _p, _i64, _u8, _p, _i64, _p, _p]),
     "bnpk_validate_entries": (_int, [_p, _p, _p, _i64, _int, _u8, _int, _p, _p]),
     "bnpk_field_table": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
+    "bnpk_fastq_tiles": (_i64, [_i64]),
+    "bnpk_fastq_table_words": (_i64, [_i64]),
+    "bnpk_fastq_census": (_int, [_p, _p, _i64, _int, _int, _p, C.POINTER(_i64), _p]),
+    "bnpk_fastq_encode": (_int, [_p, _p, _i64, _int, _int, _u8, _int, _p, _i64, _i64, _p, _p, _p, _p]),
+    "bnpk_kmer_starts_from_ends": (_int, [_p, _p, _i64, _int, _p, _p, _p]),
     "bnpk_row_offsets": (_int, [_p, _p, _i64, _int, _p, _p]),
     "bnpk_gather_encode_dna": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "bnpk_gather_rows": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),

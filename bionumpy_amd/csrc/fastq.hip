@@ -1,0 +1,543 @@
+// Fused FASTQ / two-line-FASTA decode for the k-mer pipeline (A2-A7 in one read of the text after a census):
+// newline scan, entry validation, sequence-line extraction and ASCII -> 2-bit packing without ever materialising
+// the newline table, the field tables or the row offsets.
+//
+//   census  (reads the text once)  per 16 KiB tile: newline count + the number of payload bytes on the lines of
+//           each phase (line index mod lines_per_entry, relative to the tile's first line); after a scan of the
+//           newline counts every tile knows its absolute first line, picks "its" sequence-byte count and a second
+//           scan gives every tile the flat base index its sequence bytes start at
+//   encode  (reads the text once)  per tile: classify every byte by the phase of its line, rank the sequence
+//           bytes (wave scans), validate the first byte of header / '+' lines, 2-bit encode into an LDS staging
+//           area aligned like the global packed words, mark read ends in a bit mask, write both out (interior
+//           words with plain stores, the two edge words shared with the neighbouring tiles with atomicOr)
+//   starts  bit-parallel pass over the read-end mask: a k-mer starts at base i iff no read ends in [i, i+k-2]
+//
+// Equivalent reference expressions: OneLineBuffer.from_raw_buffer + _validate (io/one_line_buffer.py:45-71,156-173,
+// io/fastq_buffer.py:39-45), _get_buffer_extractor + get_field_by_number(1) (io/one_line_buffer.py:140-152,
+// io/file_buffers.py:315-338), EncodedRaggedArray.ravel() + AlphabetEncoding._encode (encodings/alphabet_encoding.py:19-46),
+// BitArray.pack (sequence/kmers.py:121) and the ragged trim [..., :-(k-1)] (sequence/kmers.py:100).
+#include <algorithm>
+
+#include "common.h"
+#include "scan.h"
+
+namespace {
+
+constexpr int FQ_VEC = 16;                                   // bytes per lane per load
+constexpr int FQ_WAVE_BYTES = BNPK_WAVE * FQ_VEC;            // 1 KiB per wavefront-instruction
+constexpr int FQ_ITERS = 4;
+constexpr int FQ_WAVES = BNPK_BLOCK / BNPK_WAVE;
+constexpr int FQ_TILE = FQ_WAVES * FQ_ITERS * FQ_WAVE_BYTES; // 16 KiB per workgroup
+constexpr int FQ_MAXLPE = 4;
+constexpr int FQ_TREC = 1 + FQ_MAXLPE;                       // per-tile census record: first line, payload bytes per phase
+constexpr uint8_t FQ_NL = 10, FQ_CR = 13;
+
+__device__ __forceinline__ uint32_t fq_match4(uint32_t w, uint32_t rep) {       // high bit of every matching byte
+  uint32_t x = w ^ rep;
+  uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+  return ~(t | x | 0x7f7f7f7fu);
+}
+__device__ __forceinline__ uint32_t fq_mask16(uint64_t lo, uint64_t hi, uint32_t rep) {   // bit j = byte j matches
+  const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t h = fq_match4(w[q], rep);
+    uint32_t b = ((h >> 7) & 1u) | ((h >> 14) & 2u) | ((h >> 21) & 4u) | ((h >> 28) & 8u);
+    m |= b << (4 * q);
+  }
+  return m;
+}
+
+// one 16-byte chunk of the tile: raw bytes, newline mask, mask of the bytes that are not payload (newlines and,
+// when CRs are stripped, the CR right before a newline), number of valid bytes
+struct fq_chunk {
+  uint64_t lo, hi;                                           // bytes 0-7, 8-15 (no arrays: runtime byte indices must not
+  uint32_t nl, skip, valid;                                  // push the chunk into scratch memory)
+};
+
+__device__ __forceinline__ int64_t fq_chunk_pos(int64_t tile_base, int it) {
+  return tile_base + (int64_t)wave_id() * (FQ_ITERS * FQ_WAVE_BYTES) + (int64_t)it * FQ_WAVE_BYTES + lane_id() * FQ_VEC;
+}
+
+__device__ __forceinline__ fq_chunk fq_load(const uint8_t* __restrict__ buf, int64_t pos, int64_t n, int strip_cr) {
+  fq_chunk c;
+  c.lo = c.hi = 0;
+  c.nl = c.skip = 0;
+  c.valid = 0;
+  if (pos >= n) return c;
+  if (pos + FQ_VEC <= n) {
+    uint4 v = *reinterpret_cast<const uint4*>(buf + pos);
+    c.lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
+    c.hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    c.valid = 0xffffu;
+  } else {
+    for (int j = 0; pos + j < n; ++j) {
+      const uint64_t b = (uint64_t)buf[pos + j] << (8 * (j & 7));
+      if (j < 8) c.lo |= b; else c.hi |= b;
+      c.valid |= 1u << j;
+    }
+  }
+  c.nl = fq_mask16(c.lo, c.hi, 0x01010101u * FQ_NL) & c.valid;
+  c.skip = c.nl;
+  if (strip_cr) {
+    const uint32_t cr = fq_mask16(c.lo, c.hi, 0x01010101u * FQ_CR) & c.valid;
+    uint32_t before_nl = cr & (c.nl >> 1);
+    if ((cr >> 15) & 1u) {                                   // CR in the last byte: is the next byte a newline?
+      if (pos + FQ_VEC < n && buf[pos + FQ_VEC] == FQ_NL) before_nl |= 1u << 15;
+    }
+    c.skip |= before_nl;
+  }
+  return c;
+}
+
+__device__ __forceinline__ uint32_t fq_byte(const fq_chunk& c, int j) {
+  return (uint32_t)((j < 8 ? c.lo : c.hi) >> (8 * (j & 7))) & 0xffu;
+}
+
+// Exclusive prefix, in tile byte order (wave, iteration, lane), of one value per chunk; `smem` needs FQ_WAVES ints.
+// Returns the tile total through *total.
+__device__ __forceinline__ void fq_tile_prefix(const int v[FQ_ITERS], int ex[FQ_ITERS], int* smem, int* total) {
+  int run = 0;
+  int inc[FQ_ITERS];
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    inc[it] = wave_inclusive_scan(v[it]);
+    ex[it] = run + inc[it] - v[it];
+    run += __builtin_amdgcn_readlane(inc[it], 63);
+  }
+  __syncthreads();                                           // smem may still be read from a previous call
+  if (lane_id() == 0) smem[wave_id()] = run;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < FQ_WAVES; ++w) {
+    const int x = smem[w];
+    if (w < wave_id()) base += x;
+    tot += x;
+  }
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) ex[it] += base;
+  *total = tot;
+}
+
+// payload bytes of the chunk per line phase; `line` = tile-relative index of the chunk's first line
+__device__ __forceinline__ void fq_count_phases(const fq_chunk& c, int line, int lpe, int cnt[FQ_MAXLPE]) {
+  uint32_t nl = c.nl, todo = c.valid & ~c.skip;
+  int ph = line % lpe;
+  while (true) {
+    const uint32_t upto = nl ? ((1u << (__ffs(nl) - 1)) - 1u) : 0xffffu;     // bytes before the next newline
+    const int m = __popc(todo & upto);
+#pragma unroll
+    for (int p = 0; p < FQ_MAXLPE; ++p) cnt[p] += (p == ph) ? m : 0;
+    if (!nl) break;
+    todo &= ~upto;
+    nl &= nl - 1;
+    ph = (ph + 1 == lpe) ? 0 : ph + 1;
+  }
+}
+
+// ---- census --------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BNPK_BLOCK) void fq_census_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
+                                                               const int64_t* __restrict__ flags,
+                                                               int64_t* __restrict__ recs,
+                                                               int64_t* __restrict__ newlines) {
+  __shared__ int smem[FQ_WAVES];
+  __shared__ int acc[FQ_MAXLPE];
+  const int strip_cr = (int)flags[0];
+  const int64_t tile_base = (int64_t)blockIdx.x * FQ_TILE;
+  if (threadIdx.x < FQ_MAXLPE) acc[threadIdx.x] = 0;
+  fq_chunk c[FQ_ITERS];
+  int nls[FQ_ITERS], line[FQ_ITERS], total;
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    c[it] = fq_load(buf, fq_chunk_pos(tile_base, it), n, strip_cr);
+    nls[it] = __popc(c[it].nl);
+  }
+  fq_tile_prefix(nls, line, smem, &total);
+  int cnt[FQ_MAXLPE] = {0, 0, 0, 0};
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) fq_count_phases(c[it], line[it], lpe, cnt);
+#pragma unroll
+  for (int p = 0; p < FQ_MAXLPE; ++p) {
+    const int s = (int)wave_sum((unsigned)cnt[p]);
+    if (lane_id() == 0 && s) atomicAdd(&acc[p], s);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t* r = recs + (int64_t)blockIdx.x * FQ_TREC;
+    newlines[blockIdx.x] = total;
+#pragma unroll
+    for (int p = 0; p < FQ_MAXLPE; ++p) r[1 + p] = acc[p];
+  }
+}
+
+// does one of the first lpe entries' header lines end in CR? (_modify_for_carriage_return, one_line_buffer.py:176-182)
+// One wavefront walks the text 64 bytes at a time until it has seen (lpe-1)*lpe + 1 line ends.
+__global__ void fq_detect_cr_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe, int64_t* __restrict__ flags) {
+  const int lane = threadIdx.x;
+  int64_t line = 0;
+  const int64_t last_line = (int64_t)(lpe - 1) * lpe;
+  bool found = false;
+  uint32_t prev_last = 0;                                    // byte before the current 64-byte window
+  for (int64_t base = 0; base < n && line <= last_line && !found; base += 64) {
+    const int64_t i = base + lane;
+    const uint32_t b = i < n ? buf[i] : 0;
+    uint32_t prev = __shfl_up(b, 1, 64);
+    if (lane == 0) prev = prev_last;
+    uint64_t nlm = __ballot(b == FQ_NL);
+    const uint64_t crm = __ballot(b == FQ_NL && prev == FQ_CR);
+    while (nlm && line <= last_line) {
+      const int j = __ffsll((long long)nlm) - 1;
+      if (line % lpe == 0 && ((crm >> j) & 1ull)) found = true;
+      nlm &= nlm - 1;
+      ++line;
+    }
+    prev_last = __shfl(b, 63, 64);
+  }
+  if (lane == 0) flags[0] = found ? 1 : 0;
+}
+
+// after the scan of the newline counts: absolute first line of every tile, number of lines that take part
+// (a multiple of lpe), the tile's sequence-byte count
+__global__ void fq_select_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe, int seq_line, int64_t n_tiles,
+                                 const int64_t* __restrict__ line_base, const int64_t* __restrict__ flags,
+                                 int64_t* __restrict__ recs, int64_t* __restrict__ seq_count,
+                                 int64_t* __restrict__ totals) {
+  const int64_t n_newlines = line_base[n_tiles];
+  const int64_t used = n_newlines - n_newlines % lpe;
+  const int strip_cr = (int)flags[0];
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; t < n_tiles; t += stride) {
+    int64_t* r = recs + t * FQ_TREC;
+    const int64_t g = line_base[t];                          // line index of the tile's first byte
+    r[0] = g;
+    int64_t seq = 0;
+    if (line_base[t + 1] < used) {                           // every line touching the tile takes part
+      const int ph = (int)(((seq_line - g) % lpe + lpe) % lpe);
+      seq = r[1 + ph];
+    } else if (g < used) {                                   // the tile holds the end of the last entry: recount
+      int64_t line = g;
+      const int64_t end = min((t + 1) * (int64_t)FQ_TILE, n);
+      for (int64_t i = t * (int64_t)FQ_TILE; i < end && line < used; ++i) {
+        const uint8_t b = buf[i];
+        if (b == FQ_NL) { ++line; continue; }
+        if (line % lpe != seq_line) continue;
+        if (strip_cr && b == FQ_CR && i + 1 < n && buf[i + 1] == FQ_NL) continue;
+        ++seq;
+      }
+    }
+    seq_count[t] = seq;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    totals[0] = n_newlines;
+    totals[1] = used;
+  }
+}
+
+// ---- encode --------------------------------------------------------------------------------------------------------
+constexpr int FQ_SWORDS = (FQ_TILE + 64) / 16;               // staged 2-bit codes (32-bit words), aligned like the packed words
+constexpr int FQ_EWORDS = (FQ_TILE + 128) / 32;              // read-end bits (32-bit words), aligned like the mask words
+
+constexpr uint64_t FQ_REP01 = 0x0101010101010101ull, FQ_REP7F = 0x7f7f7f7f7f7f7f7full, FQ_REP80 = 0x8080808080808080ull;
+__device__ __forceinline__ uint64_t fq_eq_bytes(uint64_t x, uint64_t rep) {     // 0x80 in every byte equal to rep's
+  const uint64_t z = x ^ rep;
+  const uint64_t t = (z & FQ_REP7F) + FQ_REP7F;
+  return ~(t | z | FQ_REP7F);
+}
+// eight bytes -> sixteen bits of 2-bit codes (A C G T / a c g t -> 0 1 2 3) + a bit per byte that is none of them
+__device__ __forceinline__ uint32_t fq_codes8(uint64_t x, uint32_t* invalid) {
+  const uint64_t u = x & (0xDFull * FQ_REP01);               // fold lower case onto upper case (exact for A C G T)
+  const uint64_t ok = fq_eq_bytes(u, 'A' * FQ_REP01) | fq_eq_bytes(u, 'C' * FQ_REP01) | fq_eq_bytes(u, 'G' * FQ_REP01) |
+                      fq_eq_bytes(u, 'T' * FQ_REP01);
+  uint64_t bad = (~ok & FQ_REP80) >> 7;                      // one bit per byte, at bit 8j
+  bad = (bad | (bad >> 7)) & 0x0003000300030003ull;
+  bad = (bad | (bad >> 14)) & 0x0000000F0000000Full;
+  *invalid = (uint32_t)((bad | (bad >> 28)) & 0xFFull);
+  uint64_t c = ((u >> 1) & (3ull * FQ_REP01)) ^ ((u >> 2) & FQ_REP01);
+  c = (c | (c >> 6)) & 0x000F000F000F000Full;
+  c = (c | (c >> 12)) & 0x000000FF000000FFull;
+  return (uint32_t)((c | (c >> 24)) & 0xFFFFull);
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
+                                                               int seq_line, uint8_t header, int check_plus,
+                                                               const int64_t* __restrict__ flags,
+                                                               const int64_t* __restrict__ recs,
+                                                               const int64_t* __restrict__ seq_base, int64_t used,
+                                                               unsigned long long* __restrict__ packed,
+                                                               unsigned long long* __restrict__ ends,
+                                                               unsigned long long* __restrict__ err) {
+  __shared__ __attribute__((aligned(16))) unsigned stage[FQ_SWORDS];
+  __shared__ unsigned ebits[FQ_EWORDS];
+  __shared__ int smem[FQ_WAVES];
+  const int strip_cr = (int)flags[0];
+  const int tid = threadIdx.x;
+  const int64_t tile_base = (int64_t)blockIdx.x * FQ_TILE;
+  const int64_t g0 = recs[(int64_t)blockIdx.x * FQ_TREC];              // absolute line of the tile's first byte
+  const int64_t fbase = seq_base[blockIdx.x];                          // flat base index of the tile's first sequence byte
+  const int S = (int)(seq_base[blockIdx.x + 1] - fbase);               // sequence bytes of the tile
+  const int off32 = (int)(fbase & 31), off64 = (int)(fbase & 63);
+  for (int i = tid; i < FQ_SWORDS; i += BNPK_BLOCK) stage[i] = 0;
+  for (int i = tid; i < FQ_EWORDS; i += BNPK_BLOCK) ebits[i] = 0;
+  if (blockIdx.x == 0 && tid == 0 && n > 0 && used > 0 && buf[0] != header) atomicMin(&err[0], 0ull);
+
+  fq_chunk c[FQ_ITERS];
+  int nls[FQ_ITERS], line[FQ_ITERS], total;
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    c[it] = fq_load(buf, fq_chunk_pos(tile_base, it), n, strip_cr);
+    nls[it] = __popc(c[it].nl);
+  }
+  fq_tile_prefix(nls, line, smem, &total);                   // (also orders the LDS clears above before the writes below)
+  // the two bytes that follow every chunk: from the next lane, the next iteration's lane 0, or (last chunk of the
+  // wavefront) from memory
+  uint32_t follow[FQ_ITERS];
+  {
+    const int64_t wave_end = tile_base + (int64_t)(wave_id() + 1) * (FQ_ITERS * FQ_WAVE_BYTES);
+    uint32_t tail = 0;
+    if (wave_end < n) tail = buf[wave_end];
+    if (wave_end + 1 < n) tail |= (uint32_t)buf[wave_end + 1] << 8;
+#pragma unroll
+    for (int it = FQ_ITERS - 1; it >= 0; --it) {
+      const uint32_t mine = (uint32_t)c[it].lo & 0xffffu;
+      uint32_t nxt = __shfl_down(mine, 1, 64);
+      const uint32_t wrap = it + 1 < FQ_ITERS ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)c[it + 1 < FQ_ITERS ? it + 1 : it].lo & 0xffffu)) : tail;
+      if (lane_id() == 63) nxt = wrap;
+      follow[it] = nxt;
+    }
+  }
+  // sequence bytes per chunk -> rank of every chunk's first sequence byte inside the tile
+  uint32_t seqbits[FQ_ITERS];
+  int nseq[FQ_ITERS], rank[FQ_ITERS];
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    uint32_t nl = c[it].nl, todo = c[it].valid & ~c[it].skip, bits = 0;
+    int64_t ln = g0 + line[it];
+    while (true) {
+      const uint32_t upto = nl ? ((1u << (__ffs(nl) - 1)) - 1u) : 0xffffu;
+      if (ln < used && ln % lpe == seq_line) bits |= todo & upto;
+      if (!nl) break;
+      todo &= ~upto;
+      nl &= nl - 1;
+      ++ln;
+    }
+    seqbits[it] = bits;
+    nseq[it] = __popc(bits);
+  }
+  int tot_seq;
+  fq_tile_prefix(nseq, rank, smem, &tot_seq);
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    const int64_t pos = fq_chunk_pos(tile_base, it);
+    // 2-bit codes of the sequence bytes -> staging area; a base followed by a line end (newline, or CR + newline
+    // when CRs are stripped) is the last base of its read
+    uint32_t bits = seqbits[it];
+    uint32_t endbits = bits & (c[it].skip >> 1);
+    if ((bits >> 15) & 1u) {
+      const uint32_t b16 = pos + 16 < n ? (follow[it] & 0xffu) : 0u, b17 = pos + 17 < n ? (follow[it] >> 8) : 0u;
+      if (b16 == FQ_NL || (strip_cr && b16 == FQ_CR && b17 == FQ_NL)) endbits |= 1u << 15;
+    }
+    // all sixteen codes at once; the sequence bytes of a chunk form (at most a few) contiguous runs, each of which
+    // is OR-ed into the staging words at its rank
+    uint32_t inv_lo, inv_hi;
+    const uint32_t codes = fq_codes8(c[it].lo, &inv_lo) | (fq_codes8(c[it].hi, &inv_hi) << 16);
+    const uint32_t invalid = (inv_lo | (inv_hi << 8)) & bits;
+    if (invalid) {
+      const int j = __ffs(invalid) - 1;
+      const unsigned long long at = (unsigned long long)(fbase + rank[it] + __popc(bits & ((1u << j) - 1u)));
+      if (at < bad) bad = at;
+    }
+    int r = rank[it];
+    uint32_t runs = bits;
+    while (runs) {
+      const int a = __ffs(runs) - 1;
+      const int len = __ffs(~(runs >> a)) - 1;               // run of set bits starting at a (runs has 16 significant bits)
+      const uint32_t m = len >= 16 ? ~0u : ((1u << (2 * len)) - 1u);
+      uint32_t v = (codes >> (2 * a)) & m;
+      const int bitpos = 2 * (off32 + r);
+      const int sh = bitpos & 31;
+      atomicOr(&stage[bitpos >> 5], v << sh);
+      if (sh + 2 * len > 32) atomicOr(&stage[(bitpos >> 5) + 1], v >> (32 - sh));
+      r += len;
+      runs &= ~(((len >= 16 ? 0xffffu : ((1u << len) - 1u))) << a);
+    }
+    uint32_t eb = endbits;
+    while (eb) {
+      const int j = __ffs(eb) - 1;
+      eb &= eb - 1;
+      const int e = off64 + rank[it] + __popc(bits & ((1u << j) - 1u));
+      atomicOr(&ebits[e >> 5], 1u << (e & 31));
+    }
+    // line ends: validation of the byte that starts the next line
+    uint32_t nl = c[it].nl;
+    int64_t ln = g0 + line[it];
+    while (nl) {
+      const int j = __ffs(nl) - 1;
+      nl &= nl - 1;
+      const int64_t next_line = ln + 1;
+      if (next_line < used) {
+        const int ph = (int)(next_line % lpe);
+        if (ph == 0 || (check_plus && ph == 2)) {
+          const uint32_t b = j < 15 ? fq_byte(c[it], j + 1) : (pos + 16 < n ? (follow[it] & 0xffu) : 0u);
+          if (ph == 0 && b != header) atomicMin(&err[0], (unsigned long long)(next_line / lpe));
+          if (ph == 2 && b != '+') atomicMin(&err[1], (unsigned long long)(next_line / lpe));
+        }
+      }
+      ++ln;
+    }
+  }
+  if (bad != (unsigned long long)BNPK_NONE) atomicMin(&err[2], bad);
+  __syncthreads();
+  // packed words: 64-bit word w of the tile = staged 32-bit words 2w, 2w + 1
+  const int n_words = (off32 + S + 31) / 32;
+  const int64_t word0 = fbase >> 5;
+  for (int w = tid; w < n_words; w += BNPK_BLOCK) {
+    const unsigned long long word = (unsigned long long)stage[2 * w] | ((unsigned long long)stage[2 * w + 1] << 32);
+    const bool edge = (w == 0 && off32 != 0) || (w == n_words - 1 && ((off32 + S) & 31) != 0);
+    if (edge) { if (word) atomicOr(&packed[word0 + w], word); }
+    else packed[word0 + w] = word;
+  }
+  const int n_ew = (off64 + S + 63) / 64;
+  const int64_t eword0 = fbase >> 6;
+  for (int w = tid; w < n_ew; w += BNPK_BLOCK) {
+    const unsigned long long word = (unsigned long long)ebits[2 * w] | ((unsigned long long)ebits[2 * w + 1] << 32);
+    const bool edge = (w == 0 && off64 != 0) || (w == n_ew - 1 && ((off64 + S) & 63) != 0);
+    if (edge) { if (word) atomicOr(&ends[eword0 + w], word); }
+    else ends[eword0 + w] = word;
+  }
+}
+
+// ---- k-mer start mask from the read-end mask --------------------------------------------------------------------------
+__global__ __launch_bounds__(BNPK_BLOCK) void fq_starts_kernel(const unsigned long long* __restrict__ ends,
+                                                               int64_t n_bases, int k,
+                                                               unsigned long long* __restrict__ starts,
+                                                               unsigned long long* __restrict__ count) {
+  const int64_t n_words = (n_bases + 63) / 64;
+  int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (; w < n_words; w += stride) {
+    unsigned long long lo = ends[w], hi = ends[w + 1];       // the mask has one pad word
+    // OR of the window [i, i + k - 2] for every bit i, by doubling
+    int have = 1;
+    const int need = k - 1;
+    unsigned long long x_lo = need > 0 ? lo : 0ull, x_hi = need > 0 ? hi : 0ull;
+    while (have < need) {
+      const int s = min(have, need - have);
+      x_lo |= (x_lo >> s) | (x_hi << (64 - s));
+      x_hi |= x_hi >> s;
+      have += s;
+    }
+    unsigned long long v = ~x_lo;
+    const int64_t left = n_bases - w * 64;                   // bits of this word that are bases
+    if (left < 64) v &= (1ull << left) - 1ull;
+    starts[w] = v;
+    local += __popcll(v);
+  }
+  local = wave_reduce_sum(local);
+  if (lane_id() == 0 && local) atomicAdd(count, local);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bnpk_fastq_tiles(int64_t n_bytes) { return n_bytes <= 0 ? 0 : ceil_div(n_bytes, FQ_TILE); }
+
+int bnpk_fastq_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_per_entry, int seq_line,
+                      int64_t* d_tile_table, int64_t* h_totals, void* stream) {
+  if (!ctx || n < 0 || lines_per_entry < 1 || lines_per_entry > FQ_MAXLPE || seq_line < 0 || seq_line >= lines_per_entry ||
+      !d_tile_table || !h_totals || (n > 0 && !d_buf))
+    return BNPK_ERR_ARG;
+  if (((uintptr_t)d_buf & 15) != 0) return BNPK_ERR_ALIGN;
+  h_totals[0] = h_totals[1] = h_totals[2] = h_totals[3] = 0;
+  const int64_t tiles = bnpk_fastq_tiles(n);
+  if (tiles == 0) return BNPK_OK;
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  // table layout: [0 .. 8) flags + totals, records (tiles * FQ_TREC), first lines (tiles + 1), sequence bases (tiles + 1)
+  int64_t* flags = d_tile_table;
+  int64_t* totals = d_tile_table + 4;
+  int64_t* recs = d_tile_table + 8;
+  int64_t* line_base = recs + tiles * FQ_TREC;
+  int64_t* seq_base = line_base + tiles + 1;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
+  int64_t* scan_scratch = (int64_t*)scratch;
+  {
+    bnpk_timer t(ctx, "fastq_census", s);
+    hipLaunchKernelGGL(fq_detect_cr_kernel, dim3(1), dim3(64), 0, s, d_buf, n, lines_per_entry, flags);
+    hipLaunchKernelGGL(fq_census_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                       (const int64_t*)flags, recs, line_base);
+    BNPK_HIP(ctx, hipGetLastError());
+    BNPK_CHECK(bnpk_scan_launch(ctx, line_base, tiles, 1, line_base, true, scan_scratch, s));      // newline counts -> first lines
+    hipLaunchKernelGGL(fq_select_kernel, dim3(grid_for(ceil_div(tiles, 256))), dim3(256), 0, s, d_buf, n, lines_per_entry,
+                       seq_line, tiles, (const int64_t*)line_base, (const int64_t*)flags, recs, seq_base, totals);
+    BNPK_HIP(ctx, hipGetLastError());
+    BNPK_CHECK(bnpk_scan_launch(ctx, seq_base, tiles, 1, seq_base, true, scan_scratch, s));        // sequence bytes -> flat base indices
+  }
+  int64_t host[2] = {0, 0}, bases = 0, cr = 0;
+  BNPK_HIP(ctx, hipMemcpyAsync(host, totals, sizeof(host), hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(&bases, seq_base + tiles, 8, hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(&cr, flags, 8, hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  h_totals[0] = host[0];
+  h_totals[1] = host[1];
+  h_totals[2] = bases;
+  h_totals[3] = cr;
+  return BNPK_OK;
+}
+
+int64_t bnpk_fastq_table_words(int64_t n_bytes) {
+  const int64_t tiles = bnpk_fastq_tiles(n_bytes);
+  return 8 + tiles * FQ_TREC + 2 * (tiles + 1);
+}
+
+int bnpk_fastq_encode(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_per_entry, int seq_line, uint8_t header,
+                      int check_plus, const int64_t* d_tile_table, int64_t n_lines_used, int64_t n_bases,
+                      uint64_t* d_packed, uint64_t* d_row_ends, int64_t* d_err3, void* stream) {
+  if (!ctx || n < 0 || lines_per_entry < 1 || lines_per_entry > FQ_MAXLPE || seq_line < 0 || seq_line >= lines_per_entry ||
+      !d_tile_table || !d_packed || !d_row_ends || !d_err3 || n_bases < 0 || n_lines_used < 0 || (n > 0 && !d_buf))
+    return BNPK_ERR_ARG;
+  if (check_plus && lines_per_entry < 3) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_buf & 15) != 0) return BNPK_ERR_ALIGN;
+  const int64_t tiles = bnpk_fastq_tiles(n);
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "fastq_encode", s);
+  BNPK_HIP(ctx, hipMemsetAsync(d_packed, 0, (size_t)(n_bases / 32 + 2) * 8, s));
+  BNPK_HIP(ctx, hipMemsetAsync(d_row_ends, 0, (size_t)(n_bases / 64 + 2) * 8, s));
+  BNPK_CHECK(bnpk_fill_i64(ctx, d_err3, 3, BNPK_NONE, stream));
+  if (tiles == 0) return BNPK_OK;
+  const int64_t* flags = d_tile_table;
+  const int64_t* recs = d_tile_table + 8;
+  const int64_t* seq_base = recs + tiles * FQ_TREC + tiles + 1;
+  hipLaunchKernelGGL(fq_encode_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry, seq_line,
+                     header, check_plus, flags, recs, seq_base, n_lines_used,
+                     reinterpret_cast<unsigned long long*>(d_packed), reinterpret_cast<unsigned long long*>(d_row_ends),
+                     reinterpret_cast<unsigned long long*>(d_err3));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_kmer_starts_from_ends(bnpk_ctx* ctx, const uint64_t* d_row_ends, int64_t n_bases, int k, uint64_t* d_starts,
+                               int64_t* d_count, void* stream) {
+  if (!ctx || n_bases < 0 || k < 1 || k > 32 || !d_row_ends || !d_starts || !d_count) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "kmer_starts_from_ends", s);
+  BNPK_HIP(ctx, hipMemsetAsync(d_count, 0, 8, s));
+  BNPK_HIP(ctx, hipMemsetAsync(d_starts + (n_bases + 63) / 64, 0, (size_t)(n_bases / 64 + 2 - (n_bases + 63) / 64) * 8, s));
+  const int64_t n_words = (n_bases + 63) / 64;
+  if (n_words == 0) return BNPK_OK;
+  const int64_t blocks = std::min<int64_t>(ceil_div(n_words, BNPK_BLOCK), (int64_t)ctx->compute_units * 16);
+  hipLaunchKernelGGL(fq_starts_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s,
+                     reinterpret_cast<const unsigned long long*>(d_row_ends), n_bases, k,
+                     reinterpret_cast<unsigned long long*>(d_starts), reinterpret_cast<unsigned long long*>(d_count));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -83,6 +83,43 @@ class HipOps:
                                   line_number=2 + int(e[1]) * lines_per_entry)
         return LineScan(int(e[3]) + 1, n_lines, n_lines // lines_per_entry, newlines, bool(e[2]))
 
+    # -- A2-A7 fused (k-mer pipeline) -----------------------------------------------------------------------
+    def fastq_encode(self, buf, n, lines_per_entry, seq_line, header, check_plus):
+        """text -> (packed 2-bit reads, read-end bit mask, n_records, n_bases): newline scan, validation, sequence
+        extraction and 2-bit packing in two reads of the text, with the reference's exceptions
+        (one_line_buffer.py:45-71,156-173; alphabet_encoding.py:37-45)"""
+        d = buf.dev()
+        table = self._empty(lib.bnpk_fastq_table_words(n), np.int64)
+        totals = (C.c_int64 * 4)()
+        self._chk(lib.bnpk_fastq_census(self.ctx, ptr(d), n, lines_per_entry, seq_line, ptr(table), totals, self._s()))
+        n_newlines, n_lines, n_bases = int(totals[0]), int(totals[1]), int(totals[2])
+        if n_newlines < lines_per_entry:
+            raise IncompleteEntryException("No complete entry in buffer. Try increasing chunk_size.")
+        packed = self._empty(n_bases // 32 + 2, np.int64)
+        ends = self._empty(n_bases // 64 + 2, np.int64)
+        err = self._empty(3, np.int64)
+        self._chk(lib.bnpk_fastq_encode(self.ctx, ptr(d), n, lines_per_entry, seq_line, header, 1 if check_plus else 0,
+                                        ptr(table), n_lines, n_bases, ptr(packed), ptr(ends), ptr(err), self._s()))
+        e = err.cpu().numpy()
+        if e[0] != NONE:
+            raise FormatException("Expected header line to start with %s" % chr(header),
+                                  line_number=int(e[0]) * lines_per_entry)
+        if check_plus and e[1] != NONE:
+            raise FormatException("Expected '+' at third line of entry",
+                                  line_number=2 + int(e[1]) * lines_per_entry)
+        if e[2] != NONE:
+            raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character at flat "
+                                "offset %d" % int(e[2]), int(e[2]))
+        return HArray(dev=packed), HArray(dev=ends), n_lines // lines_per_entry, n_bases
+
+    def kmer_starts_from_ends(self, row_ends, n_bases, k):
+        """(k-mer start mask, number of k-mers) from the read-end mask"""
+        mask = self._empty(n_bases // 64 + 2, np.int64)
+        count = self._empty(1, np.int64)
+        self._chk(lib.bnpk_kmer_starts_from_ends(self.ctx, ptr(row_ends.dev()), n_bases, k, ptr(mask), ptr(count),
+                                                 self._s()))
+        return HArray(dev=mask), int(count.item())
+
     def field_table(self, buf, newlines, n_entries, lines_per_entry, field, line_offset, strip_cr):
         starts = self._empty(n_entries, np.int64)
         lens = self._empty(n_entries, np.int64)

@@ -6,7 +6,8 @@ docs_source/topics/kmers.rst:42-62):
     for chunk in bnp.open(fq).read_chunks(): counts += count_kmers(change_encoding(chunk.sequence, DNA), k)
 
 but on one batch sized for 288 GB of HBM (tens of millions of reads) instead of 5 MB chunks, and with
-every intermediate released as soon as the next stage has consumed it.  For the sparse histogram the
+every intermediate released as soon as the next stage has consumed it.  For the sparse histogram the text is
+decoded by the fused census + encode kernels (no newline table, field tables or row offsets) and the
 k-mer hashes are never materialised in read order: ``bnpk_kmers_partition`` generates them straight
 into the first level of the MSD radix partition.  bench.py times exactly this function; __graft_entry__.smoke()
 and the tests check it against the oracle.
@@ -29,6 +30,29 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
     ops = get_ops()
     lpe = buffer_type.n_lines_per_entry
+    distributed = group is not None or _world_size() > 1
+    key_bits = 2 * k
+    if k > DENSE_MAX_K and fused:                                                                     # A2-A7 fused
+        packed, ends, n, n_bases = ops.fastq_encode(text, text.size, lpe, 1, ord(buffer_type.HEADER),
+                                                    buffer_type._check_plus)
+        starts_mask, n_kmers = ops.kmer_starts_from_ends(ends, n_bases, k)
+        del ends
+        stats = BatchStats(n, n_bases, n_kmers, text.size)
+        if distributed:                                                                               # A9 sparse, N GPUs
+            # generate the hashes already partitioned by their top 8 bits == grouped by owning rank
+            part, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, parallel.FINE_BITS)
+            del packed, starts_mask
+            holder = [part]                   # hand the 8 B/k-mer buffer over: it is freed right after the exchange
+            del part
+            return parallel.count_sparse_distributed(holder, key_bits, group, cuts=cuts), stats
+        levels = ops.radix_plan(n_kmers, key_bits)
+        if levels:                                                                                    # A8 + A9 sparse
+            hashes, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, levels[0])
+            del packed, starts_mask
+            return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0])), stats
+        hashes, _ = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, 0)
+        del packed, starts_mask
+        return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
     scan = ops.scan_lines(text, text.size, lpe, ord(buffer_type.HEADER), buffer_type._check_plus)   # A2 + A3
     n = scan.n_records
     starts, lens = ops.field_table(text, scan.newlines, n, lpe, 1, buffer_type._line_offsets[1], scan.has_cr)  # A4
@@ -40,8 +64,6 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     out_offsets, n_kmers = ops.row_offsets(lens, k)
     del lens
     stats = BatchStats(n, n_bases, n_kmers, n_bytes)
-    distributed = group is not None or _world_size() > 1
-    key_bits = 2 * k
     if k <= DENSE_MAX_K:                                                                              # A8 + A9 dense
         hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
         del packed, offsets, out_offsets
@@ -59,14 +81,6 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
         holder = [part]                       # hand the 8 B/k-mer buffer over: it is freed right after the exchange
         del part
         return parallel.count_sparse_distributed(holder, key_bits, group, cuts=cuts), stats
-    if fused:                                                                                         # A8 + A9 sparse
-        levels = ops.radix_plan(n_kmers, key_bits)
-        if levels:
-            ends = ops.kmer_start_mask(offsets, n, n_bases, k)
-            del offsets, out_offsets
-            hashes, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, levels[0])
-            del packed, ends
-            return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0])), stats
     hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
     del packed, offsets, out_offsets
     return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats

@@ -101,6 +101,34 @@ int bnpk_field_table(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newli
                      int64_t n_entries, int lines_per_entry, int field, int line_offset,
                      int strip_cr, int64_t* d_starts, int64_t* d_lens, void* stream);
 
+/* ---- A2-A7 fused for the k-mer pipeline ------------------------------------------------------------------
+ * One-line-per-field formats (FASTQ: lines_per_entry 4, two-line FASTA: 2; seq_line = index of the sequence
+ * line inside an entry).  Replaces, without materialising the newline table, the field tables or the row
+ * offsets: OneLineBuffer.from_raw_buffer + _validate (bionumpy/io/one_line_buffer.py:45-71,156-173,
+ * bionumpy/io/fastq_buffer.py:39-45), get_field_by_number(1) (bionumpy/io/file_buffers.py:315-338),
+ * EncodedRaggedArray.ravel() + AlphabetEncoding._encode (bionumpy/encodings/alphabet_encoding.py:19-46) and
+ * BitArray.pack (bionumpy/sequence/kmers.py:121).
+ *   bnpk_fastq_census   reads the text once; synchronous.  h_totals = {newlines in the buffer, lines that take part
+ *                       (a multiple of lines_per_entry), sequence bases, 1 if CRs are stripped}.  d_tile_table
+ *                       (bnpk_fastq_table_words(n) int64) carries the per-tile state to the encoder.
+ *   bnpk_fastq_encode   reads the text once more: d_packed (n_bases/32 + 2 words, the layout of
+ *                       bnpk_gather_encode_dna), d_row_ends (n_bases/64 + 2 words: bit i set on the last base of
+ *                       every read), d_err3 = {first entry whose header line does not start with `header`, first
+ *                       entry whose third line does not start with '+' (check_plus), smallest flat offset of a
+ *                       byte that is not A/C/G/T in either case}; BNPK_NONE where there is no error.
+ *   bnpk_kmer_starts_from_ends   the ragged trim `ragged[..., :-(k-1)]` (bionumpy/sequence/kmers.py:100) as a
+ *                       mask: bit i set iff a k-mer starts at base i (same mask as bnpk_kmer_start_mask);
+ *                       *d_count = number of k-mers. */
+int64_t bnpk_fastq_tiles(int64_t n_bytes);
+int64_t bnpk_fastq_table_words(int64_t n_bytes);
+int bnpk_fastq_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_per_entry, int seq_line,
+                      int64_t* d_tile_table, int64_t* h_totals, void* stream);
+int bnpk_fastq_encode(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_per_entry, int seq_line, uint8_t header,
+                      int check_plus, const int64_t* d_tile_table, int64_t n_lines_used, int64_t n_bases,
+                      uint64_t* d_packed, uint64_t* d_row_ends, int64_t* d_err3, void* stream);
+int bnpk_kmer_starts_from_ends(bnpk_ctx* ctx, const uint64_t* d_row_ends, int64_t n_bases, int k, uint64_t* d_starts,
+                               int64_t* d_count, void* stream);
+
 /* ---- ragged offsets ----------------------------------------------------------------------
  * replaces npstructures RaggedShape (starts = cumsum(lengths) - lengths):
  * d_offsets[0..n] = exclusive scan of d_lens (d_offsets[n] = total).  If window > 1 the scanned

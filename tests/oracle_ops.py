@@ -51,6 +51,25 @@ class OracleOps:
         from bionumpy_amd.ops import HipOps
         return HipOps.radix_plan(n, key_bits, done)
 
+    def fastq_encode(self, buf, n, lines_per_entry, seq_line, header, check_plus):
+        scan = self.scan_lines(buf, n, lines_per_entry, header, check_plus)
+        starts, lens = self.field_table(buf, scan.newlines, scan.n_records, lines_per_entry, seq_line, 0, scan.has_cr)
+        offsets, n_bases = self.row_offsets(lens, 1)
+        _, packed = self.gather_encode_dna(buf, starts, offsets, scan.n_records, n_bases)
+        off = offsets.host()
+        bits = np.zeros((n_bases // 64 + 2) * 64, dtype=np.uint8)
+        bits[off[1:][np.diff(off) > 0] - 1] = 1
+        return packed, _h(np.packbits(bits, bitorder="little").view(np.int64)), scan.n_records, n_bases
+
+    def kmer_starts_from_ends(self, row_ends, n_bases, k):
+        flags = np.unpackbits(row_ends.host().view(np.uint8), bitorder="little")
+        ends = np.flatnonzero(flags[:n_bases]) + 1
+        out = np.zeros(flags.size, dtype=np.uint8)
+        for s0, e in zip(np.concatenate([[0], ends[:-1]]), ends):
+            if e - (k - 1) > s0:
+                out[s0:e - (k - 1)] = 1
+        return _h(np.packbits(out, bitorder="little").view(np.int64)), int(out.sum())
+
     def kmer_start_mask(self, offsets, n_rows, total, k):
         off = offsets.host()
         bits = np.zeros((total // 64 + 2) * 64, dtype=np.uint8)

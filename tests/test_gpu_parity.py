@@ -262,3 +262,77 @@ def test_count_sparse_radix_path(ops, seed, n, key_bits, dup):
         ek, ec = oracle.count_sparse(sub)
         gk, gc = ops.count_sparse(_h(sub), key_bits=key_bits, key_range=(lo, hi))
         assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+
+
+def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
+    """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
+    incomplete entry"""
+    rng = np.random.default_rng(seed)
+    alphabet = np.frombuffer(b"ACGTacgt" if lower else b"ACGT", dtype=np.uint8)
+    eol = b"\r\n" if crlf else b"\n"
+    parts = []
+    for i in range(n_reads):
+        ln = int(rng.integers(0, max_len))
+        seq = rng.choice(alphabet, size=ln).tobytes()
+        parts.append(b"@r%d some text" % i + eol + seq + eol + b"+" + eol + b"I" * ln + eol)
+    return np.frombuffer(b"".join(parts) + tail, dtype=np.uint8).copy()
+
+
+@pytest.mark.parametrize("seed,n_reads,max_len,crlf,tail", [
+    (1, 1, 10, False, b""), (2, 7, 40, False, b"@partial\nACG"), (3, 3000, 300, False, b""),
+    (4, 3000, 300, True, b""), (5, 40, 60_000, False, b"@x\nAC\n+\n"), (6, 50_000, 120, False, b""),
+    (7, 2000, 3, False, b""), (8, 5000, 200, True, b"@t\r\nACGT\r\n")])
+def test_fused_fastq_encode_matches_the_unfused_path(ops, seed, n_reads, max_len, crlf, tail):
+    """bnpk_fastq_census + bnpk_fastq_encode + bnpk_kmer_starts_from_ends == scan + validate + field table +
+    gather/encode + start mask of the unfused kernels == the oracle (tile-straddling reads, empty reads, CRLF,
+    trailing incomplete entry)"""
+    text = _ragged_fastq(seed, n_reads, max_len, crlf, tail)
+    res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    codes = oracle.encode_dna(oracle.gather_rows(text, starts, lens))
+    packed, ends, n_records, n_bases = ops.fastq_encode(_h(text), text.size, 4, 1, ord("@"), True)
+    assert n_records == res.n_records and n_bases == codes.size
+    words = oracle.pack_2bit(codes)
+    got = packed.host().view(np.uint64)
+    assert np.array_equal(got[:words.size], words) and not got[words.size:].any()
+    flags = np.unpackbits(ends.host().view(np.uint8), bitorder="little")
+    expect = np.zeros(flags.size, dtype=np.uint8)
+    expect[np.cumsum(lens)[lens > 0] - 1] = 1
+    assert np.array_equal(flags, expect)
+    offsets, _ = ops.row_offsets(_h(lens), 1)
+    for k in (1, 2, 5, 31):
+        mask, n_kmers = ops.kmer_starts_from_ends(ends, n_bases, k)
+        ref = ops.kmer_start_mask(offsets, n_records, n_bases, k)
+        assert np.array_equal(mask.host(), ref.host())
+        assert n_kmers == int(np.maximum(lens - k + 1, 0).sum())
+
+
+def test_fused_fastq_encode_raises_like_the_reference(ops):
+    from bionumpy_amd.exceptions import FormatException, EncodingError, IncompleteEntryException
+    good = _ragged_fastq(11, 500, 100)
+    with pytest.raises(IncompleteEntryException):
+        ops.fastq_encode(_h(good[:20]), 20, 4, 1, ord("@"), True)
+    res = oracle.scan_one_line_buffer(good, oracle.FASTQ)
+    nl = res.new_lines if hasattr(res, "new_lines") else np.flatnonzero(good == 10)
+    bad = good.copy()
+    bad[nl[4 * 123 - 1] + 1] = ord("x")                       # header of entry 123
+    with pytest.raises(FormatException) as e:
+        ops.fastq_encode(_h(bad), bad.size, 4, 1, ord("@"), True)
+    assert e.value.line_number == 123 * 4
+    bad = good.copy()
+    bad[nl[4 * 77 + 1] + 1] = ord("-")                        # '+' line of entry 77
+    with pytest.raises(FormatException) as e:
+        ops.fastq_encode(_h(bad), bad.size, 4, 1, ord("@"), True)
+    assert e.value.line_number == 2 + 77 * 4
+    bad = good.copy()
+    bad[0] = ord(">")
+    with pytest.raises(FormatException) as e:
+        ops.fastq_encode(_h(bad), bad.size, 4, 1, ord("@"), True)
+    assert e.value.line_number == 0
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    row = int(np.flatnonzero(lens > 5)[40])
+    bad = good.copy()
+    bad[starts[row] + 3] = ord("N")
+    with pytest.raises(EncodingError) as e:
+        ops.fastq_encode(_h(bad), bad.size, 4, 1, ord("@"), True)
+    assert e.value.offset == int(np.cumsum(lens)[row] - lens[row] + 3)
