@@ -5,6 +5,7 @@
 #include "common.h"
 #include "rows.h"
 #include "kmer_gen.h"
+#include "scan.h"
 
 namespace {
 
@@ -81,6 +82,85 @@ __global__ __launch_bounds__(BNPK_BLOCK) void row_ids_kernel(const int64_t* __re
   }
 }
 
+// ---- position-flat generation (the fast path of bnpk_kmers / bnpk_minimizers) --------------------------------------
+// Items are the flat base positions of the packed stream; a bit mask says at which of them a window (a k-mer, or
+// a minimizer window of several k-mers) starts, so no lane ever looks a row up.  A lane owns eight consecutive
+// positions: three packed words + one mask byte, one funnel shift for the first k-mer and a 2-bit roll for every
+// further one.  The ragged output order equals the position order, so the output index of a window is its rank
+// among the mask bits: tile counts (popcounts) -> scan -> ranks inside the tile by wave scans; the values are
+// staged in LDS and leave the CU as one contiguous run per tile.
+constexpr int WF_ITEMS = 8;
+constexpr int WF_TILE = BNPK_BLOCK * WF_ITEMS;            // 2048 positions per workgroup
+constexpr int WF_MAX_PER_WINDOW = 26;                     // k-mers per window the 64-bit "next bases" register covers
+
+// number of windows starting in every tile of 2048 positions: one lane per 64-bit mask word, 32 words per tile
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_count_kernel(const uint64_t* __restrict__ mask, int64_t n_words,
+                                                              int64_t n_tiles, int64_t* __restrict__ counts) {
+  const int64_t w = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x;
+  const unsigned c = w < n_words ? (unsigned)__popcll(mask[w]) : 0u;
+  const unsigned inc = wave_inclusive_scan(c);
+  const unsigned s31 = (unsigned)__builtin_amdgcn_readlane((int)inc, 31), s63 = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+  const int64_t tile = ((int64_t)blockIdx.x * BNPK_BLOCK + (threadIdx.x & ~63)) / 32;    // first tile of this wavefront
+  if (lane_id() == 0 && tile < n_tiles) counts[tile] = s31;
+  if (lane_id() == 32 && tile + 1 < n_tiles) counts[tile + 1] = s63 - s31;
+}
+
+__device__ __forceinline__ uint64_t wf_window(uint64_t w0, uint64_t w1, uint64_t w2, int sh) {   // 64 bits at bit sh (< 128)
+  const uint64_t lo = sh < 64 ? w0 : w1, hi = sh < 64 ? w1 : w2;
+  const int s6 = sh & 63;
+  return s6 ? (lo >> s6) | (hi << (64 - s6)) : lo;
+}
+
+// per_window == 1: the hash of the k-mer at every marked position; > 1: the minimum over the per_window k-mers of
+// the window that starts there
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_generate_kernel(const uint64_t* __restrict__ W, int64_t n_words,
+                                                                 const uint8_t* __restrict__ mask8, int64_t n_bases,
+                                                                 int k, int per_window,
+                                                                 const int64_t* __restrict__ tile_off,
+                                                                 int64_t* __restrict__ out) {
+  __shared__ uint64_t stage[WF_TILE];
+  __shared__ unsigned wsum[BNPK_BLOCK / 64];
+  const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+  const unsigned v = o < n_bases ? mask8[o >> 3] : 0u;
+  const unsigned cnt = __popc(v);
+  const unsigned inc = wave_inclusive_scan(cnt);
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  uint64_t vals[WF_ITEMS];
+  if (v) {
+    const int64_t wi = o >> 5;
+    const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0;
+    const int sh0 = 2 * (int)(o & 31), top = 2 * k - 2;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    uint64_t h = wf_window(w0, w1, w2, sh0) & kmask;        // k-mer at position o
+    const uint64_t next = wf_window(w0, w1, w2, sh0 + 2 * k);   // the bases that enter the k-mers at o+1, o+2, ...
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+      if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
+      uint64_t m = h;
+      if (per_window > 1 && ((v >> q) & 1u)) {
+        uint64_t t = h;
+        for (int i = 1; i < per_window; ++i) {
+          t = (t >> 2) | (((next >> (2 * (q + i - 1))) & 3ull) << top);
+          m = t < m ? t : m;
+        }
+      }
+      vals[q] = m;
+    }
+  }
+  __syncthreads();
+  unsigned rank = inc - cnt;
+  for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
+  if (v) {
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q)
+      if ((v >> q) & 1u) stage[rank++] = vals[q];
+  }
+  __syncthreads();
+  const int64_t base = tile_off[blockIdx.x];
+  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
+  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = (int64_t)stage[i];
+}
+
 // bits [off[r], off[r+1] - (k-1)) of the mask for every row r with at least k bases: the positions of the flat
 // packed stream at which a k-mer starts.  One lane per row; a row touches a handful of 32-bit words.
 __global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t n_rows, int k,
@@ -113,6 +193,31 @@ int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows
   if (n_rows > 0)
     hipLaunchKernelGGL(kmer_start_mask_kernel, dim3(grid_for(ceil_div(n_rows, 256))), dim3(256), 0, s, d_offsets,
                        n_rows, k, reinterpret_cast<unsigned*>(d_mask));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int k,
+                      int kmers_per_window, int64_t n_out, int64_t* d_out, void* stream) {
+  if (!ctx || k < 1 || k > 31 || kmers_per_window < 1 || n_bases < 0 || n_out < 0) return BNPK_ERR_ARG;
+  if (kmers_per_window > WF_MAX_PER_WINDOW) return BNPK_ERR_RANGE;
+  if (n_out == 0 || n_bases == 0) return BNPK_OK;
+  if (!d_packed || !d_start_mask || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ceil_div(n_bases, WF_TILE), n_mask_words = ceil_div(n_bases, 64);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  int64_t* tile_off = (int64_t*)scratch;
+  int64_t* scan_scratch = tile_off + n_tiles + 1;
+  bnpk_timer t(ctx, kmers_per_window == 1 ? "kmers_flat" : "minimizers_flat", s);
+  hipLaunchKernelGGL(wf_count_kernel, dim3((unsigned)ceil_div(n_mask_words, BNPK_BLOCK)), dim3(BNPK_BLOCK), 0, s,
+                     d_start_mask, n_mask_words, n_tiles, tile_off);
+  BNPK_HIP(ctx, hipGetLastError());
+  BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
+  hipLaunchKernelGGL(wf_generate_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases / 32 + 2,
+                     reinterpret_cast<const uint8_t*>(d_start_mask), n_bases, k, kmers_per_window,
+                     (const int64_t*)tile_off, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -11,8 +11,6 @@
 // in read order) before the buckets (~6 K keys) fit the finishing kernel, which sorts them in LDS (12-bit
 // counting sort + exact ranking inside the ~1.4-key bins), run-length-counts the duplicates and writes
 // (key, count) at the final sorted position.  MSD ranks need no stability, so they come from plain LDS atomics.
-#include <stdlib.h>
-
 #include <algorithm>
 #include <type_traits>
 
@@ -562,7 +560,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
                                                                    int64_t n_buckets, int sshift, int sbits,
                                                                    unsigned long long* __restrict__ state,
                                                                    uint64_t* __restrict__ keys_out,
-                                                                   int64_t* __restrict__ counts_out, int ablate) {
+                                                                   int64_t* __restrict__ counts_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);
@@ -727,7 +725,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q)
       if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
-    if (ablate & 8) active = 0;
     for (unsigned step = 0; __any(active != 0); ++step) {
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
@@ -753,7 +750,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     const unsigned pex = pinc - c0 - c1;
     const unsigned D = (unsigned)__builtin_amdgcn_readlane((int)pinc, 63);      // distinct keys of the bucket
     if (wave == 0) {
-      const long long base = (ablate & 1) ? cur.lo : look_back(cur.b, D);
+      const long long base = look_back(cur.b, D);
       if (lane == 0) sh[1] = base;
     }
     // multiplicity and sorted position of every distinct key (the lane shuffles run with all lanes active)
@@ -774,7 +771,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         todo |= 1u << q;
       }
     }
-    if (ablate & 4) todo = 0;
     for (unsigned step = 0; __any(todo != 0); ++step) {
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
@@ -798,7 +794,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     if (tid < FN_WORDS) fmask[tid] = 0;
     __syncthreads();
     const int64_t base = sh[1];
-    if (ablate & 2) continue;
     for (unsigned i = tid; i < D; i += FN_THREADS) {
       keys_out[base + i] = stage[i];
       counts_out[base + i] = cnt16[i];
@@ -863,8 +858,6 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
     attr_set = true;
   }
   BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)bnpk_finish_state_words(n_buckets) * sizeof(int64_t), s));
-  const char* ab = getenv("BNPK_ABLATE");        // kernel-timing experiments only; results are invalid when set
-  const int ablate = ab ? atoi(ab) : 0;
   // one workgroup per CU fits (LDS); the ticket order keeps the look-back deadlock-free for any grid size
   const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
   {
@@ -872,7 +865,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
     hipLaunchKernelGGL(finish_sorted_kernel, dim3(grid), dim3(FN_THREADS), FN_LDS, s,
                        reinterpret_cast<const uint64_t*>(d_part), d_bucket_offsets, n_buckets, sshift, sbits,
                        reinterpret_cast<unsigned long long*>(d_state), reinterpret_cast<uint64_t*>(d_keys_out),
-                       d_counts_out, ablate);
+                       d_counts_out);
     BNPK_HIP(ctx, hipGetLastError());
   }
   int64_t host[3] = {0, 0, 0};

@@ -196,13 +196,38 @@ class HipOps:
         return HArray(dev=out)
 
     # -- A8 / A11 ------------------------------------------------------------------------------------------
+    WINDOWS_FLAT_MAX = 26         # k-mers per window the row-lookup-free generator covers
+
+    def _windows_flat(self, packed, in_offsets, n_rows, n_out, k, window_size):
+        """hashes (window_size == k) / minimizers through the position-flat generator: start mask + ranks"""
+        out = self._empty(n_out, np.int64)
+        if n_out == 0:
+            return HArray(dev=out)
+        total = int(in_offsets.dev()[n_rows].item())
+        mask = self.kmer_start_mask(in_offsets, n_rows, total, window_size)
+        self._chk(lib.bnpk_windows_flat(self.ctx, ptr(packed.dev()), ptr(mask.dev()), total, k, window_size - k + 1,
+                                        n_out, ptr(out), self._s()))
+        return HArray(dev=out)
+
     def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
+        return self._windows_flat(packed, in_offsets, n_rows, n_out, k, k)
+
+    def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
+        if window_size - k + 1 <= self.WINDOWS_FLAT_MAX:
+            return self._windows_flat(packed, in_offsets, n_rows, n_out, k, window_size)
+        out = self._empty(n_out, np.int64)
+        self._chk(lib.bnpk_minimizers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
+                                      n_rows, n_out, k, window_size, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def kmers_by_rows(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
+        """bnpk_kmers: the output-flat kernel with per-lane row lookups (kept for comparison / as the reference form)"""
         out = self._empty(n_out, np.int64)
         self._chk(lib.bnpk_kmers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()), n_rows,
                                  n_out, k, ptr(out), self._s()))
         return HArray(dev=out)
 
-    def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
+    def minimizers_by_rows(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
         out = self._empty(n_out, np.int64)
         self._chk(lib.bnpk_minimizers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
                                       n_rows, n_out, k, window_size, ptr(out), self._s()))

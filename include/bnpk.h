@@ -182,6 +182,13 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
 int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t total, int k,
                          uint64_t* d_mask, void* stream);
 
+/* Row-lookup-free form of bnpk_kmers (kmers_per_window = 1) and bnpk_minimizers (kmers_per_window =
+ * window_size - k + 1 <= 26): d_start_mask marks the flat positions at which a window starts
+ * (bnpk_kmer_start_mask with k = the window length in bases); the output is the same ragged-flat array.
+ * BNPK_ERR_RANGE if the window holds more k-mers than the fast path covers (use bnpk_minimizers). */
+int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int k,
+                      int kmers_per_window, int64_t n_out, int64_t* d_out, void* stream);
+
 /* Same hashes as bnpk_kmers, but never materialised in row order: written exactly once, already partitioned (not
  * stably) by the `bits`-bit digit at bit `shift` (bits <= bnpk_radix_max_bits()) — level 1 of the MSD radix
  * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the

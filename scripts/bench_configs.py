@@ -46,8 +46,10 @@ sync(); dt = (time.perf_counter() - t0) / 2
 prof = dev.prof_report(); dev.prof_enable(False)
 out["config3_minimizers"] = {"reads": reads, "k": 31, "window_size": 40, "n_minimizers": n_out,
                              "ms_per_step": round(dt * 1e3, 2), "gbases_per_s": round(reads * 150 / dt / 1e9, 2),
-                             "minimizers_kernel_ms": round(prof["minimizers"]["total_ms"] / 2, 2),
-                             "minimizers_kernel_gbs": round((8 * n_out + reads * 150 / 4) / (prof["minimizers"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
+                             "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()},
+                             "minimizers_kernel_ms": round(prof["minimizers_flat"]["total_ms"] / 2, 2),
+                             "minimizers_kernel_gbs": round((8 * n_out + reads * 150 / 4 + reads * 150 / 8) /
+                                                            (prof["minimizers_flat"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
 del text
 
 # ---- config 5: sacCer3 index + big.fq.gz lookups ---------------------------------------------------------------

@@ -79,15 +79,15 @@ def test_gather_encode_and_kmers(ops, seed, n_rows, max_len):
     assert np.array_equal(plain.host(), oracle.gather_rows(text, starts, lengths))
     for k in (1, 3, 31):
         out_off, n_out = ops.row_offsets(_h(lengths), k)
-        got = ops.kmers(packed, offsets, out_off, n_rows, n_out, k).host()
         h, hl = oracle.get_kmers(expect, lengths, k)
-        assert np.array_equal(got, h)
+        for kernel in (ops.kmers, ops.kmers_by_rows):          # position-flat (start mask + ranks) / per-lane row lookups
+            assert np.array_equal(kernel(packed, offsets, out_off, n_rows, n_out, k).host(), h)
     if total < 3_000_000:
-        for k, w in ((2, 4), (31, 40)):
+        for k, w in ((2, 4), (31, 40), (5, 30), (7, 40)):       # (7, 40): 34 k-mers per window -> the row-lookup kernel
             out_off, n_out = ops.row_offsets(_h(lengths), w)
-            got = ops.minimizers(packed, offsets, out_off, n_rows, n_out, k, w).host()
             m, _ = oracle.get_minimizers(expect, lengths, k, w)
-            assert np.array_equal(got, m)
+            for kernel in (ops.minimizers, ops.minimizers_by_rows):
+                assert np.array_equal(kernel(packed, offsets, out_off, n_rows, n_out, k, w).host(), m)
 
 
 def test_encoding_error_offset_is_first_bad_byte(ops):
