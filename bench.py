@@ -191,6 +191,22 @@ def main():
         b = algorithmic_bytes(name, stats, args.read_len, args.k, n_distinct)
         kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
                          "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
+    # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate passes, scripts/profile_r01.sh; FETCH x2 as MI355X_MICROARCH.md prescribes)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+        cfg = pmc.get("_config", {})
+        if (cfg.get("reads_per_gpu"), cfg.get("read_len"), cfg.get("k"), cfg.get("mode")) == \
+                (args.reads, args.read_len, args.k, args.mode) and world == 1:
+            names = {"finish_sorted": "finish_sorted", "radix_scatter": "rp_scatter<mem_source>",
+                     "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
+                     "fastq_encode": "fq_encode", "fastq_census": "fq_census"}
+            rec = pmc.get(names.get(dom, dom))
+            if rec and "read_bytes_corrected" in rec and "write_bytes" in rec:
+                traffic = int(rec["read_bytes_corrected"] + rec["write_bytes"])
+    except Exception:
+        traffic = None
     if dom is not None:
         p = prof[dom]
         avg_ms = p["total_ms"] / max(p["launches"], 1)
@@ -199,7 +215,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "avg_launch_ms": round(avg_ms, 3),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
                     "algorithmic_bytes_per_launch": b}
     out = {
         "metric": "Gbases/s FASTQ->k-mer count (k=%d)" % args.k,

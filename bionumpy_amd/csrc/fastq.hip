@@ -214,7 +214,9 @@ __global__ void fq_select_kernel(const uint8_t* __restrict__ buf, int64_t n, int
     const int64_t g = line_base[t];                          // line index of the tile's first byte
     r[0] = g;
     int64_t seq = 0;
-    if (line_base[t + 1] < used) {                           // every line touching the tile takes part
+    // every line touching the tile takes part; a tile that ends on line `used` itself only adds bytes of a header
+    // line (used is a multiple of lpe), which are not sequence bytes
+    if (line_base[t + 1] < used || (line_base[t + 1] == used && seq_line != 0)) {
       const int ph = (int)(((seq_line - g) % lpe + lpe) % lpe);
       seq = r[1 + ph];
     } else if (g < used) {                                   // the tile holds the end of the last entry: recount

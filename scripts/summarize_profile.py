@@ -26,7 +26,8 @@ def _short(name):
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
         return "%s<%s>" % (kind, src)
-    for key in ("finish_sorted", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
+    for key in ("fq_census", "fq_encode", "fq_select", "fq_starts", "fq_detect_cr", "wf_generate", "wf_count",
+                "finish_sorted", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
                 "gather_encode", "kmer_kernel", "run_census", "run_heads", "run_sums", "synth_fastq", "fill_kernel",
                 "hist_lds", "hist_global", "finish_runs", "partition_scatter", "partition_hist"):
         if key in name:
@@ -100,6 +101,12 @@ def main():
                 t["read_bytes_corrected"] = int(f * 1024 * 2)        # gfx950: FETCH_SIZE reports 1/2 of wide reads
             if w is not None:
                 t["write_bytes"] = int(w * 1024)
+        bench = os.path.join(src, "bench_fetch.json")
+        if os.path.exists(bench):                      # the workload the counters were collected on
+            try:
+                table["_config"] = json.loads(open(bench).read().strip().splitlines()[-1])["config"]
+            except Exception:
+                pass
         json.dump(table, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
         print(json.dumps(table, indent=1, sort_keys=True))
 

@@ -336,3 +336,23 @@ def test_fused_fastq_encode_raises_like_the_reference(ops):
     with pytest.raises(EncodingError) as e:
         ops.fastq_encode(_h(bad), bad.size, 4, 1, ord("@"), True)
     assert e.value.offset == int(np.cumsum(lens)[row] - lens[row] + 3)
+
+
+def test_pipeline_on_two_line_fasta(ops):
+    """the fused decode is generic over one-line-per-field formats: two-line FASTA (lines_per_entry 2, header '>')"""
+    from bionumpy_amd.io.buffers import TwoLineFastaBuffer
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    rng = np.random.default_rng(3)
+    parts, seqs = [], []
+    for i in range(4000):
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(rng.integers(0, 400))).tobytes()
+        seqs.append(seq)
+        parts.append(b">seq%d\n" % i + seq + b"\n")
+    text = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    codes = oracle.encode_dna(np.frombuffer(b"".join(seqs), dtype=np.uint8))
+    for k in (15, 31):
+        (keys, counts), stats = fastq_kmer_histogram(_h(text), k, buffer_type=TwoLineFastaBuffer)
+        ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lens, k)[0])
+        assert stats.n_reads == 4000 and stats.n_bases == codes.size
+        assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
