@@ -526,9 +526,10 @@ constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_BUCKETS = 8;
 constexpr unsigned long long FN_AGG = 1ull << 62, FN_INC = 2ull << 62, FN_VALUE = (1ull << 62) - 1;
 constexpr unsigned FN_SPIN_LIMIT = 1u << 24;
 
-constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;
-constexpr size_t FN_OFF_CNT = FN_OFF_BINS + (size_t)(FN_MAXBINS + 4) * 4;
-constexpr size_t FN_OFF_MASK = FN_OFF_CNT + (size_t)FN_CAP * 2;
+constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS + 4) * 4;
+constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;                      // two bin arrays (ping-pong between buckets)
+constexpr size_t FN_OFF_AUX = FN_OFF_BINS + 2 * FN_BINS_BYTES;          // per slot {rank increments : 16 | duplicates seen : 16}
+constexpr size_t FN_OFF_MASK = FN_OFF_AUX + (size_t)FN_CAP * 4;
 constexpr size_t FN_OFF_WSUM = FN_OFF_MASK + (size_t)FN_WORDS * 8;
 constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
 constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
@@ -563,11 +564,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
                                                                    int64_t* __restrict__ counts_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
-  unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);
-  unsigned short* cnt16 = reinterpret_cast<unsigned short*>(smem + FN_OFF_CNT);
+  unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);            // bins of the bucket being sorted
+  unsigned* bins_next = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS + FN_BINS_BYTES);   // ... of the one after it
+  unsigned* aux = reinterpret_cast<unsigned*>(smem + FN_OFF_AUX);
   unsigned long long* fmask = reinterpret_cast<unsigned long long*>(smem + FN_OFF_MASK);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
-  long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base
+  long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base, [2] 2nd ticket
+  unsigned* sh_dups = reinterpret_cast<unsigned*>(sh + 4);              // duplicate counters, alternating between buckets
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned SB = 1u << sbits;
 
@@ -628,176 +631,242 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     return base;
   };
 
-  for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
+  for (unsigned i = tid; i <= SB; i += FN_THREADS) { bins[i] = 0; bins_next[i] = 0; }
   if (tid < FN_WORDS) fmask[tid] = 0;
-  // Software pipeline over tickets: `cur` is sorted while the keys of `nxt` are in flight and the offsets of the
-  // bucket after that (ticket nn_b) are being loaded.
+  if (tid < 2) sh_dups[tid] = 0;
+  // Software pipeline over tickets: while bucket `cur` is sorted, the keys of the next one are in flight (and get
+  // their bin ranks at the end of the iteration) and the offsets of the one after that are being loaded.
   if (tid == 0) { sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull); sh[2] = (long long)atomicAdd(&state[FS_TICKET], 1ull); }
   __syncthreads();
   int64_t nn_b = sh[2], nn_lo = 0, nn_hi = 0;
-  fn_bucket nxt;
+  fn_bucket cur;
   {
     const int64_t b0 = sh[0];
-    nxt = fn_open(n_buckets, b0, b0 < n_buckets ? bucket_off[b0] : 0, b0 < n_buckets ? bucket_off[b0 + 1] : 0);
+    cur = fn_open(n_buckets, b0, b0 < n_buckets ? bucket_off[b0] : 0, b0 < n_buckets ? bucket_off[b0 + 1] : 0);
   }
   if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
-  uint64_t kn[FN_ITEMS];
+  uint64_t k[FN_ITEMS];
+  unsigned r[FN_ITEMS];
+  unsigned valid = 0;
 #pragma unroll
   for (int q = 0; q < FN_ITEMS; ++q) {
     const int i = tid + q * FN_THREADS;
-    if (i < nxt.nb) kn[q] = A[nxt.lo + i];
+    if (i < cur.nb) {
+      k[q] = A[cur.lo + i];
+      r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
+      valid |= 1u << q;
+    }
   }
-  __syncthreads();                                    // everybody has read sh[0], sh[2]
+  __syncthreads();                                    // everybody has read sh[0], sh[2]; the ranks are taken
+  if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
+  __syncthreads();
+  unsigned parity = 0;
 
-  while (nxt.b < n_buckets) {
-    const fn_bucket cur = nxt;
+  while (cur.b < n_buckets) {
     const int nb = cur.nb;
-    if (tid == 0) {
-      sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);       // tickets follow the dispatch order: a bucket
-      if (cur.over) atomicOr(&state[FS_FLAGS], 1ull);              // only ever waits for workgroups that started
-    }
-    // counting sort on the next sbits bits: rank inside the bin from an LDS counter
-    uint64_t k[FN_ITEMS];
-    unsigned r[FN_ITEMS];
-    unsigned valid = 0;
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tid + q * FN_THREADS;
-      if (i < nb) {
-        k[q] = kn[q];
-        r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
-        valid |= 1u << q;
-      }
-    }
-    __syncthreads();
-    // prefetch the next bucket's keys (its offsets arrived during the previous bucket) and the offsets of the
-    // bucket after it
-    nxt = fn_open(n_buckets, nn_b, nn_lo, nn_hi);
+    if (tid == 0 && cur.over) atomicOr(&state[FS_FLAGS], 1ull);
+    // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
+    const fn_bucket nxt = fn_open(n_buckets, nn_b, nn_lo, nn_hi);
+    uint64_t kn[FN_ITEMS];
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
       const int i = tid + q * FN_THREADS;
       if (i < nxt.nb) kn[q] = A[nxt.lo + i];
     }
-    nn_b = sh[0];
-    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
+    unsigned D = 0;
+    bool all_one = true;                               // every multiplicity of the bucket is 1
     if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
-      if (wave == 0) look_back(cur.b, 0u);
+      if (wave == 0) {
+        const long long base = look_back(cur.b, 0u);
+        if (lane == 0) sh[1] = base;
+      }
+      __syncthreads();                                 // (keeps the ticket word's write and reads one barrier apart)
+    } else {
+      // counting sort on the next sbits bits: exclusive scan of the bin counts, keys to their bins
+      {
+        unsigned c[FN_BINS_PER_LANE], sum = 0;
+#pragma unroll
+        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
+          const unsigned bi = tid * FN_BINS_PER_LANE + j;
+          c[j] = (bi < SB) ? bins[bi] : 0;
+          sum += c[j];
+        }
+        const unsigned inc = wave_inclusive_scan(sum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
+          const unsigned bi = tid * FN_BINS_PER_LANE + j;
+          if (bi < SB) bins[bi] = run;
+          run += c[j];
+        }
+        if (tid == 0) bins[SB] = (unsigned)nb;
+      }
       __syncthreads();
-      continue;
-    }
-    {
-      unsigned c[FN_BINS_PER_LANE], s = 0;
-#pragma unroll
-      for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-        const unsigned bi = tid * FN_BINS_PER_LANE + j;
-        c[j] = (bi < SB) ? bins[bi] : 0;
-        s += c[j];
-      }
-      const unsigned inc = wave_inclusive_scan(s);
-      if (lane == 63) wsum[wave] = inc;
-      __syncthreads();
-      unsigned run = inc - s;
-      for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-      for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-        const unsigned bi = tid * FN_BINS_PER_LANE + j;
-        if (bi < SB) bins[bi] = run;
-        run += c[j];
-      }
-      if (tid == 0) bins[SB] = (unsigned)nb;
-    }
-    __syncthreads();
-    unsigned p[FN_ITEMS], bs[FN_ITEMS];
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      p[q] = bs[q] = 0;
-      if ((valid >> q) & 1u) {
-        bs[q] = bins[(unsigned)(k[q] >> sshift) & (SB - 1)];
-        p[q] = bs[q] + r[q];
-        stage[p[q]] = k[q];
-      }
-    }
-    __syncthreads();
-    // First occurrence of every distinct key inside its (tiny) bin: walk the bin from its start up to the key's own
-    // slot.  The eight keys of a lane advance together (eight independent LDS reads per step instead of eight
-    // latency-bound loops); a key that finds an earlier equal one marks its slot (bit 63) and drops out.
-    unsigned active = 0, dup = 0;
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q)
-      if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
-    for (unsigned step = 0; __any(active != 0); ++step) {
+      unsigned bs[FN_ITEMS];                           // start of the key's bin; its own slot is bs + r
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
-        if ((active >> q) & 1u) {
-          const unsigned j = bs[q] + step;
-          const uint64_t y = stage[j] & KEYMASK;
-          if (y == k[q]) { dup |= 1u << q; active &= ~(1u << q); }
-          else if (j + 1 >= p[q]) active &= ~(1u << q);
+        bs[q] = 0;
+        if ((valid >> q) & 1u) {
+          bs[q] = bins[(unsigned)(k[q] >> sshift) & (SB - 1)];
+          stage[bs[q] + r[q]] = k[q];
+          aux[bs[q] + r[q]] = 0;
+        }
+      }
+      __syncthreads();
+      // Triangular pass over the (tiny) bins: every key meets the keys in EARLIER slots of its bin exactly once.
+      // An earlier key that is smaller adds to this key's rank; one that is larger gets its own rank bumped (LDS
+      // atomic); an equal one — the first hit of the ascending walk is that key's first occurrence — makes this
+      // key a duplicate: it adds itself to the first occurrence's counter and drops out.  The eight keys of a lane
+      // advance together (eight independent LDS reads per step instead of eight latency-bound loops).
+      unsigned active = 0, dup = 0;
+      unsigned lt[FN_ITEMS];
+#pragma unroll
+      for (int q = 0; q < FN_ITEMS; ++q) {
+        lt[q] = 0;
+        if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
+      }
+      for (unsigned step = 0; __any(active != 0); ++step) {
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          if ((active >> q) & 1u) {
+            const unsigned j = bs[q] + step;
+            const uint64_t y = stage[j];
+            if (y == k[q]) { atomicAdd(&aux[j], 0x10000u); dup |= 1u << q; active &= ~(1u << q); }
+            else {
+              if (y < k[q]) ++lt[q]; else atomicAdd(&aux[j], 1u);
+              if (step + 1 >= r[q]) active &= ~(1u << q);
+            }
+          }
+        }
+      }
+      {
+        const unsigned nd = wave_sum((unsigned)__popc(dup));
+        if (lane == 0 && nd) atomicAdd(&sh_dups[parity], nd);
+      }
+      __syncthreads();
+      const unsigned n_dups = sh_dups[parity];
+      D = (unsigned)nb - n_dups;                       // distinct keys of the bucket
+      const unsigned first_bits = valid & ~dup;
+      unsigned idx[FN_ITEMS];
+      if (n_dups == 0) {                               // uniform: the common case for well-spread k-mers
+        if (wave == 0) {
+          const long long base = look_back(cur.b, D);
+          if (lane == 0) sh[1] = base;
+        }
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q)
+          if ((valid >> q) & 1u) idx[q] = bs[q] + lt[q] + (aux[bs[q] + r[q]] & 0xffffu);
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q)
+          if ((valid >> q) & 1u) stage[idx[q]] = k[q];
+      } else {
+        // Buckets with duplicates: the first occurrences (bit mask + popcount prefix) are compacted to the front of
+        // the stage in slot order (bins stay contiguous) and ranked among themselves, so the work per key does not
+        // grow with the multiplicities; a first occurrence's multiplicity is 1 + the duplicates that found it above.
+        all_one = false;
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          const unsigned slot = bs[q] + r[q];
+          if ((first_bits >> q) & 1u) atomicOr(&fmask32[slot >> 5], 1u << (slot & 31));
+        }
+        __syncthreads();
+        // every wavefront scans the popcounts of the mask words in its own registers (lane l: words FN_WPL*l ..)
+        const unsigned c0 = __popcll(fmask[FN_WPL * lane]);
+        const unsigned c1 = FN_WPL == 2 ? __popcll(fmask[FN_WPL * lane + 1]) : 0u;
+        const unsigned pinc = wave_inclusive_scan(c0 + c1);
+        const unsigned pex = pinc - c0 - c1;
+        if (wave == 0) {
+          const long long base = look_back(cur.b, D);
+          if (lane == 0) sh[1] = base;
+        }
+        auto distinct_before = [&](unsigned x) -> unsigned {   // first occurrences in slots < x (all lanes must call)
+          const unsigned w = min(x >> 6, (unsigned)FN_WORDS - 1);
+          const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
+          const uint64_t below = x >= (unsigned)FN_CAP ? ~0ull : ((1ull << (x & 63)) - 1ull);
+          return pw + ((FN_WPL == 2 && (w & 1)) ? cw : 0u) + __popcll(fmask[w] & below);
+        };
+        unsigned todo = 0;                             // idx[q] = compact start of the bin, r[q] = first occurrences in it,
+#pragma unroll                                         // lt[q] = compact slot | multiplicity << 16
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          const bool is_first = (first_bits >> q) & 1u;
+          unsigned e = bs[q];
+          if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
+          const unsigned slot = bs[q] + r[q];
+          const unsigned cs = distinct_before(bs[q]), ce = distinct_before(e), c = distinct_before(slot);
+          const unsigned m = is_first ? 1u + (aux[slot] >> 16) : 0u;
+          idx[q] = cs;
+          r[q] = is_first ? ce - cs : 0u;
+          lt[q] = c | (m << 16);
+          if (is_first && ce - cs > 1) todo |= 1u << q;
+        }
+        __syncthreads();                               // every lane has read its slot's counter
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q)
+          if ((first_bits >> q) & 1u) stage[lt[q] & 0xffffu] = k[q];
+        __syncthreads();
+        for (unsigned step = 0; __any(todo != 0); ++step) {            // rank inside the compacted bin, in r[q] >> 16
+#pragma unroll
+          for (int q = 0; q < FN_ITEMS; ++q) {
+            if ((todo >> q) & 1u) {
+              r[q] += (stage[idx[q] + step] < k[q]) ? 0x10000u : 0u;
+              if (step + 1 >= (r[q] & 0xffffu)) todo &= ~(1u << q);
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          if ((first_bits >> q) & 1u) {
+            stage[idx[q] + (r[q] >> 16)] = k[q];
+            aux[idx[q] + (r[q] >> 16)] = lt[q] >> 16;
+          }
+        }
+        if (tid < FN_WORDS) fmask[tid] = 0;
+        // (the prefetched keys of the next bucket are loaded again here, so that their registers are free
+        // throughout this rarely taken branch)
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          const int i = tid + q * FN_THREADS;
+          if (i < nxt.nb) kn[q] = A[nxt.lo + i];
         }
       }
     }
-    const unsigned first_bits = valid & ~dup;
+    // ---- tail: this bucket's bins are free; the next bucket takes its ranks in the other bin array (zeroed one
+    // iteration ago), so its counting sort can start right after the output below
+    for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
+    if (tid == 0) sh_dups[parity ^ 1] = 0;
+    valid = 0;
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
-      if ((dup >> q) & 1u) stage[p[q]] = k[q] | ~KEYMASK;
-      if ((first_bits >> q) & 1u) atomicOr(&fmask32[p[q] >> 5], 1u << (p[q] & 31));
-    }
-    __syncthreads();
-    // every wavefront scans the popcounts of the mask words in its own registers (lane l: words FN_WPL*l ..)
-    const unsigned c0 = __popcll(fmask[FN_WPL * lane]);
-    const unsigned c1 = FN_WPL == 2 ? __popcll(fmask[FN_WPL * lane + 1]) : 0u;
-    const unsigned pinc = wave_inclusive_scan(c0 + c1);
-    const unsigned pex = pinc - c0 - c1;
-    const unsigned D = (unsigned)__builtin_amdgcn_readlane((int)pinc, 63);      // distinct keys of the bucket
-    if (wave == 0) {
-      const long long base = look_back(cur.b, D);
-      if (lane == 0) sh[1] = base;
-    }
-    // multiplicity and sorted position of every distinct key (the lane shuffles run with all lanes active)
-    unsigned idx[FN_ITEMS], mult[FN_ITEMS], len[FN_ITEMS];
-    unsigned todo = 0;
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      const bool is_first = (first_bits >> q) & 1u;
-      unsigned e = 0;
-      if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
-      const unsigned s = bs[q];
-      const unsigned w = s >> 6;                       // distinct keys before the bin = prefix of mask word w + bits below s
-      const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
-      idx[q] = mult[q] = len[q] = 0;
-      if (is_first) {
-        idx[q] = pw + ((FN_WPL == 2 && (w & 1)) ? cw : 0u) + __popcll(fmask[w] & ((1ull << (s & 63)) - 1ull));
-        len[q] = e - s;
-        todo |= 1u << q;
+      const int i = tid + q * FN_THREADS;
+      if (i < nxt.nb) {
+        k[q] = kn[q];
+        r[q] = atomicAdd(&bins_next[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
+        valid |= 1u << q;
       }
     }
-    for (unsigned step = 0; __any(todo != 0); ++step) {
-#pragma unroll
-      for (int q = 0; q < FN_ITEMS; ++q) {
-        if ((todo >> q) & 1u) {
-          const uint64_t y = stage[bs[q] + step];
-          mult[q] += ((y & KEYMASK) == k[q]);
-          idx[q] += (y < k[q]);                        // marked duplicates (bit 63) compare greater: not counted
-          if (step + 1 >= len[q]) todo &= ~(1u << q);
-        }
-      }
-    }
+    nn_b = sh[0];                                      // ticket of the bucket after the next one ...
+    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      if ((first_bits >> q) & 1u) {
-        stage[idx[q]] = k[q];
-        cnt16[idx[q]] = (unsigned short)mult[q];
-      }
-    }
-    for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;      // ready for the next bucket
-    if (tid < FN_WORDS) fmask[tid] = 0;
-    __syncthreads();
+    if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);   // ... and one more for the iteration after
     const int64_t base = sh[1];
-    for (unsigned i = tid; i < D; i += FN_THREADS) {
-      keys_out[base + i] = stage[i];
-      counts_out[base + i] = cnt16[i];
+    if (all_one) {
+      for (unsigned i = tid; i < D; i += FN_THREADS) {
+        keys_out[base + i] = stage[i];
+        counts_out[base + i] = 1;
+      }
+    } else {
+      for (unsigned i = tid; i < D; i += FN_THREADS) {
+        keys_out[base + i] = stage[i];
+        counts_out[base + i] = aux[i];
+      }
     }
+    unsigned* t = bins; bins = bins_next; bins_next = t;
+    parity ^= 1;
+    cur = nxt;
   }
 }
 
