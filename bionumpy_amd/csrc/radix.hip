@@ -508,7 +508,7 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
 // is sorted in LDS, its duplicates are counted and the distinct (key, count) pairs are written in sorted order.
 // Single pass: buckets are handed out in ticket order; the output offset of a bucket (= number of distinct keys
 // in all earlier buckets) comes from a decoupled look-back over one 64-bit {flag, value} word per bucket, walked
-// by wavefront 0 (128 predecessors per round) while the other wavefronts rank the bucket's keys, so its latency
+// by wavefront 0 (64 predecessors per poll) while the other wavefronts rank the bucket's keys, so its latency
 // is hidden.  The next bucket's keys are loaded while the current one is processed.
 constexpr int FN_THREADS = 1024;
 constexpr int FN_CAP = 8192;
@@ -518,7 +518,7 @@ constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
 constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask words
 constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
 constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
-constexpr int FN_LB = 2;                             // look-back: status words read per lane and round (window 128)
+constexpr int FN_LB = 1;                             // look-back: status words read per lane and poll (window 64; wider windows cost registers)
 static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
 // d_state words: [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
 // [2] number of distinct keys, [8 + b] status word of bucket b
@@ -536,6 +536,14 @@ constexpr size_t FN_OFF_MASK = FN_OFF_AUX + (size_t)FN_CAP * 4;
 constexpr size_t FN_OFF_WSUM = FN_OFF_MASK + (size_t)FN_WORDS * 8;
 constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
 constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
+
+// a value every lane holds identically -> scalar registers (the compiler cannot prove that what was read from LDS /
+// global memory is wave-uniform and would keep it in vector registers)
+__device__ __forceinline__ int64_t fn_uniform(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 
 struct fn_bucket {
   int64_t b, lo;
@@ -647,8 +655,8 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   __syncthreads();
   fn_bucket cur;
   {
-    const int64_t b0 = sh[0];
-    cur = fn_open(n_buckets, b0, b0 < n_buckets ? bucket_off[b0] : 0, b0 < n_buckets ? bucket_off[b0 + 1] : 0);
+    const int64_t b0 = fn_uniform(sh[0]);
+    cur = fn_open(n_buckets, b0, b0 < n_buckets ? fn_uniform(bucket_off[b0]) : 0, b0 < n_buckets ? fn_uniform(bucket_off[b0 + 1]) : 0);
   }
   uint64_t k[FN_ITEMS];
   unsigned r[FN_ITEMS];
@@ -665,7 +673,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   __syncthreads();                                    // the ranks are taken
   if (tid == 0) sh[2] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
   __syncthreads();
-  int64_t nn_b = sh[2], nn_lo = 0, nn_hi = 0;          // the bucket after `cur`: ticket + offsets
+  int64_t nn_b = fn_uniform(sh[2]), nn_lo = 0, nn_hi = 0;          // the bucket after `cur`: ticket + offsets
   if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
   unsigned parity = 0;
 
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     const int nb = cur.nb;
     if (tid == 0 && cur.over) atomicOr(&state[FS_FLAGS], 1ull);
     // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
-    const fn_bucket nxt = fn_open(n_buckets, nn_b, nn_lo, nn_hi);
+    const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi));
     uint64_t kn[FN_ITEMS];
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
@@ -857,9 +865,9 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     }
     if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);   // this iteration's ticket: the bucket after the next one
     __syncthreads();
-    nn_b = sh[0];
-    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
-    const int64_t base = sh[1];
+    nn_b = fn_uniform(sh[0]);
+    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }   // consumed (made scalar) next iteration
+    const int64_t base = fn_uniform(sh[1]);
     if (all_one) {
       for (unsigned i = tid; i < D; i += FN_THREADS) {
         keys_out[base + i] = stage[i];

@@ -349,7 +349,7 @@ class HipOps:
             cap = int(lib.bnpk_finish_capacity())
             for _ in range(2):
                 largest = int((offsets[1:] - offsets[:-1]).max().item())
-                bits = min(11, key_bits - skip - done, max(1, (2 * largest // cap).bit_length()))
+                bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
                 if largest <= cap or bits <= 0:
                     break
                 out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
