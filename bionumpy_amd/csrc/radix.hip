@@ -533,7 +533,8 @@ constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS + 4) * 4;
 constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;                      // two bin arrays (ping-pong between buckets)
 constexpr size_t FN_OFF_AUX = FN_OFF_BINS + 2 * FN_BINS_BYTES;          // per slot {rank increments : 16 | duplicates seen : 16}
 constexpr size_t FN_OFF_MASK = FN_OFF_AUX + (size_t)FN_CAP * 4;
-constexpr size_t FN_OFF_WSUM = FN_OFF_MASK + (size_t)FN_WORDS * 8;
+constexpr size_t FN_OFF_LIST = FN_OFF_MASK + (size_t)FN_WORDS * 8;       // per wavefront: slots of the keys with long walks
+constexpr size_t FN_OFF_WSUM = FN_OFF_LIST + (size_t)FN_CAP * 2;
 constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
 constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
 
@@ -579,6 +580,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   unsigned* bins_next = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS + FN_BINS_BYTES);   // ... of the one after it
   unsigned* aux = reinterpret_cast<unsigned*>(smem + FN_OFF_AUX);
   unsigned long long* fmask = reinterpret_cast<unsigned long long*>(smem + FN_OFF_MASK);
+  unsigned short* wlist = reinterpret_cast<unsigned short*>(smem + FN_OFF_LIST) + (threadIdx.x >> 6) * (FN_ITEMS * 64);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
   long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base, [2] 2nd ticket
   unsigned* sh_dups = reinterpret_cast<unsigned*>(sh + 4);              // duplicate counters, alternating between buckets
@@ -680,6 +682,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   while (cur.b < n_buckets) {
     const int nb = cur.nb;
     if (tid == 0 && cur.over) atomicOr(&state[FS_FLAGS], 1ull);
+
     // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
     const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi));
     uint64_t kn[FN_ITEMS];
@@ -743,7 +746,8 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         lt[q] = 0;
         if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
       }
-      for (unsigned step = 0; __any(active != 0); ++step) {
+      // Two dense steps (most walks are that short) ...
+      for (unsigned step = 0; step < 2 && __any(active != 0); ++step) {
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
           if ((active >> q) & 1u) {
@@ -761,9 +765,46 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         const unsigned nd = wave_sum((unsigned)__popc(dup));
         if (lane == 0 && nd) atomicAdd(&sh_dups[parity], nd);
       }
+      // ... then the few keys with longer walks (~10 %) are compacted into a list private to the wavefront, ONE
+      // per lane, instead of sweeping all eight register slots of every lane for a handful of stragglers.  Their
+      // results travel through LDS: rank increments in aux (low half), "I am a duplicate" in bit 31.
+      if (__any(active != 0)) {                        // wave-uniform
+        unsigned n_items = 0;
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q) {
+          const bool a = (active >> q) & 1u;
+          const uint64_t m = __ballot(a);
+          if (a) wlist[n_items + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(bs[q] + r[q]);
+          n_items += (unsigned)__popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (unsigned i0 = 0; i0 < n_items; i0 += 64) {
+          if (i0 + lane < n_items) {
+            const unsigned slot = wlist[i0 + lane];
+            const uint64_t x = stage[slot];
+            const unsigned b0 = bins[(unsigned)(x >> sshift) & (SB - 1)];
+            for (unsigned j = b0 + 2; j < slot; ++j) {
+              const uint64_t y = stage[j];
+              if (y == x) {
+                atomicAdd(&aux[j], 0x10000u);
+                atomicOr(&aux[slot], 0x80000000u);
+                atomicAdd(&sh_dups[parity], 1u);
+                break;
+              }
+              atomicAdd(&aux[y < x ? slot : j], 1u);
+            }
+          }
+        }
+      }
       __syncthreads();
       const unsigned n_dups = sh_dups[parity];
       D = (unsigned)nb - n_dups;                       // distinct keys of the bucket
+      if (n_dups) {                                    // uniform: duplicates found by the list walkers above
+#pragma unroll
+        for (int q = 0; q < FN_ITEMS; ++q)
+          if (((valid >> q) & 1u) && (aux[bs[q] + r[q]] >> 31)) dup |= 1u << q;
+      }
       const unsigned first_bits = valid & ~dup;
       unsigned idx[FN_ITEMS];
       if (n_dups == 0) {                               // uniform: the common case for well-spread k-mers
@@ -811,7 +852,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
           if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
           const unsigned slot = bs[q] + r[q];
           const unsigned cs = distinct_before(bs[q]), ce = distinct_before(e), c = distinct_before(slot);
-          const unsigned m = is_first ? 1u + (aux[slot] >> 16) : 0u;
+          const unsigned m = is_first ? 1u + ((aux[slot] >> 16) & 0x7fffu) : 0u;
           idx[q] = cs;
           r[q] = is_first ? ce - cs : 0u;
           lt[q] = c | (m << 16);
@@ -863,7 +904,11 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         valid |= 1u << q;
       }
     }
-    if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);   // this iteration's ticket: the bucket after the next one
+    // This iteration's ticket (the bucket after the next one).  Taken by wavefront 0 AFTER its look-back: the
+    // order of the tickets then follows the order in which the buckets complete, which keeps the rounds intact
+    // (taken by another wavefront, or earlier in the iteration, the launch becomes unstable: 35-44 / 57-67 ms
+    // instead of 37.4 per 3e9 keys).
+    if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
     __syncthreads();
     nn_b = fn_uniform(sh[0]);
     if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }   // consumed (made scalar) next iteration
