@@ -503,6 +503,89 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   return BNPK_OK;
 }
 
+// ---- one more level over MANY SMALL segments ------------------------------------------------------------------------
+// When some buckets come out larger than the finishing kernel's capacity (skewed / duplicate-heavy keys) the host
+// splits all of them once more by a few bits.  With ~10^6 segments of a few thousand keys the slab kernels above
+// spend their time on per-slab setup and unaligned edge lines; here one workgroup takes a whole segment (at most
+// RS_CAP keys) into registers, ranks the keys with wave ballots (no atomics: match lanes with the same digit),
+// groups them in LDS and writes the segment back as one contiguous run.
+constexpr int RS_THREADS = 1024;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_CAP = RS_THREADS * RS_ITEMS;           // 16384 keys = 128 KiB
+constexpr int RS_MAXBITS = 4;
+constexpr int RS_MAXB = 1 << RS_MAXBITS;
+
+__global__ __launch_bounds__(RS_THREADS) void rp_split_small_kernel(const uint64_t* __restrict__ keys,
+                                                                    const int64_t* __restrict__ seg_off, int64_t n_seg,
+                                                                    int shift, int bits, uint64_t* __restrict__ out,
+                                                                    int64_t* __restrict__ child_off,
+                                                                    unsigned long long* __restrict__ too_big) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* stage = reinterpret_cast<uint64_t*>(smem);                               // RS_CAP keys
+  unsigned* wcnt = reinterpret_cast<unsigned*>(smem + (size_t)RS_CAP * 8);          // [digit][wave] counts -> offsets
+  unsigned* dstart = wcnt + RS_MAXB * (RS_THREADS / 64);                            // [digit] start inside the segment
+  const int B = 1 << bits;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = RS_THREADS / 64;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
+    const int64_t lo = seg_off[seg], hi = seg_off[seg + 1];
+    int n = (int)min(hi - lo, (int64_t)RS_CAP + 1);
+    if (n > RS_CAP) {                                  // (the host only calls this for small segments)
+      if (tid == 0) atomicOr(too_big, 1ull);
+      n = RS_CAP;
+    }
+    for (int i = tid; i < RS_MAXB * NW; i += RS_THREADS) wcnt[i] = 0;
+    __syncthreads();
+    uint64_t k[RS_ITEMS];
+    unsigned pos[RS_ITEMS];                            // digit << 16 | rank among the wavefront's keys of that digit
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; ++q) {
+      const int i = tid + q * RS_THREADS;
+      const bool ok = i < n;
+      k[q] = ok ? keys[lo + i] : 0ull;
+      const unsigned d = (unsigned)(k[q] >> shift) & (B - 1);
+      uint64_t m = __ballot(ok);                       // lanes of this wavefront holding the same digit
+      for (int b = 0; b < bits; ++b) {
+        const uint64_t bb = __ballot((d >> b) & 1u);
+        m &= ((d >> b) & 1u) ? bb : ~bb;
+      }
+      pos[q] = 0;
+      if (ok) {
+        const unsigned before = wcnt[d * NW + wave];   // every lane of the group reads, then its first lane adds
+        pos[q] = (d << 16) | (before + (unsigned)__popcll(m & lt_mask));
+        __builtin_amdgcn_wave_barrier();
+        if ((m & lt_mask) == 0) wcnt[d * NW + wave] = before + (unsigned)__popcll(m);
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    if (wave == 0) {                                   // exclusive scan over (digit, wave): B * 16 <= 256 entries
+      unsigned run = 0;
+      for (int base = 0; base < B * NW; base += 64) {
+        const unsigned c = wcnt[base + lane];
+        const unsigned inc = wave_inclusive_scan(c);
+        wcnt[base + lane] = run + inc - c;
+        run += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+      }
+    }
+    __syncthreads();
+    if (tid < B) {
+      dstart[tid] = wcnt[tid * NW];
+      child_off[seg * B + tid] = lo + wcnt[tid * NW];
+    }
+#pragma unroll
+    for (int q = 0; q < RS_ITEMS; ++q) {
+      const int i = tid + q * RS_THREADS;
+      if (i < n) stage[wcnt[(pos[q] >> 16) * NW + wave] + (pos[q] & 0xffffu)] = k[q];
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += RS_THREADS) out[lo + i] = stage[i];
+    __syncthreads();
+  }
+}
+
 // ===================================================================================================================
 // Finishing kernel: every bucket of the partitioned keys (equal top bits, <= FN_CAP keys, arbitrary order inside)
 // is sorted in LDS, its duplicates are counted and the distinct (key, count) pairs are written in sorted order.
@@ -963,6 +1046,41 @@ int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t
   kmer_source src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
   return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
                   "kmers_partition_hist", "kmers_partition_scatter", s);
+}
+
+int64_t bnpk_radix_small_capacity(void) { return RS_CAP; }
+
+int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets,
+                               int64_t n_seg, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets,
+                               void* stream) {
+  if (!ctx || n < 0 || n_seg < 1 || bits < 1 || bits > RS_MAXBITS || shift < 0 || shift + bits > 63 || !d_seg_offsets ||
+      !d_child_offsets)
+    return BNPK_ERR_ARG;
+  if (n > 0 && (!d_keys || !d_out || d_keys == d_out)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, 64, &scratch));
+  const size_t lds = (size_t)RS_CAP * 8 + (size_t)RS_MAXB * (RS_THREADS / 64) * 4 + RS_MAXB * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_split_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  BNPK_HIP(ctx, hipMemsetAsync(scratch, 0, 8, s));
+  {
+    bnpk_timer t(ctx, "radix_split_small", s);
+    const unsigned grid = (unsigned)std::min<int64_t>(n_seg, (int64_t)ctx->compute_units * 8);
+    hipLaunchKernelGGL(rp_split_small_kernel, dim3(grid), dim3(RS_THREADS), lds, s, reinterpret_cast<const uint64_t*>(d_keys),
+                       d_seg_offsets, n_seg, shift, bits, reinterpret_cast<uint64_t*>(d_out), d_child_offsets,
+                       reinterpret_cast<unsigned long long*>(scratch));
+    BNPK_HIP(ctx, hipGetLastError());
+    // the last boundary
+    BNPK_HIP(ctx, hipMemcpyAsync(d_child_offsets + (n_seg << bits), d_seg_offsets + n_seg, 8, hipMemcpyDeviceToDevice, s));
+  }
+  unsigned long long flag = 0;
+  BNPK_HIP(ctx, hipMemcpyAsync(&flag, scratch, 8, hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  return flag ? BNPK_ERR_RANGE : BNPK_OK;
 }
 
 int64_t bnpk_finish_state_words(int64_t n_buckets) { return FS_BUCKETS + std::max<int64_t>(n_buckets, 0) + 1; }

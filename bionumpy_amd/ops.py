@@ -352,7 +352,15 @@ class HipOps:
                 bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
                 if largest <= cap or bits <= 0:
                     break
-                out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
+                if bits <= 4 and n_seg > 4096 and largest <= int(lib.bnpk_radix_small_capacity()):
+                    out = spare if spare is not None else self._empty(n, np.int64)
+                    child = self._empty(n_seg * (1 << bits) + 1, np.int64)
+                    self._chk(lib.bnpk_radix_partition_small(self.ctx, ptr(cur), n, ptr(offsets), n_seg,
+                                                             key_bits - skip - done - bits, bits, ptr(out), ptr(child),
+                                                             self._s()))
+                    offsets = child
+                else:
+                    out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
                 spare = cur if owned else None
                 cur, owned = out, True
                 done += bits

@@ -245,6 +245,13 @@ int64_t bnpk_radix_max_bits(void);
 int64_t bnpk_finish_capacity(void);
 int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
                          int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
+/* one more MSD level over MANY SMALL segments (each at most bnpk_radix_small_capacity() keys, bits <= 4): one
+ * workgroup takes a whole segment, ranks with wave ballots and writes it back as one contiguous run.  Same
+ * outputs as bnpk_radix_partition; BNPK_ERR_RANGE if a segment was larger (outputs then invalid). */
+int64_t bnpk_radix_small_capacity(void);
+int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets,
+                               int64_t n_seg, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets,
+                               void* stream);
 int64_t bnpk_finish_state_words(int64_t n_buckets);
 int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,

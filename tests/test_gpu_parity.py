@@ -356,3 +356,32 @@ def test_pipeline_on_two_line_fasta(ops):
         ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lens, k)[0])
         assert stats.n_reads == 4000 and stats.n_bases == codes.size
         assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+
+
+@pytest.mark.parametrize("seed,n,first_bits,bits", [(1, 200_000, 6, 1), (2, 3_000_000, 10, 2), (3, 1_000_000, 8, 4),
+                                                    (4, 50_000, 10, 3)])
+def test_radix_partition_small_segments(ops, seed, n, first_bits, bits):
+    """bnpk_radix_partition_small (one workgroup per small segment, wave-ballot ranks) == the generic level:
+    same child offsets, same multiset in every child bucket (empty and single-key segments included)"""
+    import ctypes as C
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import ptr
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, 1 << 40, size=n, dtype=np.int64)
+    keys[rng.integers(0, n, size=min(n // 20, 3000))] = keys[3]           # a heavy hitter that still fits a segment
+    cur, offsets = ops.radix_partition(_h(keys).dev(), None, 1, 40 - first_bits, first_bits)
+    n_seg = 1 << first_bits
+    sizes = np.diff(offsets.cpu().numpy())
+    if sizes.max() > lib.bnpk_radix_small_capacity():
+        pytest.skip("a segment exceeds the small-segment capacity for this seed")
+    out = ops._empty(n, np.int64)
+    child = ops._empty(n_seg * (1 << bits) + 1, np.int64)
+    ops._chk(lib.bnpk_radix_partition_small(ops.ctx, ptr(cur), n, ptr(offsets), n_seg, 40 - first_bits - bits, bits,
+                                            ptr(out), ptr(child), ops._s()))
+    ref, ref_child = ops.radix_partition(cur, offsets, n_seg, 40 - first_bits - bits, bits)
+    assert np.array_equal(child.cpu().numpy(), ref_child.cpu().numpy())
+    got, want, co = out.cpu().numpy(), ref.cpu().numpy(), child.cpu().numpy()
+    top = got >> (40 - first_bits - bits)
+    assert np.all(np.diff(top) >= 0)
+    assert np.array_equal(np.sort(got), np.sort(want))
+    assert np.array_equal(co, np.searchsorted(top, np.arange(n_seg * (1 << bits) + 1)))
