@@ -656,7 +656,10 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
                                                                    int64_t n_buckets, int sshift, int sbits,
                                                                    unsigned long long* __restrict__ state,
                                                                    uint64_t* __restrict__ keys_out,
-                                                                   int64_t* __restrict__ counts_out) {
+                                                                   int64_t* __restrict__ counts_out,
+                                                                   const int64_t* __restrict__ big_table, int n_big,
+                                                                   const uint64_t* __restrict__ big_keys,
+                                                                   const int64_t* __restrict__ big_counts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);            // bins of the bucket being sorted
@@ -764,7 +767,23 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 
   while (cur.b < n_buckets) {
     const int nb = cur.nb;
-    if (tid == 0 && cur.over) atomicOr(&state[FS_FLAGS], 1ull);
+    // A bucket over capacity (heavy-hitter k-mers) has been counted by the caller beforehand: big_table holds
+    // {bucket, distinct keys, offset into big_keys / big_counts} triples sorted by bucket.
+    int64_t big_src = -1;
+    unsigned big_D = 0;
+    if (cur.over) {                                    // uniform
+      int lo_i = 0, hi_i = n_big;
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (big_table[3 * mid] < cur.b) lo_i = mid + 1; else hi_i = mid;
+      }
+      if (lo_i < n_big && big_table[3 * lo_i] == cur.b) {
+        big_D = (unsigned)fn_uniform(big_table[3 * lo_i + 1]);
+        big_src = fn_uniform(big_table[3 * lo_i + 2]);
+      } else if (tid == 0) {
+        atomicOr(&state[FS_FLAGS], 1ull);
+      }
+    }
 
     // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
     const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi));
@@ -777,8 +796,9 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     unsigned D = 0;
     bool all_one = true;                               // every multiplicity of the bucket is 1
     if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
+      D = big_D;
       if (wave == 0) {
-        const long long base = look_back(cur.b, 0u);
+        const long long base = look_back(cur.b, D);
         if (lane == 0) sh[1] = base;
       }
       __syncthreads();                                 // keeps the reads of the ticket word a barrier away from its next write
@@ -996,7 +1016,12 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     nn_b = fn_uniform(sh[0]);
     if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }   // consumed (made scalar) next iteration
     const int64_t base = fn_uniform(sh[1]);
-    if (all_one) {
+    if (big_src >= 0) {                                // pre-counted bucket: copy its (key, count) pairs into place
+      for (unsigned i = tid; i < D; i += FN_THREADS) {
+        keys_out[base + i] = big_keys[big_src + i];
+        counts_out[base + i] = big_counts[big_src + i];
+      }
+    } else if (all_one) {
       for (unsigned i = tid; i < D; i += FN_THREADS) {
         keys_out[base + i] = stage[i];
         counts_out[base + i] = 1;
@@ -1087,9 +1112,10 @@ int64_t bnpk_finish_state_words(int64_t n_buckets) { return FS_BUCKETS + std::ma
 
 int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                       const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream) {
   if (!ctx || n < 0 || n_buckets < 1 || low_bits < 0 || low_bits > 63 || !h_n_unique || !h_overflow || !d_state ||
-      !d_bucket_offsets)
+      !d_bucket_offsets || n_big < 0 || (n_big > 0 && (!d_big_table || !d_big_keys || !d_big_counts)))
     return BNPK_ERR_ARG;
   *h_n_unique = 0;
   *h_overflow = 0;
@@ -1112,7 +1138,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
     hipLaunchKernelGGL(finish_sorted_kernel, dim3(grid), dim3(FN_THREADS), FN_LDS, s,
                        reinterpret_cast<const uint64_t*>(d_part), d_bucket_offsets, n_buckets, sshift, sbits,
                        reinterpret_cast<unsigned long long*>(d_state), reinterpret_cast<uint64_t*>(d_keys_out),
-                       d_counts_out);
+                       d_counts_out, d_big_table, n_big, reinterpret_cast<const uint64_t*>(d_big_keys), d_big_counts);
     BNPK_HIP(ctx, hipGetLastError());
   }
   int64_t host[3] = {0, 0, 0};

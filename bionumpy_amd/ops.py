@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _native
 from ._native import lib, check, NONE
-from .device import Device, HArray, ptr
+from .device import Device, HArray, ptr, torch as torch_mod
 from .exceptions import EncodingError
 from .exceptions import FormatException, IncompleteEntryException
 
@@ -344,13 +344,23 @@ class HipOps:
                 n_seg <<= bits
             if offsets is None:
                 offsets = self.device.upload(np.array([0, n], dtype=np.int64))
-            # the plan assumes well-spread keys; real bucket sizes decide: a bucket over the finishing kernel's
-            # capacity gets (at most two) extra levels sized from the largest bucket
+            # The plan assumes well-spread keys; the real bucket sizes decide.  MANY buckets over the finishing
+            # kernel's capacity (skewed / duplicate-heavy keys): up to two extra levels sized from the largest
+            # bucket.  A FEW (heavy-hitter k-mers: extra levels cannot split equal keys): those buckets are
+            # counted here, one by one, with the sort + run kernels and handed to the finishing kernel as
+            # ready-made (key, count) runs.
             cap = int(lib.bnpk_finish_capacity())
-            for _ in range(2):
-                largest = int((offsets[1:] - offsets[:-1]).max().item())
+            big = None
+            for attempt in range(3):
+                sizes = offsets[1:] - offsets[:-1]
+                largest = int(sizes.max().item())
+                if largest <= cap:
+                    break
+                over = (sizes > cap).nonzero().flatten()
                 bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
-                if largest <= cap or bits <= 0:
+                if over.numel() <= self.MAX_PRECOUNTED or attempt == 2 or bits <= 0:
+                    if over.numel() <= self.MAX_PRECOUNTED:
+                        big = self._precount_buckets(cur, offsets, over, key_bits)
                     break
                 if bits <= 4 and n_seg > 4096 and largest <= int(lib.bnpk_radix_small_capacity()):
                     out = spare if spare is not None else self._empty(n, np.int64)
@@ -369,13 +379,22 @@ class HipOps:
             counts = self._empty(n, np.int64)
             state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
             n_unique, overflow = C.c_int64(0), C.c_int(0)
+            table, big_keys, big_counts = big if big is not None else (None, None, None)
             self._chk(lib.bnpk_finish_sorted(self.ctx, ptr(cur), n, ptr(offsets), n_seg, key_bits - skip - done,
-                                             ptr(keys_out), ptr(counts), ptr(state), C.byref(n_unique),
-                                             C.byref(overflow), self._s()))
+                                             ptr(keys_out), ptr(counts), ptr(state), ptr(table),
+                                             0 if table is None else table.numel() // 3, ptr(big_keys), ptr(big_counts),
+                                             C.byref(n_unique), C.byref(overflow), self._s()))
             if not overflow.value:
                 return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
-            del counts, state, keys_out, spare          # heavy-hitter buckets: fall back to the full sort
-        work = cur if owned else cur.clone()
+            del counts, state, keys_out, spare, big     # too many heavy buckets: fall back to the full sort
+        keys_out, counts = self._count_by_sorting(cur if owned else cur.clone(), key_bits)
+        return HArray(dev=keys_out), HArray(dev=counts)
+
+    MAX_PRECOUNTED = 256          # buckets over the finishing kernel's capacity that are counted one by one
+
+    def _count_by_sorting(self, work, key_bits):
+        """(sorted distinct keys, counts) of a torch int64 tensor (consumed): rocPRIM radix sort + run kernels"""
+        n = work.numel()
         sorted_t, free_t = self.sort_keys(work, key_bits)
         n_runs, tile_off = self._runs(sorted_t)
         keys_out = free_t[:n_runs]                       # the ping-pong buffer is free after the sort
@@ -384,7 +403,22 @@ class HipOps:
                                      ptr(starts), self._s()))
         counts = self._empty(n_runs, np.int64)
         self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, None, ptr(counts), self._s()))
-        return HArray(dev=keys_out), HArray(dev=counts)
+        return keys_out, counts
+
+    def _precount_buckets(self, keys_t, offsets_t, bucket_ids_t, key_bits):
+        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets counted with the sort + run kernels"""
+        t = torch_mod()
+        ids = bucket_ids_t.cpu().numpy()
+        bounds = t.stack([offsets_t[bucket_ids_t], offsets_t[bucket_ids_t + 1]]).cpu().numpy()
+        table, all_keys, all_counts, at = [], [], [], 0
+        for j, b in enumerate(ids):
+            k, c = self._count_by_sorting(keys_t[int(bounds[0, j]):int(bounds[1, j])].clone(), key_bits)
+            table += [int(b), int(k.numel()), at]
+            at += int(k.numel())
+            all_keys.append(k.clone())
+            all_counts.append(c)
+        return (self.device.upload(np.array(table, dtype=np.int64)), t.cat(all_keys), t.cat(all_counts))
+
 
     def reduce_by_key(self, keys, weights, key_bits=62):
         """sum of weights per distinct key (merge of sparse histograms; EncodedCounts.__add__ analogue)."""

@@ -238,8 +238,11 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  *   bnpk_finish_sorted    every bucket [d_bucket_offsets[b], d_bucket_offsets[b+1]) (keys equal above bit
  *                         `low_bits`, at most bnpk_finish_capacity() of them, any order) is sorted in LDS,
  *                         run-length-counted and written as sorted distinct keys + multiplicities.  Synchronous:
- *                         returns the number of distinct keys; *h_overflow = 1 means a bucket exceeded the
- *                         capacity and the outputs must be discarded (fall back to bnpk_sort_keys + run kernels).
+ *                         returns the number of distinct keys.  Buckets over the capacity (heavy-hitter keys) must
+ *                         have been counted by the caller beforehand: d_big_table holds n_big {bucket, number of
+ *                         distinct keys, offset into d_big_keys / d_big_counts} int64 triples sorted by bucket;
+ *                         their pairs are copied into place.  *h_overflow = 1 means a bucket exceeded the capacity
+ *                         without being listed: the outputs must be discarded (bnpk_sort_keys + run kernels).
  *                         d_state needs bnpk_finish_state_words(n_buckets) int64. */
 int64_t bnpk_radix_max_bits(void);
 int64_t bnpk_finish_capacity(void);
@@ -255,6 +258,7 @@ int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, 
 int64_t bnpk_finish_state_words(int64_t n_buckets);
 int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                       const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream);
 /* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */
 int64_t bnpk_run_tiles(int64_t n);

@@ -21,7 +21,7 @@ for rep in range(reps):
     nu, ov = C.c_int64(0), C.c_int(0)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 43, ptr(a), ptr(counts), ptr(state), C.byref(nu), C.byref(ov), dev.stream())
+    lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 43, ptr(a), ptr(counts), ptr(state), None, 0, None, None, C.byref(nu), C.byref(ov), dev.stream())
     e1.record(); torch.cuda.synchronize()
     times.append(round(e0.elapsed_time(e1), 2))
 print("finish ms:", times, "n_unique", nu.value)

@@ -28,7 +28,7 @@ for rep in range(reps + 1):
     counts = torch.empty(n, dtype=torch.int64, device="cuda")
     state = torch.empty(lib.bnpk_finish_state_words(nseg), dtype=torch.int64, device="cuda")
     nu, ov = C.c_int64(0), C.c_int(0)
-    lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 62 - b1 - b2, ptr(a), ptr(counts), ptr(state), C.byref(nu), C.byref(ov), dev.stream())
+    lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 62 - b1 - b2, ptr(a), ptr(counts), ptr(state), None, 0, None, None, C.byref(nu), C.byref(ov), dev.stream())
     torch.cuda.synchronize()
     if rep == 0 and not os.environ.get("BNPK_ABLATE"):
         print("n_unique", nu.value, "overflow", ov.value, "sorted", bool((a[1:nu.value] > a[:nu.value - 1]).all().item()))

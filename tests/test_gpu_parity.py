@@ -385,3 +385,16 @@ def test_radix_partition_small_segments(ops, seed, n, first_bits, bits):
     assert np.all(np.diff(top) >= 0)
     assert np.array_equal(np.sort(got), np.sort(want))
     assert np.array_equal(co, np.searchsorted(top, np.arange(n_seg * (1 << bits) + 1)))
+
+
+@pytest.mark.parametrize("n_hot,copies", [(3, 50_000), (300, 9000)])
+def test_heavy_hitter_buckets(ops, n_hot, copies):
+    """a few buckets over the finishing kernel's capacity are counted beforehand and spliced in by the kernel;
+    more than ops.MAX_PRECOUNTED of them take the sort + run fallback — np.unique's answer either way"""
+    rng = np.random.default_rng(n_hot)
+    base = rng.integers(0, 1 << 62, size=400_000).astype(np.int64)
+    hot = np.repeat(rng.integers(0, 1 << 62, size=n_hot).astype(np.int64), copies)
+    v = rng.permutation(np.concatenate([base, hot]))
+    ek, ec = oracle.count_sparse(v)
+    keys, counts = ops.count_sparse(_h(v), key_bits=62)
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
