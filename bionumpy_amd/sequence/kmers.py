@@ -36,9 +36,8 @@ def _rolling(sequence, window, kernel):
     return values, out_off, lens, n_rows, n_out, single
 
 
-def get_kmers(sequence, k):
-    """k-mer hashes of every position of every sequence (sequence/kmers.py:36-87)."""
-    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+def _as_four_letter(sequence):
+    """the encoding checks get_kmers makes (kmers.py:66-81), returning the 2-bit encoded sequence"""
     if sequence.encoding == BaseEncoding:
         try:
             sequence = change_encoding(sequence, DNAEncoding)
@@ -52,6 +51,13 @@ def get_kmers(sequence, k):
     if sequence.encoding.alphabet_size != 4:
         raise NotImplementedError("only 4-letter alphabets (the 2-bit fast path, kmers.py:82-85) are on the "
                                   "MI355X path")
+    return sequence
+
+
+def get_kmers(sequence, k):
+    """k-mer hashes of every position of every sequence (sequence/kmers.py:36-87)."""
+    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    sequence = _as_four_letter(sequence)
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
         sequence, k, lambda ops, p, i, o, n, m: ops.kmers(p, i, o, n, m, k))
     encoding = KmerEncoding(sequence.encoding, k)
@@ -91,6 +97,25 @@ class _LazyLens:
 @streamable(sum)
 def count_kmers(sequence, k, axis=None):
     """count every k-mer (sequence/kmers.py:129-145); k <= 8 gives the reference's dense EncodedCounts,
-    larger k the sparse (sorted unique keys, counts) extension — see count_encoded."""
+    larger k the sparse (sorted unique keys, counts) extension — see count_encoded.
+
+    For the flattened sparse histogram the hashes are never laid out row by row: they are generated straight
+    into the first radix level of the counting sort (bnpk_kmers_partition), as in pipeline.py."""
+    assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    if axis is None and k > 8:
+        from .count_encoded import SparseKmerCounts
+        sequence = _as_four_letter(sequence)
+        ops = get_ops()
+        packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
+        _, n_out = ops.row_offsets(lens, k)
+        if n_out > 0:
+            mask = ops.kmer_start_mask(in_off, n_rows, total, k)
+            levels = ops.radix_plan(n_out, 2 * k)
+            bits = levels[0] if levels else 0
+            hashes, cuts = ops.kmers_partitioned(packed, mask, total, n_out, k, bits)
+            del mask
+            keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True,
+                                            partition=(cuts, bits) if bits else None)
+            return SparseKmerCounts(KmerEncoding(sequence.encoding, k), keys, counts)
     kmers = get_kmers(sequence, k)
     return count_encoded(kmers, axis=axis)

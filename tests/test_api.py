@@ -285,6 +285,21 @@ def test_doc_31mers_of_big_fq(bnp, big_fq_gz):
             "[CGGTAGCCAGCTGCGTTCAGTATGGAAGATT, GGTAGCCAGCTGCGTTCAGTATGGAAGATTT, GTAGCCAGCTGCGTTCAGTATGGAAGATTTG]"
 
 
+def test_count_kmers_fused_equals_get_kmers_then_count(bnp):
+    # count_kmers(axis=None, k > 8) generates the hashes inside the counting sort; same result as the
+    # reference's two-step form (sequence/kmers.py:129-145), rows shorter than k included
+    rng = np.random.default_rng(5)
+    rows = ["".join(rng.choice(list("ACGT"), size=n)) for n in (40, 3, 31, 0 + 12, 150, 30, 64, 65, 11)]
+    sequences = bnp.as_encoded_array(rows, bnp.DNAEncoding)
+    for k in (9, 11, 14, 31):
+        two_step = bnp.count_encoded(bnp.sequence.get_kmers(sequences, k), axis=None)
+        fused = bnp.sequence.count_kmers(sequences, k)
+        assert fused == two_step
+        assert int(fused.counts.sum()) == sum(max(0, len(r) - k + 1) for r in rows)
+    short = bnp.as_encoded_array(["ACGT", "AC"], bnp.DNAEncoding)
+    assert len(bnp.sequence.count_kmers(short, 31)) == 0
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()
