@@ -19,7 +19,7 @@ HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"), os.path
            os.path.join(HERE, "kmer_gen.h"),
            os.path.join(ROOT, "include", "bnpk.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("BNPK_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

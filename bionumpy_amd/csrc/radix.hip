@@ -601,7 +601,6 @@ constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
 constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask words
 constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
 constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
-constexpr int FN_LB = 1;                             // look-back: status words read per lane and poll (window 64; wider windows cost registers)
 static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
 // d_state words: [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
 // [2] number of distinct keys, [8 + b] status word of bucket b
@@ -627,6 +626,13 @@ __device__ __forceinline__ int64_t fn_uniform(int64_t v) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
   return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// the same value, but opaque to the optimiser: what is derived from it is recomputed where it is used (two or three
+// VALU instructions) instead of being hoisted out of the bucket loop and held in — or spilled from — registers
+__device__ __forceinline__ int fn_fresh(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
 
 struct fn_bucket {
@@ -670,64 +676,55 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
   long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base, [2] 2nd ticket
   unsigned* sh_dups = reinterpret_cast<unsigned*>(sh + 4);              // duplicate counters, alternating between buckets
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: scalar
   const unsigned SB = 1u << sbits;
 
   unsigned* fmask32 = reinterpret_cast<unsigned*>(fmask);
   constexpr uint64_t KEYMASK = ~(1ull << 63);
 
-  // publish the bucket's distinct count, return the number of distinct keys in all earlier buckets (wavefront 0)
-  auto look_back = [&](int64_t b, unsigned D) -> long long {
-    unsigned long long* mine = &state[FS_BUCKETS + b];
+  // ---- decoupled look-back, off the critical path.  A bucket's distinct count is published as soon as it is known;
+  // the walk over the predecessors' status words (wavefront 0) starts one phase later — they have published by then:
+  // one poll of the 64 nearest words completes 99 % of the walks — and the poll stays in flight, in a register,
+  // across the barriers until the start of the next iteration, so the latency of the device-scope loads is hidden.
+  // The result is needed when the NEXT bucket is about to be placed in the stage; until then the sorted keys wait
+  // in LDS.  A poll uses every word up to the first one that has not been published yet (nearest predecessor first).
+  // (Measured per 3e9 keys: blocking walk before the final placement 36.0 ms, this 30.1 ms, no look-back at all 27.0;
+  // every wavefront polling for itself: 52 ms — the status words are a hot spot.)
+  auto lb_poll = [&](int64_t top) -> unsigned long long {          // lane l: the status word at distance l behind `top`
+    const unsigned long long* first = state + FS_BUCKETS + (top - 63);   // (scalar; only dereferenced where it is valid)
+    const bool in_range = top >= 63 || lane <= (int)top;
+    return in_range ? __hip_atomic_load(first + (63 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FN_INC;
+  };
+  unsigned long long lb_v = FN_INC;                    // the poll in flight
+  auto lb_resolve = [&](int64_t b) -> long long {      // distinct keys in all buckets before b
     long long base = 0;
-    if (b > 0) {
-      if (lane == 0)
-        __hip_atomic_store(mine, FN_AGG | (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t top = b - 1;
-      unsigned spins = 0;
-      while (true) {
-        // lane l reads the words at distance l, 64 + l, ... behind `top` (distance 0 = nearest predecessor)
-        unsigned long long v[FN_LB];
-        uint64_t incm[FN_LB], badm[FN_LB];
-#pragma unroll
-        for (int m = 0; m < FN_LB; ++m) {
-          const int64_t pp = top - 64 * m - lane;
-          v[m] = (pp >= 0) ? __hip_atomic_load(&state[FS_BUCKETS + pp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FN_INC;
-        }
-        int first_inc = 64 * FN_LB;                    // distance of the nearest inclusive word in the window
-#pragma unroll
-        for (int m = FN_LB - 1; m >= 0; --m) {
-          incm[m] = __ballot((v[m] & ~FN_VALUE) == FN_INC);
-          badm[m] = __ballot((v[m] & ~FN_VALUE) == 0);
-          if (incm[m]) first_inc = 64 * m + __ffsll((long long)incm[m]) - 1;
-        }
-        bool blocked = false;                          // a needed predecessor has not published yet
-#pragma unroll
-        for (int m = 0; m < FN_LB; ++m) {
-          const int rel = first_inc - 64 * m;
-          const uint64_t need = rel >= 63 ? ~0ull : (rel < 0 ? 0ull : ((2ull << rel) - 1ull));
-          blocked |= (badm[m] & need) != 0;
-        }
-        if (blocked) {
-          if (++spins > FN_SPIN_LIMIT) { if (lane == 0) atomicOr(&state[FS_FLAGS], 2ull); break; }
-          __builtin_amdgcn_s_sleep(FN_SLEEP);
-          continue;
-        }
-        long long contrib = 0;
-#pragma unroll
-        for (int m = 0; m < FN_LB; ++m)
-          if (64 * m + lane <= first_inc) contrib += (long long)(v[m] & FN_VALUE);
-        contrib = wave_reduce_sum(contrib);
-        base += __shfl(contrib, 0, 64);
-        if (first_inc < 64 * FN_LB) break;
-        top -= 64 * FN_LB;
+    int64_t top = b - 1;
+    unsigned long long v = lb_v;
+    unsigned spins = 0;
+    while (true) {
+      const uint64_t incm = __ballot((v & ~FN_VALUE) == FN_INC);
+      const uint64_t badm = __ballot((v & ~FN_VALUE) == 0);
+      const int first_inc = incm ? __ffsll((long long)incm) - 1 : 64;
+      const int first_bad = badm ? __ffsll((long long)badm) - 1 : 64;
+      const int use = first_inc < first_bad ? first_inc + 1 : first_bad;    // words usable, nearest first
+      long long contrib = lane < use ? (long long)(v & FN_VALUE) : 0ll;
+      contrib = wave_reduce_sum(contrib);
+      base += fn_uniform(__shfl(contrib, 0, 64));
+      if (first_inc < first_bad) break;
+      top -= use;
+      if (use == 0) {
+        if (++spins > FN_SPIN_LIMIT) { if (lane == 0) atomicOr(&state[FS_FLAGS], 2ull); break; }
+        __builtin_amdgcn_s_sleep(FN_SLEEP);
       }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(mine, FN_INC | (unsigned long long)(base + D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (b == n_buckets - 1) state[FS_UNIQUE] = (unsigned long long)(base + D);
+      v = lb_poll(top);
     }
     return base;
+  };
+
+  // a bucket's own distinct count, published as soon as it is known (nobody waits for the look-back of another bucket)
+  auto publish_count = [&](int64_t b, unsigned D) {
+    if (b > 0 && tid == 0)
+      __hip_atomic_store(&state[FS_BUCKETS + b], FN_AGG | (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
   for (unsigned i = tid; i <= SB; i += FN_THREADS) { bins[i] = 0; bins_next[i] = 0; }
@@ -753,7 +750,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   for (int q = 0; q < FN_ITEMS; ++q) {
     const int i = tid + q * FN_THREADS;
     if (i < cur.nb) {
-      k[q] = A[cur.lo + i];
+      k[q] = (A + cur.lo)[(unsigned)i];
       r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
       valid |= 1u << q;
     }
@@ -764,6 +761,45 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   int64_t nn_b = fn_uniform(sh[2]), nn_lo = 0, nn_hi = 0;          // the bucket after `cur`: ticket + offsets
   if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
   unsigned parity = 0;
+  // The sorted keys of a bucket stay in LDS until the NEXT bucket is about to be placed there: its look-back runs
+  // at the start of the following iteration, so the predecessors have had the rest of an iteration to publish
+  // their counts, and the workgroups no longer wait for the slowest one of every round.
+  bool have_prev = false, prev_one = true;
+  int64_t prev_b = 0, prev_big = -1;
+  unsigned prev_D = 0;
+  auto resolve_prev = [&]() {                          // wavefront 0: where the previous bucket's output goes
+    const long long base = lb_resolve(prev_b);
+    if (lane == 0) {
+      sh[1] = base;
+      __hip_atomic_store(&state[FS_BUCKETS + prev_b], FN_INC | (unsigned long long)(base + prev_D), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (prev_b == n_buckets - 1) state[FS_UNIQUE] = (unsigned long long)(base + prev_D);
+    }
+  };
+  auto emit_prev = [&]() {
+    const int64_t base = fn_uniform(sh[1]);
+    uint64_t* ko = keys_out + base;                    // scalar bases, 32-bit lane offsets
+    int64_t* co = counts_out + base;
+    const unsigned t0 = (unsigned)fn_fresh(tid);
+    if (prev_big >= 0) {                               // pre-counted bucket: copy its (key, count) pairs into place
+      const uint64_t* bk = big_keys + prev_big;
+      const int64_t* bc = big_counts + prev_big;
+      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
+        ko[i] = bk[i];
+        co[i] = bc[i];
+      }
+    } else if (prev_one) {
+      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
+        ko[i] = stage[i];
+        co[i] = 1;
+      }
+    } else {
+      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
+        ko[i] = stage[i];
+        co[i] = aux[i];
+      }
+    }
+  };
 
   while (cur.b < n_buckets) {
     const int nb = cur.nb;
@@ -785,30 +821,34 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       }
     }
 
+    // (before this wavefront's loads of the next keys: the memory counter is in-order, younger loads would be waited for)
+    if (have_prev && wave == 0) resolve_prev();
     // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
     const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi));
     uint64_t kn[FN_ITEMS];
+    {
+      const int t = fn_fresh(tid);
 #pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tid + q * FN_THREADS;
-      if (i < nxt.nb) kn[q] = A[nxt.lo + i];
+      for (int q = 0; q < FN_ITEMS; ++q) {
+        const int i = t + q * FN_THREADS;
+        if (i < nxt.nb) kn[q] = (A + nxt.lo)[(unsigned)i];   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
+      }
     }
     unsigned D = 0;
     bool all_one = true;                               // every multiplicity of the bucket is 1
     if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
       D = big_D;
-      if (wave == 0) {
-        const long long base = look_back(cur.b, D);
-        if (lane == 0) sh[1] = base;
-      }
+      publish_count(cur.b, D);
       __syncthreads();                                 // keeps the reads of the ticket word a barrier away from its next write
+      if (have_prev) emit_prev();
     } else {
       // counting sort on the next sbits bits: exclusive scan of the bin counts, keys to their bins
       {
         unsigned c[FN_BINS_PER_LANE], sum = 0;
+        const int t = fn_fresh(tid);
 #pragma unroll
         for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-          const unsigned bi = tid * FN_BINS_PER_LANE + j;
+          const unsigned bi = t * FN_BINS_PER_LANE + j;
           c[j] = (bi < SB) ? bins[bi] : 0;
           sum += c[j];
         }
@@ -819,12 +859,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         for (int w = 0; w < wave; ++w) run += wsum[w];
 #pragma unroll
         for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-          const unsigned bi = tid * FN_BINS_PER_LANE + j;
+          const unsigned bi = t * FN_BINS_PER_LANE + j;
           if (bi < SB) bins[bi] = run;
           run += c[j];
         }
         if (tid == 0) bins[SB] = (unsigned)nb;
       }
+      if (have_prev) emit_prev();                      // the stage is free for this bucket after the next barrier
       __syncthreads();
       unsigned bs[FN_ITEMS];                           // start of the key's bin; its own slot is bs + r
 #pragma unroll
@@ -901,7 +942,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         }
       }
       __syncthreads();
-      const unsigned n_dups = sh_dups[parity];
+      const unsigned n_dups = (unsigned)__builtin_amdgcn_readfirstlane((int)sh_dups[parity]);
       D = (unsigned)nb - n_dups;                       // distinct keys of the bucket
       if (n_dups) {                                    // uniform: duplicates found by the list walkers above
 #pragma unroll
@@ -910,11 +951,8 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       }
       const unsigned first_bits = valid & ~dup;
       unsigned idx[FN_ITEMS];
+      publish_count(cur.b, D);
       if (n_dups == 0) {                               // uniform: the common case for well-spread k-mers
-        if (wave == 0) {
-          const long long base = look_back(cur.b, D);
-          if (lane == 0) sh[1] = base;
-        }
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q)
           if ((valid >> q) & 1u) idx[q] = bs[q] + lt[q] + (aux[bs[q] + r[q]] & 0xffffu);
@@ -937,10 +975,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         const unsigned c1 = FN_WPL == 2 ? __popcll(fmask[FN_WPL * lane + 1]) : 0u;
         const unsigned pinc = wave_inclusive_scan(c0 + c1);
         const unsigned pex = pinc - c0 - c1;
-        if (wave == 0) {
-          const long long base = look_back(cur.b, D);
-          if (lane == 0) sh[1] = base;
-        }
         auto distinct_before = [&](unsigned x) -> unsigned {   // first occurrences in slots < x (all lanes must call)
           const unsigned w = min(x >> 6, (unsigned)FN_WORDS - 1);
           const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
@@ -989,18 +1023,22 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
           const int i = tid + q * FN_THREADS;
-          if (i < nxt.nb) kn[q] = A[nxt.lo + i];
+          if (i < nxt.nb) kn[q] = (A + nxt.lo)[(unsigned)i];
         }
       }
     }
     // ---- tail: this bucket's bins are free; the next bucket takes its ranks in the other bin array (zeroed one
     // iteration ago), so its counting sort can start right after the output below
-    for (unsigned i = tid; i <= SB; i += FN_THREADS) bins[i] = 0;
+    // the walk over the predecessors' counts starts here: they have had the final placement above to publish, and
+    // the poll has the rest of the iteration to come back
+    if (wave == 0) lb_v = lb_poll(cur.b - 1);
+    const int tt = fn_fresh(tid);
+    for (unsigned i = tt; i <= SB; i += FN_THREADS) bins[i] = 0;
     if (tid == 0) sh_dups[parity ^ 1] = 0;
     valid = 0;
 #pragma unroll
     for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tid + q * FN_THREADS;
+      const int i = tt + q * FN_THREADS;
       if (i < nxt.nb) {
         k[q] = kn[q];
         r[q] = atomicAdd(&bins_next[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
@@ -1015,26 +1053,19 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     __syncthreads();
     nn_b = fn_uniform(sh[0]);
     if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }   // consumed (made scalar) next iteration
-    const int64_t base = fn_uniform(sh[1]);
-    if (big_src >= 0) {                                // pre-counted bucket: copy its (key, count) pairs into place
-      for (unsigned i = tid; i < D; i += FN_THREADS) {
-        keys_out[base + i] = big_keys[big_src + i];
-        counts_out[base + i] = big_counts[big_src + i];
-      }
-    } else if (all_one) {
-      for (unsigned i = tid; i < D; i += FN_THREADS) {
-        keys_out[base + i] = stage[i];
-        counts_out[base + i] = 1;
-      }
-    } else {
-      for (unsigned i = tid; i < D; i += FN_THREADS) {
-        keys_out[base + i] = stage[i];
-        counts_out[base + i] = aux[i];
-      }
-    }
+    have_prev = true;
+    prev_b = cur.b;
+    prev_D = D;
+    prev_one = all_one;
+    prev_big = big_src;
     unsigned* t = bins; bins = bins_next; bins_next = t;
     parity ^= 1;
     cur = nxt;
+  }
+  if (have_prev) {                                     // the last bucket of this workgroup
+    if (wave == 0) resolve_prev();
+    __syncthreads();
+    emit_prev();
   }
 }
 

@@ -24,4 +24,4 @@ for rep in range(reps):
     lib.bnpk_finish_sorted(dev.ctx, ptr(b), n, ptr(off2), nseg, 43, ptr(a), ptr(counts), ptr(state), None, 0, None, None, C.byref(nu), C.byref(ov), dev.stream())
     e1.record(); torch.cuda.synchronize()
     times.append(round(e0.elapsed_time(e1), 2))
-print("finish ms:", times, "n_unique", nu.value)
+print("finish ms:", times, "n_unique", nu.value, "state[0:8]", state[:8].tolist())
