@@ -790,13 +790,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       }
     } else if (prev_one) {
       for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
-        ko[i] = stage[i];
-        co[i] = 1;
+        __builtin_nontemporal_store(stage[i], &ko[i]);
+        __builtin_nontemporal_store((int64_t)1, &co[i]);
       }
     } else {
       for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
-        ko[i] = stage[i];
-        co[i] = aux[i];
+        __builtin_nontemporal_store(stage[i], &ko[i]);
+        __builtin_nontemporal_store((int64_t)aux[i], &co[i]);
       }
     }
   };
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
         const int i = t + q * FN_THREADS;
-        if (i < nxt.nb) kn[q] = (A + nxt.lo)[(unsigned)i];   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
+        if (i < nxt.nb) kn[q] = __builtin_nontemporal_load(&(A + nxt.lo)[(unsigned)i]);   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
       }
     }
     unsigned D = 0;
