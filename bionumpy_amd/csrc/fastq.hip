@@ -67,7 +67,8 @@ __device__ __forceinline__ fq_chunk fq_load(const uint8_t* __restrict__ buf, int
   c.valid = 0;
   if (pos >= n) return c;
   if (pos + FQ_VEC <= n) {
-    uint4 v = *reinterpret_cast<const uint4*>(buf + pos);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(buf + pos));   // streamed: 16 GB per batch, no reuse
     c.lo = (uint64_t)v.x | ((uint64_t)v.y << 32);
     c.hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
     c.valid = 0xffffu;

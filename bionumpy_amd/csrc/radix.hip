@@ -94,11 +94,12 @@ __device__ __forceinline__ bool find_slab(const int64_t* __restrict__ seg_off, c
 struct mem_source {
   const uint64_t* __restrict__ keys;
   struct raw_t { uint64_t v[RP_MAXITEMS]; };
+  template <bool STREAM = false>
   __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
       const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
-      if (i < hi) raw.v[q] = keys[i];
+      if (i < hi) raw.v[q] = STREAM ? __builtin_nontemporal_load(&keys[i]) : keys[i];   // STREAM: last use of the keys
     }
   }
   __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[RP_MAXITEMS]) const {
@@ -123,6 +124,7 @@ struct kmer_source {
   int64_t n_words;                         // words of W
   int k;
   struct raw_t { uint64_t w0, w1, w2; unsigned v; };
+  template <bool STREAM = false>
   __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
     const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
     if (o < hi) {
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   int64_t t0 = sl.lo;
   unsigned T = tile_size(carried);
   typename Source::raw_t raw;                     // loads of the next tile, in flight while this one is staged + flushed
-  src.issue(t0, sl.hi, raw);
+  src.template issue<true>(t0, sl.hi, raw);
   uint64_t k[RP_MAXITEMS];
   unsigned r[RP_MAXITEMS];
   unsigned vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     __syncthreads();
     // the next tile's extent is known: start its loads now, they land while this tile is staged and flushed
     const unsigned T_next = tile_size(total >> 16);
-    if (!last) src.issue(t0 + T, sl.hi, raw);
+    if (!last) src.template issue<true>(t0 + T, sl.hi, raw);
     // stage the new keys behind the carried ones
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
@@ -358,7 +360,11 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
             j = j >= rot ? j - rot : j + nf[u] - rot;
             uint64_t* dst = out + (((int64_t)ln[u] << C::LOG_LINE) + j);
             if (!((kk[u].x | kk[u].y) >> 63)) {
-              *reinterpret_cast<ulonglong2*>(dst) = kk[u];
+              typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+              u64x2 pair;
+              pair.x = kk[u].x;
+              pair.y = kk[u].y;
+              __builtin_nontemporal_store(pair, reinterpret_cast<u64x2*>(dst));
             } else {                                           // phantom slots before the bucket's first key
               if (!(kk[u].x >> 63)) dst[0] = kk[u].x;
               if (!(kk[u].y >> 63)) dst[1] = kk[u].y;
