@@ -122,10 +122,19 @@ __device__ __forceinline__ void fq_tile_prefix(const int v[FQ_ITERS], int ex[FQ_
   *total = tot;
 }
 
+// x mod m for 0 <= x < 2^20 and a small run-time m: a float reciprocal and a fix-up instead of the ~30-instruction
+// integer division sequence (the line phases below are computed once per 16-byte chunk)
+__device__ __forceinline__ int fq_mod_small(int x, int m, float inv_m) {
+  int r = x - (int)((float)x * inv_m) * m;
+  if (r < 0) r += m;
+  if (r >= m) r -= m;
+  return r;
+}
+
 // payload bytes of the chunk per line phase; `line` = tile-relative index of the chunk's first line
 __device__ __forceinline__ void fq_count_phases(const fq_chunk& c, int line, int lpe, int cnt[FQ_MAXLPE]) {
   uint32_t nl = c.nl, todo = c.valid & ~c.skip;
-  int ph = line % lpe;
+  int ph = fq_mod_small(line, lpe, 1.0f / (float)lpe);
   while (true) {
     const uint32_t upto = nl ? ((1u << (__ffs(nl) - 1)) - 1u) : 0xffffu;     // bytes before the next newline
     const int m = __popc(todo & upto);
@@ -282,6 +291,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
   const int64_t fbase = seq_base[blockIdx.x];                          // flat base index of the tile's first sequence byte
   const int S = (int)(seq_base[blockIdx.x + 1] - fbase);               // sequence bytes of the tile
   const int off32 = (int)(fbase & 31), off64 = (int)(fbase & 63);
+  // line numbers relative to the tile's first line: 32-bit compares and a cheap phase instead of 64-bit % per chunk
+  const int g0_phase = (int)(g0 % lpe);
+  const int used_rel = (int)max((int64_t)-1, min(used - g0, (int64_t)1 << 30));      // lines [0, used_rel) take part
+  const float inv_lpe = 1.0f / (float)lpe;
   for (int i = tid; i < FQ_SWORDS; i += BNPK_BLOCK) stage[i] = 0;
   for (int i = tid; i < FQ_EWORDS; i += BNPK_BLOCK) ebits[i] = 0;
   if (blockIdx.x == 0 && tid == 0 && n > 0 && used > 0 && buf[0] != header) atomicMin(&err[0], 0ull);
@@ -317,14 +330,15 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
 #pragma unroll
   for (int it = 0; it < FQ_ITERS; ++it) {
     uint32_t nl = c[it].nl, todo = c[it].valid & ~c[it].skip, bits = 0;
-    int64_t ln = g0 + line[it];
+    int ln = line[it], ph = fq_mod_small(g0_phase + ln, lpe, inv_lpe);
     while (true) {
       const uint32_t upto = nl ? ((1u << (__ffs(nl) - 1)) - 1u) : 0xffffu;
-      if (ln < used && ln % lpe == seq_line) bits |= todo & upto;
+      if (ln < used_rel && ph == seq_line) bits |= todo & upto;
       if (!nl) break;
       todo &= ~upto;
       nl &= nl - 1;
       ++ln;
+      ph = (ph + 1 == lpe) ? 0 : ph + 1;
     }
     seqbits[it] = bits;
     nseq[it] = __popc(bits);
@@ -376,20 +390,19 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
     }
     // line ends: validation of the byte that starts the next line
     uint32_t nl = c[it].nl;
-    int64_t ln = g0 + line[it];
-    while (nl) {
-      const int j = __ffs(nl) - 1;
-      nl &= nl - 1;
-      const int64_t next_line = ln + 1;
-      if (next_line < used) {
-        const int ph = (int)(next_line % lpe);
-        if (ph == 0 || (check_plus && ph == 2)) {
+    if (nl) {
+      int ln = line[it], ph = fq_mod_small(g0_phase + ln, lpe, inv_lpe);
+      while (nl) {
+        const int j = __ffs(nl) - 1;
+        nl &= nl - 1;
+        ++ln;                                                // the line that starts after this newline
+        ph = (ph + 1 == lpe) ? 0 : ph + 1;
+        if (ln < used_rel && (ph == 0 || (check_plus && ph == 2))) {
           const uint32_t b = j < 15 ? fq_byte(c[it], j + 1) : (pos + 16 < n ? (follow[it] & 0xffu) : 0u);
-          if (ph == 0 && b != header) atomicMin(&err[0], (unsigned long long)(next_line / lpe));
-          if (ph == 2 && b != '+') atomicMin(&err[1], (unsigned long long)(next_line / lpe));
+          if (ph == 0 && b != header) atomicMin(&err[0], (unsigned long long)((g0 + ln) / lpe));
+          if (ph == 2 && b != '+') atomicMin(&err[1], (unsigned long long)((g0 + ln) / lpe));
         }
       }
-      ++ln;
     }
   }
   if (bad != (unsigned long long)BNPK_NONE) atomicMin(&err[2], bad);
