@@ -617,6 +617,10 @@ constexpr unsigned FN_SPIN_LIMIT = 1u << 22;
 #define FN_SLEEP 1
 #endif
 
+#define FN_SLOT(w) ((w) & 0x1fffu)
+#define FN_RANK(w) (((w) >> 13) & 0x1fffu)
+#define FN_LESS(w) ((w) >> 26)
+
 constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS + 4) * 4;
 constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;                      // two bin arrays (ping-pong between buckets)
 constexpr size_t FN_OFF_AUX = FN_OFF_BINS + 2 * FN_BINS_BYTES;          // per slot {rank increments : 16 | duplicates seen : 16}
@@ -873,14 +877,17 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       }
       if (have_prev) emit_prev();                      // the stage is free for this bucket after the next barrier
       __syncthreads();
-      unsigned bs[FN_ITEMS];                           // start of the key's bin; its own slot is bs + r
+      // From here on r[q] packs what the ranking needs about a key, in ONE register (the kernel sits at the 128-VGPR
+      // limit of 1024-thread workgroups and every spilled value costs a wait for all loads in flight):
+      // {slot in the stage : 13 | rank in its bin : 13 | earlier keys that are smaller (dense steps) : 6}
+      static_assert(FN_CAP <= 8192, "slot and rank are packed in 13 bits each");
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
-        bs[q] = 0;
         if ((valid >> q) & 1u) {
-          bs[q] = bins[(unsigned)(k[q] >> sshift) & (SB - 1)];
-          stage[bs[q] + r[q]] = k[q];
-          aux[bs[q] + r[q]] = 0;
+          const unsigned slot = bins[(unsigned)(k[q] >> sshift) & (SB - 1)] + r[q];
+          stage[slot] = k[q];
+          aux[slot] = 0;
+          r[q] = slot | (r[q] << 13);
         }
       }
       __syncthreads();
@@ -890,23 +897,20 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       // key a duplicate: it adds itself to the first occurrence's counter and drops out.  The eight keys of a lane
       // advance together (eight independent LDS reads per step instead of eight latency-bound loops).
       unsigned active = 0, dup = 0;
-      unsigned lt[FN_ITEMS];
 #pragma unroll
-      for (int q = 0; q < FN_ITEMS; ++q) {
-        lt[q] = 0;
-        if (((valid >> q) & 1u) && r[q] > 0) active |= 1u << q;
-      }
+      for (int q = 0; q < FN_ITEMS; ++q)
+        if (((valid >> q) & 1u) && FN_RANK(r[q]) > 0) active |= 1u << q;
       // Two dense steps (most walks are that short) ...
       for (unsigned step = 0; step < 2 && __any(active != 0); ++step) {
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
           if ((active >> q) & 1u) {
-            const unsigned j = bs[q] + step;
+            const unsigned j = FN_SLOT(r[q]) - FN_RANK(r[q]) + step;
             const uint64_t y = stage[j];
             if (y == k[q]) { atomicAdd(&aux[j], 0x10000u); dup |= 1u << q; active &= ~(1u << q); }
             else {
-              if (y < k[q]) ++lt[q]; else atomicAdd(&aux[j], 1u);
-              if (step + 1 >= r[q]) active &= ~(1u << q);
+              if (y < k[q]) r[q] += 1u << 26; else atomicAdd(&aux[j], 1u);
+              if (step + 1 >= FN_RANK(r[q])) active &= ~(1u << q);
             }
           }
         }
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         for (int q = 0; q < FN_ITEMS; ++q) {
           const bool a = (active >> q) & 1u;
           const uint64_t m = __ballot(a);
-          if (a) wlist[n_items + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(bs[q] + r[q]);
+          if (a) wlist[n_items + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)FN_SLOT(r[q]);
           n_items += (unsigned)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
@@ -953,7 +957,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       if (n_dups) {                                    // uniform: duplicates found by the list walkers above
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q)
-          if (((valid >> q) & 1u) && (aux[bs[q] + r[q]] >> 31)) dup |= 1u << q;
+          if (((valid >> q) & 1u) && (aux[FN_SLOT(r[q])] >> 31)) dup |= 1u << q;
       }
       const unsigned first_bits = valid & ~dup;
       unsigned idx[FN_ITEMS];
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       if (n_dups == 0) {                               // uniform: the common case for well-spread k-mers
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q)
-          if ((valid >> q) & 1u) idx[q] = bs[q] + lt[q] + (aux[bs[q] + r[q]] & 0xffffu);
+          if ((valid >> q) & 1u) idx[q] = FN_SLOT(r[q]) - FN_RANK(r[q]) + FN_LESS(r[q]) + (aux[FN_SLOT(r[q])] & 0xffffu);
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q)
           if ((valid >> q) & 1u) stage[idx[q]] = k[q];
@@ -970,9 +974,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         // the stage in slot order (bins stay contiguous) and ranked among themselves, so the work per key does not
         // grow with the multiplicities; a first occurrence's multiplicity is 1 + the duplicates that found it above.
         all_one = false;
+        unsigned bs[FN_ITEMS], lt[FN_ITEMS];           // (this rarely taken branch works on the unpacked fields)
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
-          const unsigned slot = bs[q] + r[q];
+          const unsigned slot = FN_SLOT(r[q]);
+          r[q] = FN_RANK(r[q]);
+          bs[q] = slot - r[q];
+          lt[q] = 0;
           if ((first_bits >> q) & 1u) atomicOr(&fmask32[slot >> 5], 1u << (slot & 31));
         }
         __syncthreads();
