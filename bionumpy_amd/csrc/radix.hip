@@ -1043,9 +1043,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     }
     // ---- tail: this bucket's bins are free; the next bucket takes its ranks in the other bin array (zeroed one
     // iteration ago), so its counting sort can start right after the output below
-    // the walk over the predecessors' counts starts here: they have had the final placement above to publish, and
-    // the poll has the rest of the iteration to come back
-    if (wave == 0) lb_v = lb_poll(cur.b - 1);
     const int tt = fn_fresh(tid);
     for (unsigned i = tt; i <= SB; i += FN_THREADS) bins[i] = 0;
     if (tid == 0) sh_dups[parity ^ 1] = 0;
@@ -1063,6 +1060,10 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     // order of the tickets then follows the order in which the buckets complete, which keeps the rounds intact
     // (taken by another wavefront, or earlier in the iteration, the launch becomes unstable: 35-44 / 57-67 ms
     // instead of 37.4 per 3e9 keys).
+    // The walk over the predecessors' counts starts here, as late as possible: a predecessor that has not published
+    // yet costs a second, blocking poll at the top of the next iteration (measured: 0.61 extra polls per bucket
+    // from here, 0.82 when the poll is issued before the ranks above).
+    if (wave == 0) lb_v = lb_poll(cur.b - 1);
     if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
     __syncthreads();
     nn_b = fn_uniform(sh[0]);
