@@ -264,6 +264,26 @@ def test_count_sparse_radix_path(ops, seed, n, key_bits, dup):
         assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("key_bits", [1, 2, 3, 5, 12, 13, 14])
+@pytest.mark.parametrize("n", [1, 2, 63, 7167, 7168, 7169, 14336, 20011])
+def test_finishing_kernel_edges(ops, key_bits, n):
+    """few low bits (fewer LDS bins than keys: 1, 2, 4 .. bins, packed two per word), bucket sizes around the
+    finishing kernel's capacity (one more key than fits = the pre-counted bucket path), single-key inputs"""
+    import ctypes as C
+    from bionumpy_amd._native import lib
+    assert int(lib.bnpk_finish_capacity()) == 7168
+    rng = np.random.default_rng(key_bits * 100003 + n)
+    keys = rng.integers(0, 1 << key_bits, size=n, dtype=np.int64)
+    ek, ec = oracle.count_sparse(keys)
+    gk, gc = ops.count_sparse(_h(keys), key_bits=key_bits)
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+    spread = keys | (rng.integers(0, 1 << 40, size=n, dtype=np.int64) << key_bits)      # (nearly) all distinct
+    ek, ec = oracle.count_sparse(spread)
+    gk, gc = ops.count_sparse(_h(spread), key_bits=key_bits + 40)
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
