@@ -600,11 +600,11 @@ __global__ __launch_bounds__(RS_THREADS) void rp_split_small_kernel(const uint64
 // by wavefront 0 (64 predecessors per poll) while the other wavefronts rank the bucket's keys, so its latency
 // is hidden.  The next bucket's keys are loaded while the current one is processed.
 constexpr int FN_THREADS = 1024;
-constexpr int FN_CAP = 7168;                         // keys per bucket (7 per lane)
+constexpr int FN_CAP = 8192;
 constexpr int FN_ITEMS = FN_CAP / FN_THREADS;
 constexpr int FN_MAXBITS = 12;
 constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
-constexpr int FN_WORDS = 128;                        // first-occurrence mask words (one bit per slot, 8192 slots spanned)
+constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask words
 constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
 constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
 static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
@@ -621,14 +621,12 @@ constexpr unsigned FN_SPIN_LIMIT = 1u << 22;
 #define FN_RANK(w) (((w) >> 13) & 0x1fffu)
 #define FN_LESS(w) ((w) >> 26)
 
-// bin counters / bin starts are 16-bit (a bucket has at most FN_CAP < 65536 keys), two bins per LDS word
-constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS / 2 + 2) * 4;
-#define FN_BIN(arr, b) (((arr)[(b) >> 1] >> (((b) & 1u) << 4)) & 0xffffu)
+constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS + 4) * 4;
 constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;                      // two bin arrays (ping-pong between buckets)
 constexpr size_t FN_OFF_AUX = FN_OFF_BINS + 2 * FN_BINS_BYTES;          // per slot {rank increments : 16 | duplicates seen : 16}
 constexpr size_t FN_OFF_MASK = FN_OFF_AUX + (size_t)FN_CAP * 4;
 constexpr size_t FN_OFF_LIST = FN_OFF_MASK + (size_t)FN_WORDS * 8;       // per wavefront: slots of the keys with long walks
-constexpr size_t FN_OFF_WSUM = FN_OFF_LIST + (size_t)(FN_THREADS / 64) * 64 * 2;       // 64 list entries per wavefront
+constexpr size_t FN_OFF_WSUM = FN_OFF_LIST + (size_t)FN_CAP * 2;
 constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
 constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
 
@@ -645,12 +643,6 @@ __device__ __forceinline__ int64_t fn_uniform(int64_t v) {
 __device__ __forceinline__ int fn_fresh(int x) {
   asm volatile("" : "+v"(x));
   return x;
-}
-
-// rank of a new key in bin b = the bin's count before the increment
-__device__ __forceinline__ unsigned fn_bin_take(unsigned* bins, unsigned b) {
-  const unsigned sh = (b & 1u) << 4;
-  return (atomicAdd(&bins[b >> 1], 1u << sh) >> sh) & 0xffffu;
 }
 
 struct fn_bucket {
@@ -690,7 +682,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   unsigned* bins_next = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS + FN_BINS_BYTES);   // ... of the one after it
   unsigned* aux = reinterpret_cast<unsigned*>(smem + FN_OFF_AUX);
   unsigned long long* fmask = reinterpret_cast<unsigned long long*>(smem + FN_OFF_MASK);
-  unsigned short* wlist = reinterpret_cast<unsigned short*>(smem + FN_OFF_LIST) + (threadIdx.x >> 6) * 64;
+  unsigned short* wlist = reinterpret_cast<unsigned short*>(smem + FN_OFF_LIST) + (threadIdx.x >> 6) * (FN_ITEMS * 64);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
   long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base, [2] 2nd ticket
   unsigned* sh_dups = reinterpret_cast<unsigned*>(sh + 4);              // duplicate counters, alternating between buckets
@@ -745,7 +737,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       __hip_atomic_store(&state[FS_BUCKETS + b], FN_AGG | (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
 
-  for (unsigned i = tid; i < FN_BINS_BYTES / 4; i += FN_THREADS) { bins[i] = 0; bins_next[i] = 0; }
+  for (unsigned i = tid; i <= SB; i += FN_THREADS) { bins[i] = 0; bins_next[i] = 0; }
   if (tid < FN_WORDS) fmask[tid] = 0;
   if (tid < 2) sh_dups[tid] = 0;
   // Software pipeline over tickets: while bucket `cur` is sorted, the keys of the next one are in flight (and get
@@ -769,7 +761,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     const int i = tid + q * FN_THREADS;
     if (i < cur.nb) {
       k[q] = (A + cur.lo)[(unsigned)i];
-      r[q] = fn_bin_take(bins, (unsigned)(k[q] >> sshift) & (SB - 1));
+      r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
       valid |= 1u << q;
     }
   }
@@ -862,16 +854,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     } else {
       // counting sort on the next sbits bits: exclusive scan of the bin counts, keys to their bins
       {
-        static_assert(FN_BINS_PER_LANE % 2 == 0, "a lane owns whole words of the packed bin array");
         unsigned c[FN_BINS_PER_LANE], sum = 0;
         const int t = fn_fresh(tid);
 #pragma unroll
-        for (int j = 0; j < FN_BINS_PER_LANE; j += 2) {
+        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
           const unsigned bi = t * FN_BINS_PER_LANE + j;
-          const unsigned w = (bi < SB) ? bins[bi >> 1] : 0;
-          c[j] = w & 0xffffu;
-          c[j + 1] = w >> 16;
-          sum += c[j] + c[j + 1];
+          c[j] = (bi < SB) ? bins[bi] : 0;
+          sum += c[j];
         }
         const unsigned inc = wave_inclusive_scan(sum);
         if (lane == 63) wsum[wave] = inc;
@@ -879,12 +868,12 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         unsigned run = inc - sum;
         for (int w = 0; w < wave; ++w) run += wsum[w];
 #pragma unroll
-        for (int j = 0; j < FN_BINS_PER_LANE; j += 2) {
+        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
           const unsigned bi = t * FN_BINS_PER_LANE + j;
-          if (bi < SB) bins[bi >> 1] = run | ((run + c[j]) << 16);          // starts of bins bi, bi + 1
-          run += c[j] + c[j + 1];
+          if (bi < SB) bins[bi] = run;
+          run += c[j];
         }
-        if (tid == 0 && !(SB & 1u)) bins[SB >> 1] = (unsigned)nb;          // bin SB = end of the last bin (SB == 1: set above)
+        if (tid == 0) bins[SB] = (unsigned)nb;
       }
       if (have_prev) emit_prev();                      // the stage is free for this bucket after the next barrier
       __syncthreads();
@@ -895,7 +884,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
         if ((valid >> q) & 1u) {
-          const unsigned slot = FN_BIN(bins, (unsigned)(k[q] >> sshift) & (SB - 1)) + r[q];
+          const unsigned slot = bins[(unsigned)(k[q] >> sshift) & (SB - 1)] + r[q];
           stage[slot] = k[q];
           aux[slot] = 0;
           r[q] = slot | (r[q] << 13);
@@ -933,26 +922,22 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       // ... then the few keys with longer walks (~10 %) are compacted into a list private to the wavefront, ONE
       // per lane, instead of sweeping all eight register slots of every lane for a handful of stragglers.  Their
       // results travel through LDS: rank increments in aux (low half), "I am a duplicate" in bit 31.
-      while (__any(active != 0)) {                     // wave-uniform; one round takes up to 64 stragglers
+      if (__any(active != 0)) {                        // wave-uniform
         unsigned n_items = 0;
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
           const bool a = (active >> q) & 1u;
           const uint64_t m = __ballot(a);
-          const unsigned pos = n_items + __popcll(m & ((1ull << lane) - 1ull));
-          if (a && pos < 64u) {
-            wlist[pos] = (unsigned short)FN_SLOT(r[q]);
-            active &= ~(1u << q);
-          }
-          n_items = min(64u, n_items + (unsigned)__popcll(m));
+          if (a) wlist[n_items + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)FN_SLOT(r[q]);
+          n_items += (unsigned)__popcll(m);
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        {
-          if (lane < n_items) {
-            const unsigned slot = wlist[lane];
+        for (unsigned i0 = 0; i0 < n_items; i0 += 64) {
+          if (i0 + lane < n_items) {
+            const unsigned slot = wlist[i0 + lane];
             const uint64_t x = stage[slot];
-            const unsigned b0 = FN_BIN(bins, (unsigned)(x >> sshift) & (SB - 1));
+            const unsigned b0 = bins[(unsigned)(x >> sshift) & (SB - 1)];
             for (unsigned j = b0 + 2; j < slot; ++j) {
               const uint64_t y = stage[j];
               if (y == x) {
@@ -1007,7 +992,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         auto distinct_before = [&](unsigned x) -> unsigned {   // first occurrences in slots < x (all lanes must call)
           const unsigned w = min(x >> 6, (unsigned)FN_WORDS - 1);
           const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
-          const uint64_t below = x >= (unsigned)(64 * FN_WORDS) ? ~0ull : ((1ull << (x & 63)) - 1ull);
+          const uint64_t below = x >= (unsigned)FN_CAP ? ~0ull : ((1ull << (x & 63)) - 1ull);
           return pw + ((FN_WPL == 2 && (w & 1)) ? cw : 0u) + __popcll(fmask[w] & below);
         };
         unsigned todo = 0;                             // idx[q] = compact start of the bin, r[q] = first occurrences in it,
@@ -1015,7 +1000,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
         for (int q = 0; q < FN_ITEMS; ++q) {
           const bool is_first = (first_bits >> q) & 1u;
           unsigned e = bs[q];
-          if (is_first) e = FN_BIN(bins, ((unsigned)(k[q] >> sshift) & (SB - 1)) + 1);
+          if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
           const unsigned slot = bs[q] + r[q];
           const unsigned cs = distinct_before(bs[q]), ce = distinct_before(e), c = distinct_before(slot);
           const unsigned m = is_first ? 1u + ((aux[slot] >> 16) & 0x7fffu) : 0u;
@@ -1059,7 +1044,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     // ---- tail: this bucket's bins are free; the next bucket takes its ranks in the other bin array (zeroed one
     // iteration ago), so its counting sort can start right after the output below
     const int tt = fn_fresh(tid);
-    for (unsigned i = tt; i <= (SB >> 1); i += FN_THREADS) bins[i] = 0;
+    for (unsigned i = tt; i <= SB; i += FN_THREADS) bins[i] = 0;
     if (tid == 0) sh_dups[parity ^ 1] = 0;
     valid = 0;
 #pragma unroll
@@ -1067,7 +1052,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
       const int i = tt + q * FN_THREADS;
       if (i < nxt.nb) {
         k[q] = kn[q];
-        r[q] = fn_bin_take(bins_next, (unsigned)(k[q] >> sshift) & (SB - 1));
+        r[q] = atomicAdd(&bins_next[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
         valid |= 1u << q;
       }
     }
