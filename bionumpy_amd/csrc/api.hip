@@ -39,9 +39,9 @@ int bnpk_ctx_create(int device, bnpk_ctx** out) {
 
 void bnpk_ctx_destroy(bnpk_ctx* ctx) {
   if (!ctx) return;
-  for (auto& p : ctx->pending) { hipEventDestroy(p.start); hipEventDestroy(p.stop); }
-  for (auto e : ctx->event_pool) hipEventDestroy(e);
-  if (ctx->scratch) hipFree(ctx->scratch);
+  for (auto& p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
   delete ctx;
 }
 

@@ -690,7 +690,6 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   const unsigned SB = 1u << sbits;
 
   unsigned* fmask32 = reinterpret_cast<unsigned*>(fmask);
-  constexpr uint64_t KEYMASK = ~(1ull << 63);
 
   // ---- decoupled look-back, off the critical path.  A bucket's distinct count is published as soon as it is known;
   // the walk over the predecessors' status words (wavefront 0) starts one phase later — they have published by then:
