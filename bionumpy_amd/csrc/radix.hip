@@ -692,12 +692,13 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   unsigned* fmask32 = reinterpret_cast<unsigned*>(fmask);
 
   // ---- decoupled look-back, off the critical path.  A bucket's distinct count is published as soon as it is known;
-  // the walk over the predecessors' status words (wavefront 0) starts one phase later — they have published by then:
-  // one poll of the 64 nearest words completes 99 % of the walks — and the poll stays in flight, in a register,
-  // across the barriers until the start of the next iteration, so the latency of the device-scope loads is hidden.
-  // The result is needed when the NEXT bucket is about to be placed in the stage; until then the sorted keys wait
-  // in LDS.  A poll uses every word up to the first one that has not been published yet (nearest predecessor first).
-  // (Measured per 3e9 keys: blocking walk before the final placement 36.0 ms, this 30.1 ms, no look-back at all 27.0;
+  // the walk over the predecessors' status words (wavefront 0) starts at the end of the iteration and its first poll
+  // (the 64 nearest words) stays in flight, in a register, across the barrier until the start of the next
+  // iteration, so the latency of the device-scope loads is hidden.  The result is needed when the NEXT bucket is
+  // about to be placed in the stage; until then the sorted keys wait in LDS.  A poll uses every word up to the first
+  // one that has not been published yet (nearest predecessor first); 0.6 further, blocking polls per bucket are
+  // what a late predecessor costs today.
+  // (Measured per 3e9 keys: blocking walk before the final placement 36.0 ms, this 23 ms, no waiting at all 20;
   // every wavefront polling for itself: 52 ms — the status words are a hot spot.)
   auto lb_poll = [&](int64_t top) -> unsigned long long {          // lane l: the status word at distance l behind `top`
     const unsigned long long* first = state + FS_BUCKETS + (top - 63);   // (scalar; only dereferenced where it is valid)
