@@ -72,6 +72,9 @@ SIGNATURES = {
     "bnpk_unpack_codes": (_int, [_p, _p, _i64, _int, _p, _p]),
     "bnpk_kmers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_kmer_start_mask": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
+    "bnpk_reverse_complement_packed": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "bnpk_reverse_complement_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "bnpk_canonical_kmers": (_int, [_p, _p, _i64, _int, _p]),
     "bnpk_windows_flat": (_int, [_p, _p, _p, _i64, _int, _int, _i64, _p, _p]),
     "bnpk_kmers_partition": (_int, [_p, _p, _p, _i64, _int, _int, _int, _p, _p, _p]),
     "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),

@@ -1,0 +1,160 @@
+// Reverse complement of ragged DNA (bionumpy/sequence/dna.py:36-65) and canonical k-mer hashes, gfx950.
+//
+//   get_reverse_complement(seq) = complement(seq)[..., ::-1]: every row is reversed and every base replaced by its
+//   complement.  On the 2-bit form (A C G T = 0 1 2 3) the complement of a code is 3 - code = ~code & 3, so a run
+//   of up to 32 bases is reverse-complemented with one reversal of the 2-bit groups of a 64-bit word and one NOT.
+//   The ASCII form goes through the reference's 128-entry table (A<->T, C<->G, N->N, everything else -> 0).
+//
+//   canonical(h) = min(h, rc(h)) for a k-mer hash in the reference's layout (first base in the least significant
+//   2 bits): rc(h) is the hash of the reverse complement k-mer = the reversed 2-bit groups of h, complemented.
+#include "common.h"
+#include "rows.h"
+
+namespace {
+
+constexpr int RC_TILE_WORDS = BNPK_BLOCK;            // one output word (32 bases) per lane
+constexpr int64_t RC_TILE_BASES = (int64_t)RC_TILE_WORDS * 32;
+constexpr int RC_BYTES_PER_LANE = 8;
+constexpr int64_t RC_TILE_BYTES = (int64_t)BNPK_BLOCK * RC_BYTES_PER_LANE;
+
+// the 2-bit groups of x in reverse order (group 0 <-> group 31)
+__device__ __forceinline__ uint64_t reverse_groups(uint64_t x) {
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+  return __builtin_bswap64(x);
+}
+
+// bases [pos, pos + n) of the packed stream, n <= 32, in the low 2n bits
+__device__ __forceinline__ uint64_t packed_run(const uint64_t* __restrict__ w, int64_t pos, int n) {
+  const int64_t i = pos >> 5;
+  const int sh = 2 * (int)(pos & 31);
+  uint64_t v = w[i] >> sh;
+  if (sh && sh + 2 * n > 64) v |= w[i + 1] << (64 - sh);
+  return n >= 32 ? v : (v & ((1ull << (2 * n)) - 1ull));
+}
+
+// last row r in [lo, hi] with off[r] <= p
+__device__ __forceinline__ int64_t row_of(const int64_t* __restrict__ off, int64_t lo, int64_t hi, int64_t p) {
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo + 1) >> 1);
+    if (off[mid] <= p) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* __restrict__ in,
+                                                               const int64_t* __restrict__ off, int64_t n_rows,
+                                                               int64_t total, const int64_t* __restrict__ tile_rows,
+                                                               int64_t n_tiles, uint64_t* __restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * RC_TILE_WORDS + threadIdx.x;
+  const int64_t p0 = w * 32;
+  if (p0 >= total) {
+    if (p0 < total + 64) out[w] = 0;                         // the pad words of the packed layout
+    return;
+  }
+  // (the table has an entry for every tile that starts inside the data; the pad words form tiles of their own)
+  const int64_t lo = tile_rows[blockIdx.x];
+  const int64_t hi = ((int64_t)(blockIdx.x + 1) * RC_TILE_BASES < total) ? tile_rows[blockIdx.x + 1] : n_rows - 1;
+  int64_t r = row_of(off, lo, hi, p0);
+  const int64_t p1 = min(p0 + 32, total);
+  uint64_t word = 0;
+  int64_t p = p0;
+  while (p < p1) {
+    int64_t s = off[r], e = off[r + 1];
+    while (e <= p) { ++r; s = e; e = off[r + 1]; }           // empty rows, and the step to the next row
+    const int64_t stop = min(e, p1);
+    const int n = (int)(stop - p);
+    // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
+    const uint64_t src = packed_run(in, s + e - stop, n);
+    const uint64_t rc = ~(reverse_groups(src) >> (64 - 2 * n));
+    const uint64_t bits = n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
+    word |= bits << (2 * (int)(p - p0));
+    p = stop;
+  }
+  out[w] = word;
+}
+
+// complement table of the reference (bionumpy/sequence/dna.py:10,29-33), as a function
+__device__ __forceinline__ uint32_t ascii_complement(uint32_t b) {
+  return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'N' ? 'N' : 0u;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __restrict__ in,
+                                                              const int64_t* __restrict__ off, int64_t n_rows,
+                                                              int64_t total, const int64_t* __restrict__ tile_rows,
+                                                              int64_t n_tiles, uint8_t* __restrict__ out) {
+  const int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * RC_BYTES_PER_LANE;
+  if (p0 >= total) return;
+  int64_t lo, hi;
+  tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, lo, hi);
+  int64_t r = row_of(off, lo, hi, p0);
+  const int64_t p1 = min(p0 + RC_BYTES_PER_LANE, total);
+  int64_t s = off[r], e = off[r + 1];
+  for (int64_t p = p0; p < p1; ++p) {
+    while (e <= p) { ++r; s = e; e = off[r + 1]; }
+    out[p] = (uint8_t)ascii_complement(in[s + e - 1 - p]);
+  }
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void canonical_kernel(int64_t* __restrict__ h, int64_t n, int k) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const uint64_t mask = (1ull << (2 * k)) - 1ull;
+  for (; i < n; i += stride) {
+    const uint64_t x = (uint64_t)h[i];
+    const uint64_t rc = ~(reverse_groups(x) >> (64 - 2 * k)) & mask;
+    h[i] = (int64_t)min(x, rc);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnpk_reverse_complement_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_offsets, int64_t n_rows,
+                                   int64_t total, uint64_t* d_out, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || !d_out || !d_offsets || (total > 0 && !d_packed) || d_out == d_packed)
+    return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_words = total / 32 + 2;                    // the packed layout of bnpk_gather_encode_dna
+  const int64_t n_tiles = ceil_div(n_words, RC_TILE_WORDS);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  bnpk_timer t(ctx, "reverse_complement_packed", s);
+  if (n_rows > 0 && total > 0) BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, RC_TILE_BASES, (int64_t*)table, s));
+  hipLaunchKernelGGL(rc_packed_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, d_offsets, n_rows, total,
+                     (const int64_t*)table, n_tiles, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_rows,
+                                  int64_t total, uint8_t* d_out, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || !d_offsets || (total > 0 && (!d_bytes || !d_out)) || (total > 0 && d_out == d_bytes))
+    return BNPK_ERR_ARG;
+  if (total == 0 || n_rows == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ceil_div(total, RC_TILE_BYTES);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  bnpk_timer t(ctx, "reverse_complement_bytes", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, RC_TILE_BYTES, (int64_t*)table, s));
+  hipLaunchKernelGGL(rc_bytes_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_bytes, d_offsets, n_rows, total,
+                     (const int64_t*)table, n_tiles, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_canonical_kmers(bnpk_ctx* ctx, int64_t* d_hashes, int64_t n, int k, void* stream) {
+  if (!ctx || n < 0 || k < 1 || k > 31 || (n > 0 && !d_hashes)) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "canonical_kmers", s);
+  hipLaunchKernelGGL(canonical_kernel, dim3(grid_for(ceil_div(n, BNPK_BLOCK))), dim3(BNPK_BLOCK), 0, s, d_hashes, n, k);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"

@@ -220,6 +220,25 @@ class HipOps:
                                       n_rows, n_out, k, window_size, ptr(out), self._s()))
         return HArray(dev=out)
 
+    # -- reverse complement / canonical k-mers ---------------------------------------------------
+    def reverse_complement_packed(self, packed, offsets, n_rows, total):
+        out = self._empty(total // 32 + 2, np.int64)
+        self._chk(lib.bnpk_reverse_complement_packed(self.ctx, ptr(packed.dev()), ptr(offsets.dev()), n_rows, total,
+                                                     ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def reverse_complement_bytes(self, flat, offsets, n_rows, total):
+        out = self._empty(total, np.uint8)
+        self._chk(lib.bnpk_reverse_complement_bytes(self.ctx, ptr(flat.dev()), ptr(offsets.dev()), n_rows, total,
+                                                    ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def canonical_kmers(self, hashes, k):
+        """h = min(h, hash of the reverse complement k-mer); overwrites the device buffer of ``hashes``"""
+        t = hashes.dev()
+        self._chk(lib.bnpk_canonical_kmers(self.ctx, ptr(t), t.numel(), k, self._s()))
+        return HArray(dev=t)
+
     def kmers_by_rows(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
         """bnpk_kmers: the output-flat kernel with per-lane row lookups (kept for comparison / as the reference form)"""
         out = self._empty(n_out, np.int64)

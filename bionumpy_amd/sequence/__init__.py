@@ -1,9 +1,10 @@
 """Sequence ops on the hot path (bionumpy/sequence/__init__.py)."""
 from .kmers import get_kmers, count_kmers
 from .minimizers import get_minimizers
+from .dna import get_reverse_complement
 from .count_encoded import count_encoded, EncodedCounts, SparseKmerCounts
 from . import indexing
 from .indexing import KmerIndex, KmerLookup
 
-__all__ = ["get_kmers", "count_kmers", "get_minimizers", "count_encoded", "EncodedCounts", "SparseKmerCounts",
+__all__ = ["get_kmers", "count_kmers", "get_minimizers", "get_reverse_complement", "count_encoded", "EncodedCounts", "SparseKmerCounts",
            "KmerIndex", "KmerLookup", "indexing"]

@@ -176,6 +176,24 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
                const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
                int64_t* d_hashes, void* stream);
 
+/* ---- reverse complement -----------------------------------------------------------
+ * replaces get_reverse_complement = complement(sequence)[..., ::-1] (bionumpy/sequence/dna.py:36-65): every row
+ * reversed, every base complemented.  d_offsets (n_rows+1) are the row offsets of the flat input; the output has
+ * the same layout.
+ *   _packed: 2-bit DNA codes in the bnpk_gather_encode_dna layout (total/32 + 2 words); complement of a code is
+ *            3 - code (dna.py:22-27 applied to the alphabet "ACGT").
+ *   _bytes:  ASCII (BaseEncoding); the reference's 128-entry table (dna.py:10,29-33): A<->T, C<->G, N->N, every
+ *            other byte -> 0. */
+int bnpk_reverse_complement_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_offsets,
+                                   int64_t n_rows, int64_t total, uint64_t* d_out, void* stream);
+int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets,
+                                  int64_t n_rows, int64_t total, uint8_t* d_out, void* stream);
+
+/* In place h[i] = min(h[i], rc(h[i])), rc(h) = the hash (layout of bnpk_kmers, first base least significant) of the
+ * reverse complement of the k-mer with hash h: strand-independent ("canonical") k-mers.  Not in the reference;
+ * defined by the oracle (oracle/kmers.py: canonical_kmers) on top of get_reverse_complement. */
+int bnpk_canonical_kmers(bnpk_ctx* ctx, int64_t* d_hashes, int64_t n, int k, void* stream);
+
 /* One bit per base of the flat packed stream, set where a k-mer starts: bits [offsets[r], offsets[r+1]-(k-1)) of
  * every row with at least k bases (d_mask needs total/64 + 2 words) — the ragged trim `ragged[..., :-(k-1)]`
  * (bionumpy/sequence/kmers.py:100) as a mask, so that the fused generator below needs no row lookup. */

@@ -178,3 +178,39 @@ def build_kmer_index(codes, lengths, k):
     ukeys, first = np.unique(h, return_index=True)
     bounds = np.concatenate((first, [h.size]))
     return {int(key): r[bounds[i]:bounds[i + 1]] for i, key in enumerate(ukeys)}
+
+
+# ---- reverse complement / canonical k-mers -------------------------------------------------------------
+_ASCII_COMPLEMENT = np.zeros(128, dtype=np.uint8)                 # bionumpy/sequence/dna.py:10,29-33
+for _a, _b in {"A": "T", "G": "C", "C": "G", "T": "A", "N": "N"}.items():
+    _ASCII_COMPLEMENT[ord(_a)] = ord(_b)
+
+
+def reverse_complement(flat, lengths, ascii_bytes=False):
+    """get_reverse_complement = complement(sequence)[..., ::-1] (bionumpy/sequence/dna.py:36-65) on the flat data of a
+    ragged array: codes of the alphabet "ACGT" are complemented as 3 - code (dna.py:22-27: the alphabet mapped through
+    A<->T, C<->G), ASCII bytes through the 128-entry table (dna.py:29-33: every other byte becomes 0)."""
+    flat = np.asarray(flat, dtype=np.uint8)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    comp = _ASCII_COMPLEMENT[flat] if ascii_bytes else (3 - flat).astype(np.uint8)
+    starts = np.cumsum(lengths) - lengths
+    ends = starts + lengths
+    row = np.repeat(np.arange(lengths.size), lengths)
+    pos = np.arange(flat.size, dtype=np.int64)
+    return comp[starts[row] + ends[row] - 1 - pos]
+
+
+def reverse_complement_hash(hashes, k):
+    """hash (first base = least significant 2 bits) of the reverse complement of the k-mer with hash h"""
+    h = np.asarray(hashes, dtype=np.uint64)
+    out = np.zeros_like(h)
+    for j in range(k):                                            # code j of the k-mer becomes code k-1-j, complemented
+        c = (h >> np.uint64(2 * j)) & np.uint64(3)
+        out |= (np.uint64(3) - c) << np.uint64(2 * (k - 1 - j))
+    return out.astype(np.int64)
+
+
+def canonical_kmers(hashes, k):
+    """min(h, rc(h)): the strand-independent representative of a k-mer (not in the reference)"""
+    h = np.asarray(hashes, dtype=np.int64)
+    return np.minimum(h, reverse_complement_hash(h, k))

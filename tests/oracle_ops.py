@@ -163,6 +163,16 @@ class OracleOps:
         return _h(oracle.decode_dna(codes) if to_ascii else codes)
 
     # -- k-mers ------------------------------------------------------------------------------------
+    def reverse_complement_packed(self, packed, offsets, n_rows, total):
+        lens = np.diff(offsets.host())
+        return _pack(oracle.reverse_complement(_unpack(packed, total), lens))
+
+    def reverse_complement_bytes(self, flat, offsets, n_rows, total):
+        return _h(oracle.reverse_complement(flat.host()[:total], np.diff(offsets.host()), ascii_bytes=True))
+
+    def canonical_kmers(self, hashes, k):
+        return _h(oracle.canonical_kmers(hashes.host(), k))
+
     def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
         off = in_offsets.host()
         h, _ = oracle.get_kmers(_unpack(packed, int(off[-1])), np.diff(off), k)

@@ -300,6 +300,31 @@ def test_count_kmers_fused_equals_get_kmers_then_count(bnp):
     assert len(bnp.sequence.count_kmers(short, 31)) == 0
 
 
+def test_reverse_complement(bnp):
+    # tests/test_dna.py:18-20 (ASCII); 2-bit DNA and ragged rows, empty rows included
+    assert str(bnp.sequence.get_reverse_complement(bnp.as_encoded_array("ACGTG"))) == "CACGT"
+    dna = bnp.as_encoded_array("ACGTG", bnp.DNAEncoding)
+    rc = bnp.sequence.get_reverse_complement(dna)
+    assert rc.encoding == bnp.DNAEncoding and str(rc) == "CACGT"
+    rows = ["ACGT", "", "A", "GGATTTC", "ACGTACGTACGTACGTACGTACGTACGTACGTACGTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTG"]
+    for enc in (bnp.DNAEncoding, None):
+        seqs = bnp.as_encoded_array(rows, enc) if enc is not None else bnp.as_encoded_array(rows)
+        out = bnp.sequence.get_reverse_complement(seqs)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+        assert out.tolist() == ["".join(comp[c] for c in reversed(r)) for r in rows]
+        assert out.lengths.tolist() == [len(r) for r in rows]
+        assert bnp.sequence.get_reverse_complement(out).tolist() == rows              # an involution
+    # the ASCII table of the reference: N stays N, anything else becomes NUL (dna.py:29-33)
+    odd = bnp.sequence.get_reverse_complement(bnp.as_encoded_array("ANxT"))
+    assert np.asarray(odd.raw()).tolist() == [ord("A"), 0, ord("N"), ord("T")]
+    # k-mers of the reverse complement are the reverse complements of the k-mers, in reverse order
+    k = 5
+    h = np.asarray(bnp.sequence.get_kmers(bnp.as_encoded_array(rows[-1], bnp.DNAEncoding), k).raw())
+    h_rc = np.asarray(bnp.sequence.get_kmers(bnp.sequence.get_reverse_complement(
+        bnp.as_encoded_array(rows[-1], bnp.DNAEncoding)), k).raw())
+    assert np.array_equal(h_rc, oracle.reverse_complement_hash(h, k)[::-1])
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

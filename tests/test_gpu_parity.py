@@ -284,6 +284,32 @@ def test_finishing_kernel_edges(ops, key_bits, n):
     assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 1), (2, 50, 40), (3, 3000, 151), (4, 7, 20000), (5, 200_000, 33)])
+def test_reverse_complement_kernels(ops, seed, n_rows, max_len):
+    """packed 2-bit and ASCII reverse complement vs the oracle on ragged rows (empty rows, rows longer than a tile,
+    word-boundary lengths); canonical k-mer hashes vs the oracle"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+    lens[rng.integers(0, n_rows, size=max(1, n_rows // 10))] = 0
+    if n_rows > 3:
+        lens[1], lens[2] = 32, 64
+    total = int(lens.sum())
+    codes = rng.integers(0, 4, size=total).astype(np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    packed = ops.pack_codes(_h(codes))
+    out = ops.reverse_complement_packed(packed, _h(offsets), n_rows, total)
+    got = ops.unpack_codes(out, total).host()
+    assert np.array_equal(got, oracle.reverse_complement(codes, lens))
+    assert not out.host()[total // 32 + 1:].any()                                # pad words stay zero
+    text = np.frombuffer(b"ACGTNacgtX", dtype=np.uint8)[rng.integers(0, 10, size=total)]
+    got = ops.reverse_complement_bytes(_h(text), _h(offsets), n_rows, total).host()
+    assert np.array_equal(got, oracle.reverse_complement(text, lens, ascii_bytes=True))
+    for k in (1, 5, 16, 31):
+        h = rng.integers(0, 1 << (2 * k), size=1000, dtype=np.int64)
+        assert np.array_equal(ops.canonical_kmers(_h(h.copy()), k).host(), oracle.canonical_kmers(h, k))
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
