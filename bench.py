@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
+    ap.add_argument("--canonical", action="store_true",
+                    help="count strand-independent k-mers min(h, rc(h)) (extension; not the headline workload)")
     args = ap.parse_args()
 
     import numpy as np
@@ -125,7 +127,7 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        hist, stats = fastq_kmer_histogram(text, args.k)
+        hist, stats = fastq_kmer_histogram(text, args.k, canonical=args.canonical)
         return hist, stats
 
     stats = None
@@ -174,11 +176,11 @@ def main():
         import oracle
         m = min(args.reads, 2000)
         sample = text.dev()[:m * (2 * args.read_len + 16)].cpu().numpy()
-        sub, _ = fastq_kmer_histogram(HArray(host=sample), args.k)
+        sub, _ = fastq_kmer_histogram(HArray(host=sample), args.k, canonical=args.canonical)
         res = oracle.scan_one_line_buffer(sample, oracle.FASTQ)
         codes = oracle.encode_dna(oracle.gather_rows(sample, res.field_starts[:, 1], res.field_lens[:, 1]))
         h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], args.k)
-        ek, ec = oracle.count_sparse(h)
+        ek, ec = oracle.count_sparse(oracle.canonical_kmers(h, args.k) if args.canonical else h)
         assert np.array_equal(sub[0].host(), ek) and np.array_equal(sub[1].host(), ec), "verify failed"
 
     gbases = world * stats.n_bases * args.steps / dt / 1e9
@@ -225,7 +227,7 @@ def main():
         "config": {"workload": "synthetic %dbp x %d reads/GPU FASTQ (%s), k=%d get_kmers+count on %dxMI355X"
                                % (args.read_len, args.reads, args.mode, args.k, world),
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "k": args.k, "mode": args.mode,
-                   "kmers_per_gpu": stats.n_kmers, "distinct_rank0": n_distinct,
+                   "canonical": bool(args.canonical), "kmers_per_gpu": stats.n_kmers, "distinct_rank0": n_distinct,
                    "histogram": "dense" if args.k <= 13 else "sparse (sorted unique int64 keys + counts)",
                    "parallelism": "chunk-sharded x%d%s" % (world, ", key-range all-to-all" if world > 1 else "")},
         "roofline": roofline,

@@ -77,6 +77,13 @@ static inline unsigned grid_for(int64_t blocks) {
 // ------------------------------------------------------------------------------------------ device
 #ifdef __HIPCC__
 
+// the 2-bit groups of x in reverse order (group 0 <-> group 31): the reverse of a run of bases in the packed layout
+__device__ __forceinline__ uint64_t reverse_2bit_groups(uint64_t x) {
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
+  return __builtin_bswap64(x);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -118,6 +118,8 @@ struct mem_source {
 // says at which positions a k-mer starts, so the generation needs no row lookup at all — four coalesced word
 // loads per lane, one funnel shift for the first k-mer and a 2-bit roll for each of the next seven.  A lane owns
 // eight consecutive positions; a tile of T positions yields at most T keys.
+// CANON: every hash is replaced by min(h, hash of the reverse complement k-mer) — strand-independent k-mers.
+template <bool CANON>
 struct kmer_source {
   const uint64_t* __restrict__ W;          // 2 bits per base
   const uint8_t* __restrict__ V;           // 1 bit per base: a k-mer starts here (positions are multiples of 8 per lane)
@@ -156,7 +158,7 @@ struct kmer_source {
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q) {
       if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
-      kk[q] = h;                                               // slots of invalid positions are never read
+      kk[q] = CANON ? min(h, ~(reverse_2bit_groups(h) >> (64 - 2 * k)) & mask) : h;   // slots of invalid positions are never read
     }
     return valid;
   }
@@ -471,8 +473,8 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   int64_t* seg_slabs = reinterpret_cast<int64_t*>(scratch + align64(16));
   int64_t* H = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(seg_slabs) + align64((size_t)(n_seg + 1) * 8));
   int64_t* scan_scratch = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(H) + align64((size_t)(hn + 1) * 8));
-  static bool attr_set[2] = {false, false};
-  constexpr int which = std::is_same<Source, mem_source>::value ? 0 : 1;
+  static bool attr_set[3] = {false, false, false};
+  constexpr int which = std::is_same<Source, mem_source>::value ? 0 : (std::is_same<Source, kmer_source<false>>::value ? 1 : 2);
   if (!attr_set[which]) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 16>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<16>::LDS));
@@ -1106,7 +1108,7 @@ int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const 
 }
 
 int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_kmer_starts, int64_t n_bases, int k,
-                         int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream) {
+                         int canonical, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream) {
   if (!ctx || k < 1 || k > 31 || n_bases < 0 || bits < 0 || bits > RP_MAXBITS || shift < 0 || shift + bits > 2 * k)
     return BNPK_ERR_ARG;
   if (n_bases >= (1ll << 35)) return BNPK_ERR_RANGE;
@@ -1114,7 +1116,12 @@ int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n_bases, 1, bits), &scratch));
-  kmer_source src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
+  if (canonical) {
+    kmer_source<true> src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
+    return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
+                    "kmers_partition_hist", "kmers_partition_scatter", s);
+  }
+  kmer_source<false> src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
   return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
                   "kmers_partition_hist", "kmers_partition_scatter", s);
 }

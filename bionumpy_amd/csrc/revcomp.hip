@@ -17,13 +17,6 @@ constexpr int64_t RC_TILE_BASES = (int64_t)RC_TILE_WORDS * 32;
 constexpr int RC_BYTES_PER_LANE = 8;
 constexpr int64_t RC_TILE_BYTES = (int64_t)BNPK_BLOCK * RC_BYTES_PER_LANE;
 
-// the 2-bit groups of x in reverse order (group 0 <-> group 31)
-__device__ __forceinline__ uint64_t reverse_groups(uint64_t x) {
-  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-  x = ((x >> 4) & 0x0f0f0f0f0f0f0f0full) | ((x & 0x0f0f0f0f0f0f0f0full) << 4);
-  return __builtin_bswap64(x);
-}
-
 // bases [pos, pos + n) of the packed stream, n <= 32, in the low 2n bits
 __device__ __forceinline__ uint64_t packed_run(const uint64_t* __restrict__ w, int64_t pos, int n) {
   const int64_t i = pos >> 5;
@@ -66,7 +59,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
     const int n = (int)(stop - p);
     // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
     const uint64_t src = packed_run(in, s + e - stop, n);
-    const uint64_t rc = ~(reverse_groups(src) >> (64 - 2 * n));
+    const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
     const uint64_t bits = n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
     word |= bits << (2 * (int)(p - p0));
     p = stop;
@@ -102,7 +95,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void canonical_kernel(int64_t* __restri
   const uint64_t mask = (1ull << (2 * k)) - 1ull;
   for (; i < n; i += stride) {
     const uint64_t x = (uint64_t)h[i];
-    const uint64_t rc = ~(reverse_groups(x) >> (64 - 2 * k)) & mask;
+    const uint64_t rc = ~(reverse_2bit_groups(x) >> (64 - 2 * k)) & mask;
     h[i] = (int64_t)min(x, rc);
   }
 }

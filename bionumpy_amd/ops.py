@@ -305,6 +305,8 @@ class HipOps:
         if rest == 0:
             return []
         max_bits = 10                                    # bnpk_radix_max_bits() is 11; 10-bit digits flush whole 128-B lines
+        if -(-rest // 11) < -(-rest // 10):              # ... but an 11-bit digit is cheaper than one more level
+            max_bits = 11
         levels = -(-rest // max_bits)
         base, extra = divmod(rest, levels)
         return [base + (1 if i < extra else 0) for i in range(levels)]
@@ -315,12 +317,13 @@ class HipOps:
         self._chk(lib.bnpk_kmer_start_mask(self.ctx, ptr(offsets.dev()), n_rows, total, k, ptr(mask), self._s()))
         return HArray(dev=mask)
 
-    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits):
+    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits, canonical=False):
         """bnpk_kmers_partition: the k-mer hashes written once, partitioned by their top ``bits`` bits.
         Returns (hashes, bucket offsets[2^bits + 1])"""
         out = self._empty(n_out, np.int64)
         child = self._empty((1 << bits) + 1, np.int64)
-        self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(starts_mask.dev()), n_bases, k, 2 * k - bits,
+        self._chk(lib.bnpk_kmers_partition(self.ctx, ptr(packed.dev()), ptr(starts_mask.dev()), n_bases, k,
+                                           1 if canonical else 0, 2 * k - bits,
                                            bits, ptr(out), ptr(child), self._s()))
         return HArray(dev=out), HArray(dev=child)
 
@@ -333,13 +336,15 @@ class HipOps:
                                            ptr(child), self._s()))
         return out, child
 
-    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True):
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0):
         """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys).
 
         partition: (bucket_offsets, bits) if ``values`` is already grouped by its top ``bits`` bits
         (kmers_partitioned).  key_range: (lo, hi) if all values are known to lie in [lo, hi) (the key range a
         rank owns after the multi-GPU exchange) — the shared leading bits are then skipped by the partition.
-        fast=False forces the fallback (rocPRIM sort + run kernels) that heavy-hitter buckets take."""
+        fast=False forces the fallback (rocPRIM sort + run kernels) that heavy-hitter buckets take.
+        skew: densest / average density of the keys over their range, where it is known (canonical k-mers: 2) —
+        the levels are then planned for the densest part instead of discovering it from over-full buckets."""
         t = values.dev()
         n = t.numel()
         if n == 0:
@@ -348,11 +353,11 @@ class HipOps:
         cur, owned = t, consume                          # owned: may ``cur`` be overwritten / handed out?
         spare = None
         if fast and key_bits <= 62:
-            skip, n_plan = 0, n
+            skip, n_plan = 0, int(n * skew)
             if key_range is not None and partition is None:
                 lo, hi = int(key_range[0]), int(key_range[1])
                 skip = key_bits - (lo ^ (hi - 1)).bit_length()
-                n_plan = int(n * (1 << (key_bits - skip)) / max(hi - lo, 1))
+                n_plan = int(n * skew * (1 << (key_bits - skip)) / max(hi - lo, 1))
             offsets, done = (partition[0].dev(), partition[1]) if partition is not None else (None, 0)
             n_seg = 1 << done
             for bits in self.radix_plan(n_plan, key_bits - skip, done):

@@ -23,11 +23,13 @@ DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB; above that the histogra
 BatchStats = namedtuple("BatchStats", "n_reads n_bases n_kmers n_bytes")
 
 
-def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=True):
+def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=True, canonical=False):
     """text: HArray uint8 holding complete FASTQ records.  Returns (histogram, BatchStats) where the
     histogram is a dense int64 HArray (k <= 13; summed over ranks if ``group``) or a (keys, counts) pair
     of HArrays (k > 13; range-partitioned over ranks if ``group``)."""
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
+    if canonical and not (k > DENSE_MAX_K and fused):
+        raise NotImplementedError("canonical k-mers: the fused sparse path (k > %d)" % DENSE_MAX_K)
     ops = get_ops()
     lpe = buffer_type.n_lines_per_entry
     distributed = group is not None or _world_size() > 1
@@ -40,19 +42,22 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
         stats = BatchStats(n, n_bases, n_kmers, text.size)
         if distributed:                                                                               # A9 sparse, N GPUs
             # generate the hashes already partitioned by their top 8 bits == grouped by owning rank
-            part, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, parallel.FINE_BITS)
+            part, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, parallel.FINE_BITS, canonical=canonical)
             del packed, starts_mask
             holder = [part]                   # hand the 8 B/k-mer buffer over: it is freed right after the exchange
             del part
             return parallel.count_sparse_distributed(holder, key_bits, group, cuts=cuts), stats
-        levels = ops.radix_plan(n_kmers, key_bits)
+        # canonical k-mers are not spread evenly: min(h, rc(h)) has density 2(1 - x) over the key range, so the levels
+        # are planned for twice the keys
+        skew = 2.0 if canonical else 1.0
+        levels = ops.radix_plan(int(n_kmers * skew), key_bits)
         if levels:                                                                                    # A8 + A9 sparse
-            hashes, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, levels[0])
+            hashes, cuts = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, levels[0], canonical=canonical)
             del packed, starts_mask
-            return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0])), stats
-        hashes, _ = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, 0)
+            return ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, levels[0]), skew=skew), stats
+        hashes, _ = ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, 0, canonical=canonical)
         del packed, starts_mask
-        return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
+        return ops.count_sparse(hashes, key_bits=key_bits, consume=True, skew=skew), stats
     scan = ops.scan_lines(text, text.size, lpe, ord(buffer_type.HEADER), buffer_type._check_plus)   # A2 + A3
     n = scan.n_records
     starts, lens = ops.field_table(text, scan.newlines, n, lpe, 1, buffer_type._line_offsets[1], scan.has_cr)  # A4

@@ -54,12 +54,19 @@ def _as_four_letter(sequence):
     return sequence
 
 
-def get_kmers(sequence, k):
-    """k-mer hashes of every position of every sequence (sequence/kmers.py:36-87)."""
+def get_kmers(sequence, k, canonical=False):
+    """k-mer hashes of every position of every sequence (sequence/kmers.py:36-87).
+
+    canonical=True (extension): every hash is replaced by the smaller of itself and the hash of its
+    reverse complement k-mer, so that both strands of a sequence give the same k-mers."""
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
     sequence = _as_four_letter(sequence)
+    if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":
+        raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
         sequence, k, lambda ops, p, i, o, n, m: ops.kmers(p, i, o, n, m, k))
+    if canonical and n_out:
+        hashes = get_ops().canonical_kmers(hashes, k)
     encoding = KmerEncoding(sequence.encoding, k)
     if single:
         return EncodedArray(hashes, encoding)
@@ -95,7 +102,7 @@ class _LazyLens:
 
 
 @streamable(sum)
-def count_kmers(sequence, k, axis=None):
+def count_kmers(sequence, k, axis=None, canonical=False):
     """count every k-mer (sequence/kmers.py:129-145); k <= 8 gives the reference's dense EncodedCounts,
     larger k the sparse (sorted unique keys, counts) extension — see count_encoded.
 
@@ -105,17 +112,20 @@ def count_kmers(sequence, k, axis=None):
     if axis is None and k > 8:
         from .count_encoded import SparseKmerCounts
         sequence = _as_four_letter(sequence)
+        if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":
+            raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
         ops = get_ops()
         packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
         _, n_out = ops.row_offsets(lens, k)
         if n_out > 0:
             mask = ops.kmer_start_mask(in_off, n_rows, total, k)
-            levels = ops.radix_plan(n_out, 2 * k)
+            skew = 2.0 if canonical else 1.0          # min(h, rc(h)) has density 2(1 - x) over the key range
+            levels = ops.radix_plan(int(n_out * skew), 2 * k)
             bits = levels[0] if levels else 0
-            hashes, cuts = ops.kmers_partitioned(packed, mask, total, n_out, k, bits)
+            hashes, cuts = ops.kmers_partitioned(packed, mask, total, n_out, k, bits, canonical=canonical)
             del mask
             keys, counts = ops.count_sparse(hashes, key_bits=2 * k, consume=True,
-                                            partition=(cuts, bits) if bits else None)
+                                            partition=(cuts, bits) if bits else None, skew=skew)
             return SparseKmerCounts(KmerEncoding(sequence.encoding, k), keys, counts)
-    kmers = get_kmers(sequence, k)
+    kmers = get_kmers(sequence, k, canonical=canonical)
     return count_encoded(kmers, axis=axis)

@@ -212,9 +212,10 @@ int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d
  * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the
  * np.unique of SURVEY §3.5).  The multiset of values equals bnpk_kmers'; d_child_offsets (2^bits + 1 entries,
  * optional) receives the bucket boundaries, its last entry the number of k-mers.  d_out needs one entry per
- * k-mer (bnpk_row_offsets(lens, window=k) total). */
+ * k-mer (bnpk_row_offsets(lens, window=k) total).  canonical != 0: every hash h is replaced by min(h, rc(h)) as
+ * in bnpk_canonical_kmers. */
 int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_kmer_starts, int64_t n_bases, int k,
-                         int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
+                         int canonical, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
 
 /* ---- A11: minimizers -----------------------------------------------------------------------------
  * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every

@@ -78,7 +78,7 @@ class OracleOps:
                 bits[s:e - (k - 1)] = 1
         return _h(np.packbits(bits, bitorder="little").view(np.int64))
 
-    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits):
+    def kmers_partitioned(self, packed, starts_mask, n_bases, n_out, k, bits, canonical=False):
         flags = np.unpackbits(starts_mask.host().view(np.uint8), bitorder="little")[:n_bases]
         pos = np.flatnonzero(flags)
         codes = _unpack(packed, n_bases).astype(np.int64)
@@ -86,6 +86,8 @@ class OracleOps:
         for j in range(k):
             h |= codes[pos + j] << (2 * j)
         assert h.size == n_out
+        if canonical:
+            h = oracle.canonical_kmers(h, k)
         digit = h >> (2 * k - bits)
         order = np.argsort(digit, kind="stable")
         cuts = np.searchsorted(digit[order], np.arange((1 << bits) + 1)).astype(np.int64)
@@ -198,7 +200,7 @@ class OracleOps:
         return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins) for r in range(n_rows)],
                            dtype=np.int64).reshape(-1))
 
-    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True):
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0):
         k, c = oracle.count_sparse(values.host())
         return _h(k), _h(c)
 

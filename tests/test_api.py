@@ -325,6 +325,24 @@ def test_reverse_complement(bnp):
     assert np.array_equal(h_rc, oracle.reverse_complement_hash(h, k)[::-1])
 
 
+def test_canonical_kmers_are_strand_independent(bnp):
+    # extension: min(h, rc(h)); both strands of the same reads give the same histogram
+    rng = np.random.default_rng(11)
+    rows = ["".join(rng.choice(list("ACGT"), size=n)) for n in (60, 5, 31, 150, 33, 0, 90)]
+    seqs = bnp.as_encoded_array(rows, bnp.DNAEncoding)
+    rc = bnp.sequence.get_reverse_complement(seqs)
+    for k in (3, 11, 31):
+        fwd = np.asarray(bnp.sequence.get_kmers(seqs, k).raw().ravel())
+        can = np.asarray(bnp.sequence.get_kmers(seqs, k, canonical=True).raw().ravel())
+        assert np.array_equal(can, oracle.canonical_kmers(fwd, k))
+        a = bnp.sequence.count_kmers(seqs, k, canonical=True)
+        b = bnp.sequence.count_kmers(rc, k, canonical=True)
+        assert a == b
+        if k > 8:
+            ek, ec = oracle.count_sparse(oracle.canonical_kmers(fwd, k))
+            assert np.array_equal(a.keys, ek) and np.array_equal(a.counts, ec)
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

@@ -209,6 +209,13 @@ def test_fused_kmer_partition(ops, seed, n_rows, max_len, k):
         assert np.all(np.diff(digits) >= 0)
         assert np.array_equal(cuts, np.searchsorted(digits, np.arange((1 << bits) + 1)))
         assert np.array_equal(np.sort(part), np.sort(plain))
+        # strand-independent k-mers generated the same way: min(h, rc(h)) of every hash
+        part, cuts = ops.kmers_partitioned(packed, ends, total, n_out, k, bits, canonical=True)
+        part, cuts = part.host(), cuts.host()
+        digits = part >> (2 * k - bits)
+        assert np.all(np.diff(digits) >= 0)
+        assert np.array_equal(cuts, np.searchsorted(digits, np.arange((1 << bits) + 1)))
+        assert np.array_equal(np.sort(part), np.sort(oracle.canonical_kmers(plain, k)))
     # whole sparse path, fused first level vs oracle
     if n_rows >= 3000 and k == 31:
         codes = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
