@@ -44,7 +44,9 @@ class SequenceEntry:
     def __getitem__(self, idx):
         if isinstance(idx, (int, np.integer)):
             idx = [int(idx)]
-        if self._buffer is not None and not self._values:
+        if self._buffer is not None:      # stays lazy: the selection is a view of the chunk's text buffer, so
+            if isinstance(idx, np.ndarray) and idx.dtype == bool:     # that it can be written back (get_buffer)
+                idx = np.flatnonzero(idx)
             return self.__class__._lazy(self._buffer[idx], self._line_offset)
         return self.__class__(**{f: getattr(self, f)[idx] for f in self._fields})
 

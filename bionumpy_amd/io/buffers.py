@@ -137,6 +137,20 @@ class OneLineBuffer(FileBuffer):
         rows = np.arange(self._scan.n_records, dtype=np.int64) if self._rows is None else self._rows
         return self.__class__(self._data, self._scan, np.atleast_1d(rows[idx]))
 
+    def entry_bytes(self):
+        """the text of the (selected) entries as one contiguous buffer — TextThroughputExtractor._make_contigous
+        (io/file_buffers.py:430-440) behind ``chunk[mask]`` + ``LazyBNPDataClass.get_buffer``
+        (bnpdataclass/lazybnpdataclass.py:196-214): a compacting gather of whole records on the device"""
+        if self._rows is None:
+            return self._data if self._data.size == self._size else HArray(dev=self._data.dev()[:self._size])
+        ops = get_ops()
+        rows = np.asarray(self._rows, dtype=np.int64)
+        if rows.size == 0:
+            return HArray(host=np.zeros(0, dtype=np.uint8))
+        starts, lens = ops.entry_table(self._scan.newlines, self.n_lines_per_entry, HArray(host=rows))
+        offsets, total = ops.row_offsets(lens, 1)
+        return ops.gather_rows(self._data, starts, offsets, rows.size, total, 0)
+
 
 class TwoLineFastaBuffer(OneLineBuffer):
     """one_line_buffer.py:185-192"""

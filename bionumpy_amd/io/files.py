@@ -35,16 +35,54 @@ def _split_suffix(filename):
 
 def bnp_open(filename, mode=None, buffer_type=None, lazy=None):
     """Open a sequence file for chunked reading (io/files.py:85-182)."""
-    if mode in ("w", "write", "wb", "a", "append", "ab"):
-        raise NotImplementedError("writers are outside the MI355X hot path (SURVEY.md §2 row 2)")
     suffix, is_gzip = _split_suffix(filename)
     open_func = gzip.open if is_gzip else open
     if buffer_type is None:
         buffer_type = _get_buffer_type(suffix)
+    if mode in ("w", "write", "wb", "a", "append", "ab"):
+        return NpBufferedWriter(open_func(filename, "ab" if mode in ("a", "append", "ab") else "wb"), buffer_type)
     file_reader = NumpyFileReader(open_func(filename, "rb"), buffer_type)
     if is_gzip:
         file_reader.set_prepend_mode()
     return NpDataclassReader(file_reader, lazy=lazy)
+
+
+class NpBufferedWriter:
+    """File writer for chunks that still carry their text buffer (io/parser.py:209-268): the read-filter path
+    ``out.write(chunk[mask])`` (scripts/small_example.py:36-46).  The selected records are gathered into one
+    contiguous buffer on the device and written as they are; building text from edited fields (``from_data``) is
+    not on the MI355X path."""
+
+    def __init__(self, file_obj, buffer_type):
+        self._file_obj = file_obj
+        self._buffer_type = buffer_type
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc_val, exc_tb):
+        self.close()
+
+    def close(self):
+        if self._file_obj:
+            self._file_obj.close()
+            self._file_obj = None
+
+    def write(self, data):
+        if not hasattr(data, "get_buffer") and hasattr(data, "__iter__"):      # a stream of chunks
+            for chunk in data:
+                if len(chunk) > 0:
+                    self.write(chunk)
+            return
+        if len(data) == 0:
+            return
+        buf = data.get_buffer() if hasattr(data, "get_buffer") else data
+        if buf is None or not hasattr(buf, "entry_bytes"):
+            raise NotImplementedError("only chunks that still carry their text buffer can be written "
+                                      "(from_data is not on the MI355X path)")
+        if not isinstance(buf, self._buffer_type):
+            raise NotImplementedError("format conversion on write is not on the MI355X path")
+        self._file_obj.write(buf.entry_bytes().host().tobytes())
 
 
 def count_entries(filename, buffer_type=None):

@@ -127,6 +127,16 @@ class HipOps:
                                        field, line_offset, 1 if strip_cr else 0, ptr(starts), ptr(lens), self._s()))
         return HArray(dev=starts), HArray(dev=lens)
 
+    def entry_table(self, newlines, lines_per_entry, rows):
+        """(starts, lens) of whole entries ``rows`` (header byte .. newline of the last line): index arithmetic on the
+        newline table (device tensors; io/file_buffers.py:426-440 keeps entry_starts / entry_ends for this)"""
+        t = torch_mod()
+        nl, r = newlines.dev(), rows.dev()
+        first = r * lines_per_entry
+        starts = t.where(first > 0, nl[(first - 1).clamp(min=0)] + 1, t.zeros_like(first))
+        ends = nl[first + (lines_per_entry - 1)] + 1
+        return HArray(dev=starts.contiguous()), HArray(dev=(ends - starts).contiguous())
+
     def take_bytes(self, buf, positions, delta):
         m = positions.size
         out = self._empty(m, np.uint8)
@@ -219,6 +229,16 @@ class HipOps:
         self._chk(lib.bnpk_minimizers(self.ctx, ptr(packed.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
                                       n_rows, n_out, k, window_size, ptr(out), self._s()))
         return HArray(dev=out)
+
+    # -- per-row reductions of ragged uint8 data --------------------------------------------------
+    def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
+        """{name: HArray} for name in want ⊆ {sum (int64), min, max (uint8)}: one value per row"""
+        outs = {"sum": self._empty(n_rows, np.int64) if "sum" in want else None,
+                "min": self._empty(n_rows, np.uint8) if "min" in want else None,
+                "max": self._empty(n_rows, np.uint8) if "max" in want else None}
+        self._chk(lib.bnpk_row_reduce_u8(self.ctx, ptr(data.dev()), ptr(offsets.dev()), n_rows, ptr(outs["sum"]),
+                                         ptr(outs["min"]), ptr(outs["max"]), self._s()))
+        return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
 
     # -- reverse complement / canonical k-mers (SURVEY 8f-1) ---------------------------------------------------
     def reverse_complement_packed(self, packed, offsets, n_rows, total):

@@ -197,6 +197,48 @@ class RaggedArray:
             idx = np.flatnonzero(idx)
         return self._select_rows(idx.astype(np.int64))
 
+    # -- per-row reductions (npstructures RaggedArray.sum/mean/min/max(axis=-1); scripts/small_example.py:36-46) ----
+    def _row_reduce(self, what):
+        if self.dtype != np.uint8:
+            raise NotImplementedError("row reductions on the MI355X path cover uint8 data (quality scores)")
+        self._compact()
+        return get_ops().row_reduce_u8(self._data, self.offsets(), self._n_rows, want=(what,))[what].host()
+
+    @staticmethod
+    def _row_axis(axis):
+        if axis not in (-1, 1):
+            raise NotImplementedError("reductions over ragged arrays: axis=-1 (per row)")
+
+    def sum(self, axis=-1):
+        self._row_axis(axis)
+        return self._row_reduce("sum")
+
+    def mean(self, axis=-1):
+        self._row_axis(axis)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return self._row_reduce("sum") / self.lengths                   # an empty row gives nan, as in numpy
+
+    def _extreme(self, what, axis):
+        self._row_axis(axis)
+        if np.any(self.lengths == 0):
+            raise ValueError("zero-size row in a reduction which has no identity")
+        return self._row_reduce(what)
+
+    def min(self, axis=-1):
+        return self._extreme("min", axis)
+
+    def max(self, axis=-1):
+        return self._extreme("max", axis)
+
+    def __array_function__(self, func, types, args, kwargs):
+        name = {np.sum: "sum", np.mean: "mean", np.min: "min", np.max: "max", np.amin: "min", np.amax: "max"}.get(func)
+        if name is None or not args or args[0] is not self:
+            return NotImplemented
+        axis = kwargs.get("axis", args[1] if len(args) > 1 else None)
+        if axis is None:
+            raise NotImplementedError("reductions over ragged arrays: axis=-1 (per row)")
+        return getattr(self, name)(axis=axis)
+
     def __iter__(self):
         return (self[i] for i in range(self._n_rows))
 

@@ -176,6 +176,14 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
                const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
                int64_t* d_hashes, void* stream);
 
+/* ---- per-row reductions of ragged uint8 data --------------------------------------
+ * replaces np.sum / np.mean / np.min / np.max(ragged, axis=-1) on the quality scores of a chunk
+ * (scripts/small_example.py:36-46; npstructures RaggedArray reductions): row r = d_data[d_offsets[r] .. d_offsets[r+1]).
+ * d_sums (int64), d_mins, d_maxs (uint8) get one value per row; any of them may be NULL.  An empty row gives
+ * sum 0, min 255, max 0 (the caller raises, as numpy does for a reduction without identity). */
+int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
+                       int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
+
 /* ---- reverse complement -----------------------------------------------------------
  * replaces get_reverse_complement = complement(sequence)[..., ::-1] (bionumpy/sequence/dna.py:36-65): every row
  * reversed, every base complemented.  d_offsets (n_rows+1) are the row offsets of the flat input; the output has

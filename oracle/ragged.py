@@ -32,3 +32,23 @@ def flat_indices(starts, lengths):
     # offset of every flat element relative to its row start, then add the view start
     shift = np.repeat(starts - compact, lengths)
     return np.arange(total, dtype=np.int64) + shift
+
+
+def row_reduce(flat, lengths):
+    """np.sum / np.min / np.max(ragged, axis=-1) of uint8 rows (npstructures RaggedArray reductions as used in
+    scripts/small_example.py:36-46) -> (sums int64, mins uint8, maxs uint8); an empty row gives (0, 255, 0), the
+    identities of the three reductions over uint8."""
+    flat = np.asarray(flat, dtype=np.uint8)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = lengths.size
+    sums = np.zeros(n, dtype=np.int64)
+    mins = np.full(n, 255, dtype=np.uint8)
+    maxs = np.zeros(n, dtype=np.uint8)
+    nz = np.flatnonzero(lengths > 0)
+    if nz.size:
+        starts = (np.cumsum(lengths) - lengths)[nz]
+        data = flat[:int(lengths.sum())]
+        sums[nz] = np.add.reduceat(data.astype(np.int64), starts)
+        mins[nz] = np.minimum.reduceat(data, starts)
+        maxs[nz] = np.maximum.reduceat(data, starts)
+    return sums, mins, maxs

@@ -122,6 +122,13 @@ class OracleOps:
             ends = ends - ((ends >= 1) & (data[np.maximum(ends - 1, 0)] == 13))
         return _h(line_starts.astype(np.int64)), _h((ends - line_starts).astype(np.int64))
 
+    def entry_table(self, newlines, lines_per_entry, rows):
+        nl, r = newlines.host(), rows.host()
+        first = r * lines_per_entry
+        starts = np.where(first > 0, nl[np.maximum(first - 1, 0)] + 1, 0)
+        ends = nl[first + lines_per_entry - 1] + 1
+        return _h(starts.astype(np.int64)), _h((ends - starts).astype(np.int64))
+
     def take_bytes(self, buf, positions, delta):
         return _h(buf.host()[positions.host() + delta])
 
@@ -165,6 +172,11 @@ class OracleOps:
         return _h(oracle.decode_dna(codes) if to_ascii else codes)
 
     # -- k-mers ------------------------------------------------------------------------------------
+    def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
+        sums, mins, maxs = oracle.row_reduce(data.host(), np.diff(offsets.host()))
+        full = {"sum": sums, "min": mins, "max": maxs}
+        return {k: _h(full[k]) for k in want}
+
     def reverse_complement_packed(self, packed, offsets, n_rows, total):
         lens = np.diff(offsets.host())
         return _pack(oracle.reverse_complement(_unpack(packed, total), lens))

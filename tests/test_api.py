@@ -343,6 +343,41 @@ def test_canonical_kmers_are_strand_independent(bnp):
             assert np.array_equal(a.keys, ek) and np.array_equal(a.counts, ec)
 
 
+def test_filter_reads_on_base_quality_and_write_back(bnp, big_fq_gz, tmp_path):
+    # scripts/small_example.py:36-46: keep = np.mean(chunk.quality, axis=1) > t; out_file.write(chunk[keep])
+    import gzip
+    text = gzip.open(big_fq_gz, "rb").read()
+    res = oracle.scan_one_line_buffer(np.frombuffer(text, dtype=np.uint8), oracle.FASTQ)
+    qual = oracle.quality_scores(oracle.gather_rows(np.frombuffer(text, dtype=np.uint8), res.field_starts[:, 3],
+                                                    res.field_lens[:, 3]))
+    sums, mins, maxs = oracle.row_reduce(qual, res.field_lens[:, 3])
+    whole = bnp.open(big_fq_gz).read()
+    assert np.array_equal(np.sum(whole.quality, axis=1), sums)
+    assert np.array_equal(np.min(whole.quality, axis=1), mins) and np.array_equal(whole.quality.max(axis=-1), maxs)
+    means = np.mean(whole.quality, axis=1)
+    assert np.allclose(means, sums / res.field_lens[:, 3], rtol=0, atol=0)
+    for name, threshold in (("a.fq", 8.0), ("b.fq.gz", 6.5)):
+        out_name = str(tmp_path / name)
+        kept = 0
+        with bnp.open(out_name, "w") as out:
+            for chunk in bnp.open(big_fq_gz).read_chunks(100000):
+                keep = np.mean(chunk.quality, axis=1) > threshold
+                out.write(chunk[keep])
+                kept += int(keep.sum())
+        expect_rows = np.flatnonzero(sums / res.field_lens[:, 3] > threshold)
+        assert kept == expect_rows.size and 0 < kept < len(whole)
+        data = np.frombuffer(text, dtype=np.uint8)
+        expect = b"".join(data[res.entry_starts[r]:res.entry_ends[r]].tobytes() for r in expect_rows)
+        got = (gzip.open(out_name, "rb") if name.endswith(".gz") else open(out_name, "rb")).read()
+        assert got == expect
+        assert bnp.count_entries(out_name) == kept
+        again = bnp.open(out_name).read()
+        assert again.sequence.tolist() == [whole.sequence[int(r)].to_string() for r in expect_rows[:50]] + \
+            again.sequence.tolist()[50:]
+    with pytest.raises(ValueError):
+        np.min(bnp.encodings.QualityEncoding.encode(["II", "", "I"]), axis=1)
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

@@ -317,6 +317,23 @@ def test_reverse_complement_kernels(ops, seed, n_rows, max_len):
         assert np.array_equal(ops.canonical_kmers(_h(h.copy()), k).host(), oracle.canonical_kmers(h, k))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 1), (2, 100, 7), (3, 5000, 160), (4, 5, 100_000), (5, 300_000, 40)])
+def test_row_reductions(ops, seed, n_rows, max_len):
+    """per-row sum / min / max of ragged uint8 data vs the oracle (empty rows, rows that start at every byte
+    alignment, rows much longer than a group's stride)"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+    lens[rng.integers(0, n_rows, size=max(1, n_rows // 8))] = 0
+    total = int(lens.sum())
+    data = rng.integers(0, 94, size=total).astype(np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    got = ops.row_reduce_u8(_h(data if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, want=("sum", "min", "max"))
+    es, emn, emx = oracle.row_reduce(data, lens)
+    assert np.array_equal(got["sum"].host(), es)
+    assert np.array_equal(got["min"].host(), emn) and np.array_equal(got["max"].host(), emx)
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
