@@ -52,6 +52,42 @@ out["config3_minimizers"] = {"reads": reads, "k": 31, "window_size": 40, "n_mini
                                                             (prof["minimizers_flat"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
 del text
 
+# ---- widening: reverse complement of the reads, quality filter + compaction of whole records ------------
+text = ops.synth_fastq(reads, 150, 20260925, 0, 0, 0)
+buf = bnp.FastQBuffer.from_raw_buffer(text)
+seqs = bnp.change_encoding(buf.get_field_by_number(1), bnp.DNAEncoding)
+seqs._compact(); sync()
+def rc_step():
+    return bnp.sequence.get_reverse_complement(seqs)
+r = rc_step(); del r; sync(); dev.prof_enable(True); dev.prof_reset()
+t0 = time.perf_counter()
+for _ in range(2):
+    r = rc_step(); del r
+sync(); dt = (time.perf_counter() - t0) / 2
+prof = dev.prof_report(); dev.prof_enable(False)
+out["reverse_complement_packed"] = {"reads": reads, "ms_per_step": round(dt * 1e3, 2),
+                                    "kernel_ms": round(prof["reverse_complement_packed"]["total_ms"] / 2, 2),
+                                    "kernel_gbs": round(2 * reads * 150 / 4 / (prof["reverse_complement_packed"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
+del seqs
+def filter_step():
+    chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+    q = chunk.quality
+    means = np.mean(q, axis=1)
+    keep = means >= float(np.median(means[:100000]))      # (synthetic qualities are uniform per read: keeps ~all)
+    keep[::3] = False                                           # ... so drop every third read by hand
+    kept = chunk[keep].get_buffer().entry_bytes()
+    return int(keep.sum()), kept.size
+n_kept, n_bytes = filter_step(); sync(); dev.prof_enable(True); dev.prof_reset()
+t0 = time.perf_counter()
+for _ in range(2):
+    filter_step()
+sync(); dt = (time.perf_counter() - t0) / 2
+prof = dev.prof_report(); dev.prof_enable(False)
+out["quality_filter_compaction"] = {"reads": reads, "kept": n_kept, "bytes_out": n_bytes, "ms_per_step": round(dt * 1e3, 2),
+                                    "gbases_per_s": round(reads * 150 / dt / 1e9, 2),
+                                    "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
+del text, buf
+
 # ---- config 5: sacCer3 index + big.fq.gz lookups ---------------------------------------------------------------
 t0 = time.perf_counter()
 genome = bnp.open(os.path.join(GOLD, "sacCer3.fa.gz")).read()
