@@ -161,6 +161,66 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_generate_kernel(const uint64_t*
   for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = (int64_t)stage[i];
 }
 
+// match_string (bionumpy/sequence/string_matcher.py:16-55): for every window of m symbols (marked in the start mask)
+// 1 if it equals the pattern, else 0, in the ragged-flat order of the windows.  Same skeleton as wf_generate.
+// PACKED: 2-bit symbols, the window is a k-mer hash compared with the pattern's; else bytes compared one by one.
+constexpr int WF_MAX_PATTERN = 64;
+struct wf_pattern { uint8_t b[WF_MAX_PATTERN]; };
+
+template <bool PACKED>
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __restrict__ src, int64_t n_words,
+                                                              const uint8_t* __restrict__ mask8, int64_t n_items, int m,
+                                                              uint64_t pattern_hash, wf_pattern pat,
+                                                              const int64_t* __restrict__ tile_off,
+                                                              uint8_t* __restrict__ out) {
+  __shared__ uint8_t stage[WF_TILE];
+  __shared__ unsigned wsum[BNPK_BLOCK / 64];
+  const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+  const unsigned v = o < n_items ? mask8[o >> 3] : 0u;
+  const unsigned cnt = __popc(v);
+  const unsigned inc = wave_inclusive_scan(cnt);
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  unsigned hits = 0;                                          // bit q: the window at o + q matches
+  if (v) {
+    if (PACKED) {
+      const uint64_t* W = reinterpret_cast<const uint64_t*>(src);
+      const int64_t wi = o >> 5;
+      const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0;
+      const int sh0 = 2 * (int)(o & 31), top = 2 * m - 2;
+      const uint64_t kmask = (1ull << (2 * m)) - 1ull;
+      uint64_t h = wf_window(w0, w1, w2, sh0) & kmask;
+      const uint64_t next = wf_window(w0, w1, w2, sh0 + 2 * m);
+#pragma unroll
+      for (int q = 0; q < WF_ITEMS; ++q) {
+        if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
+        hits |= (h == pattern_hash ? 1u : 0u) << q;
+      }
+    } else {
+      const uint8_t* B = reinterpret_cast<const uint8_t*>(src);
+#pragma unroll
+      for (int q = 0; q < WF_ITEMS; ++q) {
+        if ((v >> q) & 1u) {                                  // (a marked position has m bytes of its row ahead)
+          bool same = true;
+          for (int j = 0; j < m; ++j) same = same && B[o + q + j] == pat.b[j];
+          hits |= (same ? 1u : 0u) << q;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  unsigned rank = inc - cnt;
+  for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
+  if (v) {
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q)
+      if ((v >> q) & 1u) stage[rank++] = (uint8_t)((hits >> q) & 1u);
+  }
+  __syncthreads();
+  const int64_t base = tile_off[blockIdx.x];
+  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
+  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = stage[i];
+}
+
 // bits [off[r], off[r+1] - (k-1)) of the mask for every row r with at least k bases: the positions of the flat
 // packed stream at which a k-mer starts.  One lane per row; a row touches a handful of 32-bit words.
 __global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t n_rows, int k,
@@ -220,6 +280,49 @@ int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d
                      (const int64_t*)tile_off, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
+}
+
+static int match_windows(bnpk_ctx* ctx, bool packed, const void* d_src, const uint64_t* d_start_mask, int64_t n_items, int m,
+                         uint64_t pattern_hash, const uint8_t* h_pattern, int64_t n_out, uint8_t* d_out, void* stream) {
+  if (n_out == 0 || n_items == 0) return BNPK_OK;
+  if (!d_src || !d_start_mask || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ceil_div(n_items, WF_TILE), n_mask_words = ceil_div(n_items, 64);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  int64_t* tile_off = (int64_t*)scratch;
+  int64_t* scan_scratch = tile_off + n_tiles + 1;
+  wf_pattern pat;
+  memset(&pat, 0, sizeof(pat));
+  if (h_pattern) memcpy(pat.b, h_pattern, (size_t)m);
+  bnpk_timer t(ctx, packed ? "match_windows_packed" : "match_windows_bytes", s);
+  hipLaunchKernelGGL(wf_count_kernel, dim3((unsigned)ceil_div(n_mask_words, BNPK_BLOCK)), dim3(BNPK_BLOCK), 0, s,
+                     d_start_mask, n_mask_words, n_tiles, tile_off);
+  BNPK_HIP(ctx, hipGetLastError());
+  BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
+  if (packed)
+    hipLaunchKernelGGL((wf_match_kernel<true>), dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_src, n_items / 32 + 2,
+                       reinterpret_cast<const uint8_t*>(d_start_mask), n_items, m, pattern_hash, pat,
+                       (const int64_t*)tile_off, d_out);
+  else
+    hipLaunchKernelGGL((wf_match_kernel<false>), dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_src, (int64_t)0,
+                       reinterpret_cast<const uint8_t*>(d_start_mask), n_items, m, pattern_hash, pat,
+                       (const int64_t*)tile_off, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_match_windows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int m,
+                              uint64_t pattern_hash, int64_t n_out, uint8_t* d_out, void* stream) {
+  if (!ctx || m < 1 || m > 31 || n_bases < 0 || n_out < 0) return BNPK_ERR_ARG;
+  return match_windows(ctx, true, d_packed, d_start_mask, n_bases, m, pattern_hash, nullptr, n_out, d_out, stream);
+}
+
+int bnpk_match_windows_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_start_mask, int64_t n_bytes, int m,
+                             const uint8_t* h_pattern, int64_t n_out, uint8_t* d_out, void* stream) {
+  if (!ctx || m < 1 || m > WF_MAX_PATTERN || n_bytes < 0 || n_out < 0 || !h_pattern) return BNPK_ERR_ARG;
+  return match_windows(ctx, false, d_bytes, d_start_mask, n_bytes, m, 0, h_pattern, n_out, d_out, stream);
 }
 
 int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets, const int64_t* d_out_offsets,

@@ -230,6 +230,27 @@ class HipOps:
                                       n_rows, n_out, k, window_size, ptr(out), self._s()))
         return HArray(dev=out)
 
+    # -- match_string ---------------------------------------------------------------------------------
+    def match_windows(self, data, offsets, n_rows, total, n_out, pattern, packed):
+        """uint8 0/1 per window of len(pattern) symbols, ragged-flat.  packed: ``data`` = 2-bit words and ``pattern``
+        = codes (first symbol in the low bits of the hash); else ``data`` = bytes and ``pattern`` = bytes"""
+        m = len(pattern)
+        out = self._empty(n_out, np.uint8)
+        if n_out == 0:
+            return HArray(dev=out)
+        mask = self.kmer_start_mask(offsets, n_rows, total, m)
+        if packed:
+            h = 0
+            for j, c in enumerate(pattern):
+                h |= int(c) << (2 * j)
+            self._chk(lib.bnpk_match_windows_packed(self.ctx, ptr(data.dev()), ptr(mask.dev()), total, m, h, n_out,
+                                                    ptr(out), self._s()))
+        else:
+            pat = (C.c_uint8 * m)(*[int(c) for c in pattern])
+            self._chk(lib.bnpk_match_windows_bytes(self.ctx, ptr(data.dev()), ptr(mask.dev()), total, m, pat, n_out,
+                                                   ptr(out), self._s()))
+        return HArray(dev=out)
+
     # -- per-row reductions of ragged uint8 data (SURVEY 8f-3) --------------------------------------------------
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         """{name: HArray} for name in want ⊆ {sum (int64), min, max (uint8)}: one value per row"""

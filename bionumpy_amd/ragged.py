@@ -199,10 +199,13 @@ class RaggedArray:
 
     # -- per-row reductions (npstructures RaggedArray.sum/mean/min/max(axis=-1); scripts/small_example.py:36-46) ----
     def _row_reduce(self, what):
-        if self.dtype != np.uint8:
-            raise NotImplementedError("row reductions on the MI355X path cover uint8 data (quality scores)")
+        if self.dtype not in (np.uint8, np.bool_):
+            raise NotImplementedError("row reductions on the MI355X path cover uint8 / bool data (quality scores, "
+                                      "match flags)")
         self._compact()
-        return get_ops().row_reduce_u8(self._data, self.offsets(), self._n_rows, want=(what,))[what].host()
+        data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
+        out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what].host()
+        return out.astype(bool) if (self.dtype == np.bool_ and what != "sum") else out
 
     @staticmethod
     def _row_axis(axis):

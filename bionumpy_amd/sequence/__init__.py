@@ -2,9 +2,11 @@
 from .kmers import get_kmers, count_kmers
 from .minimizers import get_minimizers
 from .dna import get_reverse_complement
+from .string_matcher import match_string
+from . import string_matcher
 from .count_encoded import count_encoded, EncodedCounts, SparseKmerCounts
 from . import indexing
 from .indexing import KmerIndex, KmerLookup
 
-__all__ = ["get_kmers", "count_kmers", "get_minimizers", "get_reverse_complement", "count_encoded", "EncodedCounts", "SparseKmerCounts",
+__all__ = ["get_kmers", "count_kmers", "get_minimizers", "get_reverse_complement", "match_string", "string_matcher", "count_encoded", "EncodedCounts", "SparseKmerCounts",
            "KmerIndex", "KmerLookup", "indexing"]

@@ -1,0 +1,42 @@
+"""match_string on the MI355X path (bionumpy/sequence/string_matcher.py:16-55).
+
+A boolean ragged array with one entry per window of ``len(matching_sequence)`` symbols of every row (rows shorter than
+the pattern give empty rows), True where the window equals the pattern.  2-bit DNA is matched as a k-mer hash
+comparison on the packed form, every other one-to-one encoding byte by byte (``bnpk_match_windows_*``).
+"""
+import numpy as np
+
+from ..encoded_array import (EncodedArray, EncodedRaggedArray, AlphabetEncoding, as_encoded_array, packed_words,
+                             _PackedDna)
+from ..ops import get_ops
+from ..ragged import RaggedArray
+
+
+def match_string(sequence, matching_sequence):
+    sequence = as_encoded_array(sequence)
+    pattern = as_encoded_array(matching_sequence, sequence.encoding)
+    assert isinstance(pattern, EncodedArray) and pattern.ndim == 1, "the pattern is a single sequence"
+    codes = np.asarray(pattern.raw()).astype(np.uint8)
+    m = codes.size
+    if m == 0:
+        raise ValueError("empty matching sequence")
+    single = isinstance(sequence, EncodedArray)
+    ragged = EncodedRaggedArray(sequence.ravel(), [sequence.size]) if single else sequence
+    ragged._compact()
+    ops = get_ops()
+    n_rows, total, offsets = len(ragged), ragged.total(), ragged.offsets()
+    out_off, n_out = ops.row_offsets(ragged._lens, m)
+    enc = sequence.encoding
+    packed = isinstance(enc, AlphabetEncoding) and enc.alphabet_size == 4 and m <= 31 and \
+        (isinstance(ragged._data, _PackedDna) or total >= 4096)
+    if packed:
+        hits = ops.match_windows(packed_words(ragged._data), offsets, n_rows, total, n_out, codes, True)
+    else:
+        if m > 64:
+            raise NotImplementedError("patterns longer than 64 symbols are not on the MI355X path")
+        hits = ops.match_windows(ragged._flat_data(), offsets, n_rows, total, n_out, codes, False)
+    flags = hits.host().astype(bool)
+    if single:
+        return flags
+    new_lens = np.maximum(ragged.lengths - (m - 1), 0)
+    return RaggedArray(flags, new_lens)

@@ -215,6 +215,15 @@ int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows
 int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int k,
                       int kmers_per_window, int64_t n_out, int64_t* d_out, void* stream);
 
+/* match_string (bionumpy/sequence/string_matcher.py:16-55): for every window of m symbols, in the
+ * ragged-flat order of the windows (rows trimmed by m-1 like the k-mers), 1 if the window equals the pattern, else 0.
+ * d_start_mask = bnpk_kmer_start_mask(offsets, k = m).  _packed: 2-bit symbols, pattern given as its hash (layout of
+ * bnpk_kmers), m <= 31.  _bytes: any byte sequence, pattern = m <= 64 host bytes. */
+int bnpk_match_windows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases,
+                              int m, uint64_t pattern_hash, int64_t n_out, uint8_t* d_out, void* stream);
+int bnpk_match_windows_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_start_mask, int64_t n_bytes,
+                             int m, const uint8_t* h_pattern, int64_t n_out, uint8_t* d_out, void* stream);
+
 /* Same hashes as bnpk_kmers, but never materialised in row order: written exactly once, already partitioned (not
  * stably) by the `bits`-bit digit at bit `shift` (bits <= bnpk_radix_max_bits()) — level 1 of the MSD radix
  * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the

@@ -214,3 +214,19 @@ def canonical_kmers(hashes, k):
     """min(h, rc(h)): the strand-independent representative of a k-mer (not in the reference)"""
     h = np.asarray(hashes, dtype=np.int64)
     return np.minimum(h, reverse_complement_hash(h, k))
+
+
+def match_string(flat, lengths, pattern):
+    """match_string (bionumpy/sequence/string_matcher.py:16-55): StringMatcher.rolling_window = for every window of
+    len(pattern) symbols of the FLAT array np.all(window == pattern), then the ragged trim [..., :-(m-1)]
+    (sequence/rollable.py:56-66).  Returns (uint8 0/1 per kept window, new row lengths)."""
+    flat = np.asarray(flat)
+    pattern = np.asarray(pattern, dtype=flat.dtype)
+    m = pattern.size
+    lengths = np.asarray(lengths, dtype=np.int64)
+    if flat.size < m:
+        return np.zeros(0, dtype=np.uint8), np.maximum(lengths - (m - 1), 0)
+    windows = np.lib.stride_tricks.sliding_window_view(flat, m)
+    hit = np.all(windows == pattern, axis=-1).astype(np.uint8)
+    hit = np.concatenate([hit, np.zeros(m - 1, dtype=np.uint8)])     # (flat positions without a full window)
+    return _trim_rows(hit, lengths, m)

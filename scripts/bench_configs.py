@@ -68,6 +68,18 @@ prof = dev.prof_report(); dev.prof_enable(False)
 out["reverse_complement_packed"] = {"reads": reads, "ms_per_step": round(dt * 1e3, 2),
                                     "kernel_ms": round(prof["reverse_complement_packed"]["total_ms"] / 2, 2),
                                     "kernel_gbs": round(2 * reads * 150 / 4 / (prof["reverse_complement_packed"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
+def match_step():
+    return bnp.match_string(seqs, "GATTACA")
+def match_kernel_only():
+    off, n_out = ops.row_offsets(seqs._lens, 7)
+    return ops.match_windows(bnp.encoded_array.packed_words(seqs._data), seqs.offsets(), len(seqs), seqs.total(), n_out,
+                             [2, 0, 3, 3, 0, 1, 0], True)
+h = match_kernel_only(); n_hits = int(h.dev().sum().item()); del h; sync(); dev.prof_enable(True); dev.prof_reset()
+for _ in range(2):
+    h = match_kernel_only(); del h
+sync(); prof = dev.prof_report(); dev.prof_enable(False)
+out["match_string_packed"] = {"reads": reads, "pattern": "GATTACA", "hits": n_hits,
+                              "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
 del seqs
 def filter_step():
     chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))

@@ -172,6 +172,12 @@ class OracleOps:
         return _h(oracle.decode_dna(codes) if to_ascii else codes)
 
     # -- k-mers ------------------------------------------------------------------------------------
+    def match_windows(self, data, offsets, n_rows, total, n_out, pattern, packed):
+        flat = _unpack(data, total) if packed else data.host()[:total]
+        hit, _ = oracle.match_string(flat, np.diff(offsets.host()), np.asarray(list(pattern), dtype=np.uint8))
+        assert hit.size == n_out
+        return _h(hit)
+
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         sums, mins, maxs = oracle.row_reduce(data.host(), np.diff(offsets.host()))
         full = {"sum": sums, "min": mins, "max": maxs}

@@ -378,6 +378,32 @@ def test_filter_reads_on_base_quality_and_write_back(bnp, big_fq_gz, tmp_path):
         np.min(bnp.encodings.QualityEncoding.encode(["II", "", "I"]), axis=1)
 
 
+def test_match_string(bnp):
+    # tests/test_string_matcher.py:53-65 and the docstring example of string_matcher.py:30-36
+    seqs = bnp.as_encoded_array(["ACA", "TACTAC"], bnp.encodings.AlphabetEncoding("ACGT"))
+    m = bnp.sequence.string_matcher.match_string(seqs, "AC")
+    assert m.tolist() == [[True, False], [False, True, False, False, True]]
+    ascii_seqs = bnp.as_encoded_array(["ACGT", "TACTAC"])
+    m = bnp.match_string(ascii_seqs, bnp.as_encoded_array("AC", ascii_seqs.encoding))
+    assert m.tolist() == [[True, False, False], [False, True, False, False, True]]
+    assert np.sum(m, axis=1).tolist() == [1, 2]                       # matches per read (scripts/small_example.py:13-18)
+    # rows shorter than the pattern, case sensitivity on text, a longer random case against the oracle
+    short = bnp.match_string(bnp.as_encoded_array(["A", "", "ACGTA", "acgta"]), "CGT")
+    assert short.tolist() == [[], [], [False, True, False], [False, False, False]]
+    rng = np.random.default_rng(3)
+    rows = ["".join(rng.choice(list("ACGT"), size=n)) for n in (500, 3, 0, 64, 31, 7000)]
+    for enc in (bnp.DNAEncoding, None):
+        seqs = bnp.as_encoded_array(rows, enc) if enc is not None else bnp.as_encoded_array(rows)
+        for pattern in ("A", "GAT", "ACGTACGTACGTACGTACGTACGTACGTACG"):
+            got = bnp.match_string(seqs, pattern)
+            flat = np.frombuffer("".join(rows).encode(), dtype=np.uint8)
+            hit, lens = oracle.match_string(flat, [len(r) for r in rows], np.frombuffer(pattern.encode(), dtype=np.uint8))
+            assert got.lengths.tolist() == lens.tolist()
+            assert np.array_equal(np.asarray(got.ravel()).astype(np.uint8), hit)
+    assert bnp.match_string(bnp.as_encoded_array("TACTAC", bnp.DNAEncoding), "AC").tolist() == \
+        [False, True, False, False, True]
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

