@@ -13,7 +13,7 @@ from .exceptions import FormatException, EncodingError
 from . import encodings, io, sequence, streams
 from .encodings import KmerEncoding
 from .io import bnp_open, count_entries, FastQBuffer, TwoLineFastaBuffer, MultiLineFastaBuffer
-from .sequence import (match_string, get_reverse_complement, get_kmers, count_kmers, get_minimizers, count_encoded, EncodedCounts, SparseKmerCounts,
+from .sequence import (match_string, get_motif_scores, get_reverse_complement, get_kmers, count_kmers, get_minimizers, count_encoded, EncodedCounts, SparseKmerCounts,
                        KmerIndex, KmerLookup)
 from .streams import streamable
 from .datatypes import SequenceEntry, SequenceEntryWithQuality

@@ -221,6 +221,47 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __rest
   for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = stage[i];
 }
 
+// Position weight matrix scores (bionumpy/sequence/position_weight_matrix.py:86-104,177-196): for every window of W
+// bases score = ((0 + M[0][c0]) + M[1][c1]) + ... in double precision, in that order (the order numpy's
+// `scores[:n-offset] += row[codes[offset:]]` accumulates in), so the result is bit-identical to the reference's.
+constexpr int WF_MAX_PWM = 64;
+struct wf_pwm { double m[WF_MAX_PWM][4]; };          // [position][code]
+
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_pwm_kernel(const uint64_t* __restrict__ W, const uint8_t* __restrict__ mask8,
+                                                            int64_t n_bases, int width, const wf_pwm* __restrict__ pwm,
+                                                            const int64_t* __restrict__ tile_off,
+                                                            double* __restrict__ out) {
+  __shared__ double stage[WF_TILE];
+  __shared__ double mat[WF_MAX_PWM][4];
+  __shared__ unsigned wsum[BNPK_BLOCK / 64];
+  for (int i = threadIdx.x; i < width * 4; i += BNPK_BLOCK) mat[i >> 2][i & 3] = pwm->m[i >> 2][i & 3];
+  const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+  const unsigned v = o < n_bases ? mask8[o >> 3] : 0u;
+  const unsigned cnt = __popc(v);
+  const unsigned inc = wave_inclusive_scan(cnt);
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  __syncthreads();
+  unsigned rank = inc - cnt;
+  for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
+  if (v) {
+    for (int q = 0; q < WF_ITEMS; ++q) {
+      if ((v >> q) & 1u) {
+        double score = 0.0;
+        for (int j = 0; j < width; ++j) {
+          const int64_t p = o + q + j;
+          const unsigned code = (unsigned)(W[p >> 5] >> (2 * (int)(p & 31))) & 3u;
+          score += mat[j][code];
+        }
+        stage[rank++] = score;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t base = tile_off[blockIdx.x];
+  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
+  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = stage[i];
+}
+
 // bits [off[r], off[r+1] - (k-1)) of the mask for every row r with at least k bases: the positions of the flat
 // packed stream at which a k-mer starts.  One lane per row; a row touches a handful of 32-bit words.
 __global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t n_rows, int k,
@@ -309,6 +350,34 @@ static int match_windows(bnpk_ctx* ctx, bool packed, const void* d_src, const ui
     hipLaunchKernelGGL((wf_match_kernel<false>), dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_src, (int64_t)0,
                        reinterpret_cast<const uint8_t*>(d_start_mask), n_items, m, pattern_hash, pat,
                        (const int64_t*)tile_off, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_pwm_scores(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int width,
+                    const double* h_matrix, int64_t n_out, double* d_out, void* stream) {
+  if (!ctx || width < 1 || width > WF_MAX_PWM || n_bases < 0 || n_out < 0 || !h_matrix) return BNPK_ERR_ARG;
+  if (n_out == 0 || n_bases == 0) return BNPK_OK;
+  if (!d_packed || !d_start_mask || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ceil_div(n_bases, WF_TILE), n_mask_words = ceil_div(n_bases, 64);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* scratch = nullptr;
+  const size_t pwm_bytes = (sizeof(wf_pwm) + 63) & ~(size_t)63;
+  BNPK_CHECK(bnpk_scratch(ctx, pwm_bytes + (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  wf_pwm* d_pwm = (wf_pwm*)scratch;
+  int64_t* tile_off = (int64_t*)((char*)scratch + pwm_bytes);
+  int64_t* scan_scratch = tile_off + n_tiles + 1;
+  BNPK_HIP(ctx, hipMemcpyAsync(d_pwm, h_matrix, (size_t)width * 4 * sizeof(double), hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));                      // (h_matrix is the caller's pageable memory)
+  bnpk_timer t(ctx, "pwm_scores", s);
+  hipLaunchKernelGGL(wf_count_kernel, dim3((unsigned)ceil_div(n_mask_words, BNPK_BLOCK)), dim3(BNPK_BLOCK), 0, s,
+                     d_start_mask, n_mask_words, n_tiles, tile_off);
+  BNPK_HIP(ctx, hipGetLastError());
+  BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
+  hipLaunchKernelGGL(wf_pwm_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed,
+                     reinterpret_cast<const uint8_t*>(d_start_mask), n_bases, width, (const wf_pwm*)d_pwm,
+                     (const int64_t*)tile_off, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

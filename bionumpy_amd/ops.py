@@ -251,6 +251,18 @@ class HipOps:
                                                    ptr(out), self._s()))
         return HArray(dev=out)
 
+    def pwm_scores(self, packed, offsets, n_rows, total, n_out, matrix):
+        """float64 motif score of every window of matrix.shape[1] bases, ragged-flat; matrix[code][position]"""
+        width = matrix.shape[1]
+        out = self._empty(n_out, np.float64)
+        if n_out == 0:
+            return HArray(dev=out)
+        mask = self.kmer_start_mask(offsets, n_rows, total, width)
+        m = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64).T)          # [position][code]
+        self._chk(lib.bnpk_pwm_scores(self.ctx, ptr(packed.dev()), ptr(mask.dev()), total, width,
+                                      m.ctypes.data_as(C.c_void_p), n_out, ptr(out), self._s()))
+        return HArray(dev=out)
+
     # -- per-row reductions of ragged uint8 data (SURVEY 8f-3) --------------------------------------------------
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         """{name: HArray} for name in want ⊆ {sum (int64), min, max (uint8)}: one value per row"""

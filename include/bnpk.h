@@ -224,6 +224,13 @@ int bnpk_match_windows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const uin
 int bnpk_match_windows_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_start_mask, int64_t n_bytes,
                              int m, const uint8_t* h_pattern, int64_t n_out, uint8_t* d_out, void* stream);
 
+/* Position weight matrix scores (bionumpy/sequence/position_weight_matrix.py:86-104,177-196): for every
+ * window of `width` <= 64 bases, in the ragged-flat order of the windows, the double-precision sum
+ * ((0 + M[0][c_0]) + M[1][c_1]) + ... — the accumulation order of the reference's calculate_scores, so finite scores
+ * are bit-identical.  h_matrix: width x 4 doubles, [position][code]; d_start_mask = bnpk_kmer_start_mask(k = width). */
+int bnpk_pwm_scores(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_start_mask, int64_t n_bases, int width,
+                    const double* h_matrix, int64_t n_out, double* d_out, void* stream);
+
 /* Same hashes as bnpk_kmers, but never materialised in row order: written exactly once, already partitioned (not
  * stably) by the `bits`-bit digit at bit `shift` (bits <= bnpk_radix_max_bits()) — level 1 of the MSD radix
  * partition of the sparse histogram fused into the generation (bionumpy/sequence/kmers.py:121-126 + the

@@ -36,4 +36,4 @@ from .kmers import (pack_2bit, sliding_window_2bit, kmer_hashes_flat,
                     kmer_to_string, kmer_labels, count_dense, count_sparse,
                     merge_sparse, build_kmer_index, kmer_from_string,
                     reverse_complement, reverse_complement_hash, canonical_kmers,
-                    match_string)
+                    match_string, pwm_scores)

@@ -230,3 +230,15 @@ def match_string(flat, lengths, pattern):
     hit = np.all(windows == pattern, axis=-1).astype(np.uint8)
     hit = np.concatenate([hit, np.zeros(m - 1, dtype=np.uint8)])     # (flat positions without a full window)
     return _trim_rows(hit, lengths, m)
+
+
+def pwm_scores(codes, lengths, matrix):
+    """get_motif_scores (bionumpy/sequence/position_weight_matrix.py:177-196): PWM.calculate_scores over the FLAT code
+    array (:86-104: scores[:n-offset] += matrix[:, offset][codes[offset:]], offset = 0 .. W-1, float64) followed by
+    the ragged trim [..., :-(W-1)].  matrix[code][position].  Returns (float64 scores, new row lengths)."""
+    codes = np.asarray(codes, dtype=np.int64)
+    matrix = np.asarray(matrix, dtype=float)
+    scores = np.zeros(codes.size, dtype=float)
+    for offset, row in enumerate(matrix.T.copy()):
+        scores[:scores.size - offset] += row[codes[offset:]]
+    return _trim_rows(scores, lengths, matrix.shape[1])

@@ -80,6 +80,17 @@ for _ in range(2):
 sync(); prof = dev.prof_report(); dev.prof_enable(False)
 out["match_string_packed"] = {"reads": reads, "pattern": "GATTACA", "hits": n_hits,
                               "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
+_rng = np.random.default_rng(1)
+_m = np.log(_rng.dirichlet(np.ones(4), size=12).T / 0.25)
+def pwm_kernel_only():
+    off, n_out = ops.row_offsets(seqs._lens, 12)
+    return ops.pwm_scores(bnp.encoded_array.packed_words(seqs._data), seqs.offsets(), len(seqs), seqs.total(), n_out, _m)
+h = pwm_kernel_only(); del h; sync(); dev.prof_enable(True); dev.prof_reset()
+for _ in range(2):
+    h = pwm_kernel_only(); del h
+sync(); prof = dev.prof_report(); dev.prof_enable(False)
+out["pwm_scores_12"] = {"reads": reads, "width": 12,
+                        "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
 del seqs
 def filter_step():
     chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))

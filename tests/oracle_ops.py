@@ -178,6 +178,11 @@ class OracleOps:
         assert hit.size == n_out
         return _h(hit)
 
+    def pwm_scores(self, packed, offsets, n_rows, total, n_out, matrix):
+        scores, _ = oracle.pwm_scores(_unpack(packed, total), np.diff(offsets.host()), matrix)
+        assert scores.size == n_out
+        return _h(scores)
+
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         sums, mins, maxs = oracle.row_reduce(data.host(), np.diff(offsets.host()))
         full = {"sum": sums, "min": mins, "max": maxs}

@@ -404,6 +404,35 @@ def test_match_string(bnp):
         [False, True, False, False, True]
 
 
+def test_motif_scores(bnp):
+    # docstring of get_motif_scores (position_weight_matrix.py:186-192) and tests/test_position_weight_matrix.py
+    PWM = bnp.sequence.position_weight_matrix.PWM
+    pwm = PWM.from_dict({"A": [5, 1], "C": [1, 5], "G": [0, 0], "T": [0, 0]})
+    scores = bnp.get_motif_scores(bnp.as_encoded_array(["ACTGAC", "CA", "GG"]), pwm)
+    with np.errstate(divide="ignore"):
+        e = np.log(5 * 5 * 16.0)
+        assert [r.tolist() for r in scores] == [[np.log(20.0) + np.log(20.0), -np.inf, -np.inf, -np.inf,
+                                                np.log(20.0) + np.log(20.0)], [np.log(4.0) + np.log(4.0)], [-np.inf]]
+    assert abs(scores[0][0] - 5.99146455) < 1e-8 and abs(scores[1][0] - 2.77258872) < 1e-8
+    a_only = PWM.from_dict({"A": [1.0, 1.0], "C": [0.0, 0.0], "G": [0.0, 0.0], "T": [0.0, 0.0]})
+    got = bnp.get_motif_scores(bnp.as_encoded_array("AAC", bnp.DNAEncoding), a_only)      # test_a_motifs, trimmed
+    assert got.tolist() == [np.log(4 ** 2), -np.inf]
+    matrix = np.log([[0.4, 0.25], [0.1, 0.25], [0.4, 0.25], [0.1, 0.25]])                   # the tests' fixture
+    pwm = PWM(matrix, "ACGT")
+    assert np.allclose(np.exp(pwm.calculate_score(bnp.as_encoded_array("AC", bnp.DNAEncoding))), 0.4 * 0.25)
+    assert np.allclose(np.exp(bnp.get_motif_scores(bnp.as_encoded_array("ACGT", bnp.DNAEncoding), pwm)),
+                       [0.4 * 0.25, 0.025, 0.4 * 0.25])
+    # random ragged reads, a 12-column matrix: bit-identical to the oracle's accumulation order
+    rng = np.random.default_rng(8)
+    rows = ["".join(rng.choice(list("ACGT"), size=n)) for n in (300, 11, 12, 0, 13, 5000)]
+    m = np.log(rng.dirichlet(np.ones(4), size=12).T / 0.25)
+    got = bnp.get_motif_scores(bnp.as_encoded_array(rows, bnp.DNAEncoding), PWM(m, "ACGT"))
+    codes = np.frombuffer("".join(rows).encode(), dtype=np.uint8)
+    codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), codes)
+    expect, lens = oracle.pwm_scores(codes, [len(r) for r in rows], m)
+    assert got.lengths.tolist() == lens.tolist() and np.array_equal(np.asarray(got.ravel()), expect)
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

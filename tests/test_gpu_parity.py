@@ -362,6 +362,25 @@ def test_match_windows(ops, seed, n_rows, max_len, m):
     assert hit.sum() >= (1 if total >= m and n_out else 0) or True
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len,width", [(1, 1, 1, 1), (2, 500, 60, 6), (3, 40_000, 151, 12), (4, 3, 20_000, 64)])
+def test_pwm_scores(ops, seed, n_rows, max_len, width):
+    """motif scores vs the oracle: float64 sums accumulated in the reference's order -> bit-identical (-inf columns
+    included)"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+    total = int(lens.sum())
+    codes = rng.integers(0, 4, size=total).astype(np.uint8)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    with np.errstate(divide="ignore"):
+        matrix = np.log(rng.dirichlet(np.ones(4), size=width).T / 0.25)
+        if width > 2:
+            matrix[2, 1] = -np.inf                                        # a forbidden base in one column
+    expect, new_lens = oracle.pwm_scores(codes, lens, matrix)
+    got = ops.pwm_scores(ops.pack_codes(_h(codes)), _h(offsets), n_rows, total, int(new_lens.sum()), matrix).host()
+    assert np.array_equal(got, expect)
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
