@@ -227,7 +227,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __rest
 constexpr int WF_MAX_PWM = 64;
 struct wf_pwm { double m[WF_MAX_PWM][4]; };          // [position][code]
 
-__global__ __launch_bounds__(BNPK_BLOCK) void wf_pwm_kernel(const uint64_t* __restrict__ W, const uint8_t* __restrict__ mask8,
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_pwm_kernel(const uint64_t* __restrict__ W, int64_t n_words,
+                                                            const uint8_t* __restrict__ mask8,
                                                             int64_t n_bases, int width, const wf_pwm* __restrict__ pwm,
                                                             const int64_t* __restrict__ tile_off,
                                                             double* __restrict__ out) {
@@ -244,14 +245,20 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_pwm_kernel(const uint64_t* __re
   unsigned rank = inc - cnt;
   for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
   if (v) {
+    // the lane's eight windows lie in four packed words: load them once, cut a 128-bit window per position
+    const int64_t wi = o >> 5;
+    const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0, w3 = wi + 3 < n_words ? W[wi + 3] : 0;
+    const int sh0 = 2 * (int)(o & 31);
+#pragma unroll
     for (int q = 0; q < WF_ITEMS; ++q) {
       if ((v >> q) & 1u) {
+        const int sh = sh0 + 2 * q;                           // < 128
+        uint64_t lo = wf_window(w0, w1, w2, sh);              // bases 0..31 of the window
+        uint64_t hi = wf_window(w1, w2, w3, sh);              // bases 32..63
         double score = 0.0;
-        for (int j = 0; j < width; ++j) {
-          const int64_t p = o + q + j;
-          const unsigned code = (unsigned)(W[p >> 5] >> (2 * (int)(p & 31))) & 3u;
-          score += mat[j][code];
-        }
+        const int first = min(width, 32);
+        for (int j = 0; j < first; ++j) { score += mat[j][lo & 3ull]; lo >>= 2; }
+        for (int j = 32; j < width; ++j) { score += mat[j][hi & 3ull]; hi >>= 2; }
         stage[rank++] = score;
       }
     }
@@ -375,7 +382,7 @@ int bnpk_pwm_scores(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_s
                      d_start_mask, n_mask_words, n_tiles, tile_off);
   BNPK_HIP(ctx, hipGetLastError());
   BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
-  hipLaunchKernelGGL(wf_pwm_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed,
+  hipLaunchKernelGGL(wf_pwm_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases / 32 + 2,
                      reinterpret_cast<const uint8_t*>(d_start_mask), n_bases, width, (const wf_pwm*)d_pwm,
                      (const int64_t*)tile_off, d_out);
   BNPK_HIP(ctx, hipGetLastError());
