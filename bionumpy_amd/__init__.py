@@ -16,6 +16,7 @@ from .io import bnp_open, count_entries, FastQBuffer, TwoLineFastaBuffer, MultiL
 from .sequence import (match_string, get_motif_scores, get_reverse_complement, get_kmers, count_kmers, get_minimizers, count_encoded, EncodedCounts, SparseKmerCounts,
                        KmerIndex, KmerLookup)
 from .streams import streamable
+from .memory_mapping import MemMapEncodedRaggedArray
 from .datatypes import SequenceEntry, SequenceEntryWithQuality
 
 open = bnp_open

@@ -433,6 +433,26 @@ def test_motif_scores(bnp):
     assert got.lengths.tolist() == lens.tolist() and np.array_equal(np.asarray(got.ravel()), expect)
 
 
+def test_memory_mapped_encoded_reads(bnp, big_fq_gz, tmp_path):
+    # streams/memory_mapping.py:10-90: decode once, cache as data.dat / lengths.dat / encoding.pkl, load without text
+    base = str(tmp_path / "reads")
+
+    def loader():
+        for chunk in bnp.open(big_fq_gz).read_chunks(100000):
+            yield bnp.change_encoding(chunk.sequence, bnp.DNAEncoding)
+
+    with pytest.warns(FutureWarning):
+        created = bnp.MemMapEncodedRaggedArray.create(loader, base)
+    whole = bnp.change_encoding(bnp.open(big_fq_gz).read().sequence, bnp.DNAEncoding)
+    lengths = np.memmap(base + "_lengths.dat", dtype=np.int32, mode="r")
+    data = np.memmap(base + "_data.dat", dtype=np.uint8, mode="r")
+    assert np.array_equal(lengths, whole.lengths) and data.size == int(whole.lengths.sum()) and data.max() <= 3
+    loaded = bnp.MemMapEncodedRaggedArray.load(base)
+    assert loaded.encoding == bnp.DNAEncoding and np.array_equal(loaded.lengths, whole.lengths)
+    assert loaded.tolist()[:20] == whole.tolist()[:20] and created.tolist()[-5:] == whole.tolist()[-5:]
+    assert bnp.sequence.count_kmers(loaded, 31) == bnp.sequence.count_kmers(whole, 31)
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()
