@@ -17,7 +17,7 @@ from .sequence import (match_string, get_motif_scores, get_reverse_complement, g
                        KmerIndex, KmerLookup)
 from .streams import streamable
 from .memory_mapping import MemMapEncodedRaggedArray
-from .datatypes import SequenceEntry, SequenceEntryWithQuality
+from .datatypes import SequenceEntry, SequenceEntryWithQuality, replace
 
 open = bnp_open
 

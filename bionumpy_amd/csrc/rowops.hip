@@ -4,6 +4,7 @@
 // dwords of the row's byte range, masks the bytes outside it, and the partial sums / minima / maxima meet in three
 // shuffle steps.
 #include "common.h"
+#include "rows.h"
 
 namespace {
 
@@ -66,3 +67,95 @@ int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_of
 }
 
 }  // extern "C"
+
+// ---- join_fields: text of records from their fields (bionumpy/io/one_line_buffer.py:119-134) ----------------------
+// Entry r = its lines one after the other; line i = `prefix` header bytes, the field's row r (plus `add`: quality
+// scores are written as score + 33), a newline.  A line without a field is the constant byte `fill` ('+').
+namespace {
+
+constexpr int JL_MAX_LINES = 4;
+constexpr int JL_BYTES_PER_LANE = 8;
+constexpr int64_t JL_TILE = (int64_t)BNPK_BLOCK * JL_BYTES_PER_LANE;
+
+struct jl_line {
+  const uint8_t* data;         // flat bytes of the field (nullptr: a one-byte constant line)
+  const int64_t* off;          // its row offsets
+  int add;                     // added to every byte of the field
+  int prefix;                  // header bytes in front of the field (0 or 1)
+  uint8_t fill;                // the constant byte of a line without a field
+};
+struct jl_lines { jl_line l[JL_MAX_LINES]; };
+
+__device__ __forceinline__ int64_t jl_row_of(const int64_t* __restrict__ off, int64_t lo, int64_t hi, int64_t p) {
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo + 1) >> 1);
+    if (off[mid] <= p) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, int n_lines, uint8_t header,
+                                                                const int64_t* __restrict__ entry_off, int64_t n_rows,
+                                                                int64_t total, const int64_t* __restrict__ tile_rows,
+                                                                uint8_t* __restrict__ out) {
+  const int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * JL_BYTES_PER_LANE;
+  if (p0 >= total) return;
+  const int64_t lo = tile_rows[blockIdx.x];
+  const int64_t hi = ((int64_t)(blockIdx.x + 1) * JL_TILE < total) ? tile_rows[blockIdx.x + 1] : n_rows - 1;
+  int64_t r = jl_row_of(entry_off, lo, hi, p0);
+  const int64_t p1 = min(p0 + JL_BYTES_PER_LANE, total);
+  int64_t e0 = entry_off[r], e1 = entry_off[r + 1];
+  int64_t p = p0;
+  while (p < p1) {
+    while (e1 <= p) { ++r; e0 = e1; e1 = entry_off[r + 1]; }
+    int64_t t = p - e0;                                        // offset inside entry r
+    for (int i = 0; i < n_lines && p < p1; ++i) {
+      const jl_line& L = lines.l[i];
+      const int64_t fs = L.data ? L.off[r] : 0;
+      const int64_t flen = L.data ? L.off[r + 1] - fs : 1;
+      const int64_t line_len = L.prefix + flen + 1;
+      if (t >= line_len) { t -= line_len; continue; }
+      while (t < line_len && p < p1) {                        // bytes of this line that belong to the lane
+        uint8_t b;
+        if (t < L.prefix) b = header;
+        else if (t < L.prefix + flen) b = L.data ? (uint8_t)(L.data[fs + t - L.prefix] + L.add) : L.fill;
+        else b = 10;
+        out[p] = b;
+        ++p;
+        ++t;
+      }
+      t = 0;                                                   // the next line starts at its first byte
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const uint8_t* const* d_field_data,
+                               const int64_t* const* d_field_offsets, const int* add, const int* prefix,
+                               const uint8_t* fill, uint8_t header, const int64_t* d_entry_offsets, int64_t total,
+                               uint8_t* d_out, void* stream) {
+  if (!ctx || n_rows < 0 || n_lines < 1 || n_lines > JL_MAX_LINES || total < 0 || !d_field_data || !d_field_offsets || !add ||
+      !prefix || !fill)
+    return BNPK_ERR_ARG;
+  if (n_rows == 0 || total == 0) return BNPK_OK;
+  if (!d_entry_offsets || !d_out) return BNPK_ERR_ARG;
+  jl_lines lines;
+  memset(&lines, 0, sizeof(lines));
+  for (int i = 0; i < n_lines; ++i) {
+    if (d_field_data[i] && !d_field_offsets[i]) return BNPK_ERR_ARG;
+    if (prefix[i] < 0 || prefix[i] > 1) return BNPK_ERR_ARG;
+    lines.l[i] = jl_line{d_field_data[i], d_field_offsets[i], add[i], prefix[i], fill[i]};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_tiles = ceil_div(total, JL_TILE);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  bnpk_timer t(ctx, "join_lines", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_entry_offsets, n_rows, JL_TILE, (int64_t*)table, s));
+  hipLaunchKernelGGL(join_lines_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, lines, n_lines, header,
+                     d_entry_offsets, n_rows, total, (const int64_t*)table, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}

@@ -61,9 +61,20 @@ class SequenceEntry:
     def get_buffer(self):
         return self._buffer
 
+    def _replace(self, **kwargs):
+        """bnp.replace (bnpdataclass/bnpdataclassfunction.py:14-47): same entries, some fields exchanged"""
+        unknown = set(kwargs) - set(self._fields)
+        assert not unknown, unknown
+        return self.__class__(**{f: kwargs.get(f, None) if f in kwargs else getattr(self, f) for f in self._fields})
+
     def __repr__(self):
         return "%s with %d entries" % (self.__class__.__name__, len(self))
 
 
 class SequenceEntryWithQuality(SequenceEntry):
     _fields = ("name", "sequence", "quality")
+
+
+def replace(obj, **kwargs):
+    """Replace fields of a chunk / dataclass by new values (bnpdataclass/bnpdataclassfunction.py:14-47)."""
+    return obj._replace(**kwargs)

@@ -16,7 +16,7 @@ import numpy as np
 
 from ..datatypes import SequenceEntry, SequenceEntryWithQuality
 from ..device import HArray
-from ..encoded_array import EncodedArray, EncodedRaggedArray, BaseEncoding, QualityEncoding
+from ..encoded_array import EncodedArray, EncodedRaggedArray, BaseEncoding, QualityEncoding, as_encoded_array
 from ..exceptions import FormatException, IncompleteEntryException  # noqa: F401
 from ..ops import get_ops
 
@@ -137,6 +137,36 @@ class OneLineBuffer(FileBuffer):
         rows = np.arange(self._scan.n_records, dtype=np.int64) if self._rows is None else self._rows
         return self.__class__(self._data, self._scan, np.atleast_1d(rows[idx]))
 
+    @classmethod
+    def _text_column(cls, column):
+        """(flat ASCII bytes, offsets) of a field: names / ASCII sequences as they are, encoded DNA decoded"""
+        if not isinstance(column, EncodedRaggedArray):
+            column = as_encoded_array(column)
+        column._compact()
+        if column.encoding == BaseEncoding:
+            return column._flat_data(), column.offsets(), 0
+        total = column.total()
+        from ..encoded_array import packed_words
+        return get_ops().unpack_codes(packed_words(column._data), total, to_ascii=True), column.offsets(), 0
+
+    @classmethod
+    def _columns(cls, entries):
+        return [cls._text_column(entries.name), cls._text_column(entries.sequence)]
+
+    @classmethod
+    def from_data(cls, entries):
+        """text of the entries built from their fields (one_line_buffer.py:99-134; fastq_buffer.py:46-61) — for chunks
+        whose fields have been replaced (``bnp.replace(chunk, sequence=...)``)"""
+        cols = cls._columns(entries)
+        lines = []
+        for i, col in enumerate(cols):
+            if col is None:
+                lines.append((None, None, 0, cls._line_offsets[i], ord("+")))
+            else:
+                data, off, add = col
+                lines.append((data, off, add, cls._line_offsets[i], 0))
+        return get_ops().join_lines(len(entries), lines, ord(cls.HEADER))
+
     def entry_bytes(self):
         """the text of the (selected) entries as one contiguous buffer — TextThroughputExtractor._make_contigous
         (io/file_buffers.py:430-440) behind ``chunk[mask]`` + ``LazyBNPDataClass.get_buffer``
@@ -180,6 +210,13 @@ class FastQBuffer(OneLineBuffer):
     def get_data(self):
         return SequenceEntryWithQuality(self.get_field_by_number(0), self.get_field_by_number(1),
                                         self.get_field_by_number(2))
+
+    @classmethod
+    def _columns(cls, entries):
+        quality = entries.quality
+        quality._compact()
+        return [cls._text_column(entries.name), cls._text_column(entries.sequence), None,
+                (quality._data, quality.offsets(), 33)]
 
 
 class MultiLineFastaBuffer(FileBuffer):

@@ -50,8 +50,8 @@ def bnp_open(filename, mode=None, buffer_type=None, lazy=None):
 class NpBufferedWriter:
     """File writer for chunks that still carry their text buffer (io/parser.py:209-268): the read-filter path
     ``out.write(chunk[mask])`` (scripts/small_example.py:36-46).  The selected records are gathered into one
-    contiguous buffer on the device and written as they are; building text from edited fields (``from_data``) is
-    not on the MI355X path."""
+    contiguous buffer on the device and written as they are; chunks whose fields were replaced
+    (``bnp.replace(chunk, sequence=rc)``) are rebuilt from their fields (``from_data`` -> ``bnpk_join_lines``)."""
 
     def __init__(self, file_obj, buffer_type):
         self._file_obj = file_obj
@@ -77,12 +77,11 @@ class NpBufferedWriter:
         if len(data) == 0:
             return
         buf = data.get_buffer() if hasattr(data, "get_buffer") else data
-        if buf is None or not hasattr(buf, "entry_bytes"):
-            raise NotImplementedError("only chunks that still carry their text buffer can be written "
-                                      "(from_data is not on the MI355X path)")
-        if not isinstance(buf, self._buffer_type):
-            raise NotImplementedError("format conversion on write is not on the MI355X path")
-        self._file_obj.write(buf.entry_bytes().host().tobytes())
+        if buf is not None and isinstance(buf, self._buffer_type) and hasattr(buf, "entry_bytes"):
+            text = buf.entry_bytes()                           # untouched records: a compacting gather
+        else:
+            text = self._buffer_type.from_data(data)           # edited fields / another format: join the fields
+        self._file_obj.write(text.host().tobytes())
 
 
 def count_entries(filename, buffer_type=None):

@@ -263,6 +263,28 @@ class HipOps:
                                       m.ctypes.data_as(C.c_void_p), n_out, ptr(out), self._s()))
         return HArray(dev=out)
 
+    # -- join_fields: record text from fields ------------------------------------------------------
+    def join_lines(self, n_rows, lines, header):
+        """lines: per line (data HArray | None, offsets HArray | None, add, prefix, fill byte).  Returns the text
+        (HArray uint8) of all entries: every line = prefix header bytes + field row (+ add) + newline."""
+        t = torch_mod()
+        lens = None
+        for data, off, add, prefix, fill in lines:
+            ln = (off.dev()[1:] - off.dev()[:-1]) if data is not None else None
+            part = (ln + (prefix + 1)) if ln is not None else t.full((n_rows,), prefix + 2, dtype=t.int64, device=self.device.tdev)
+            lens = part if lens is None else lens + part
+        entry_off, total = self.row_offsets(HArray(dev=lens.contiguous()), 1)
+        out = self._empty(total, np.uint8)
+        n = len(lines)
+        datas = (C.c_void_p * n)(*[ptr(d.dev()) if d is not None else None for d, _, _, _, _ in lines])
+        offs = (C.c_void_p * n)(*[ptr(o.dev()) if o is not None else None for _, o, _, _, _ in lines])
+        adds = (C.c_int * n)(*[int(a) for _, _, a, _, _ in lines])
+        prefixes = (C.c_int * n)(*[int(p) for _, _, _, p, _ in lines])
+        fills = (C.c_uint8 * n)(*[int(f) for _, _, _, _, f in lines])
+        self._chk(lib.bnpk_join_lines(self.ctx, n_rows, n, datas, offs, adds, prefixes, fills, header, ptr(entry_off.dev()),
+                                      total, ptr(out), self._s()))
+        return HArray(dev=out)
+
     # -- per-row reductions of ragged uint8 data (SURVEY 8f-3) --------------------------------------------------
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         """{name: HArray} for name in want ⊆ {sum (int64), min, max (uint8)}: one value per row"""

@@ -184,6 +184,16 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
                        int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
 
+/* ---- join_fields: the text of records from their fields ----------------------------
+ * replaces OneLineBuffer.join_fields / from_data (bionumpy/io/one_line_buffer.py:99-134, io/fastq_buffer.py:46-61):
+ * entry r is its n_lines <= 4 lines; line i = prefix[i] (0 or 1) bytes `header`, row r of field i
+ * (d_field_data[i] / d_field_offsets[i], every byte + add[i]: quality scores are written as score + 33), '\n'.
+ * d_field_data[i] == NULL: the line is the constant byte fill[i] ('+').  d_entry_offsets (n_rows+1) = exclusive scan
+ * of the entry lengths, total = its last entry.  The pointer arrays live on the host. */
+int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const uint8_t* const* d_field_data,
+                    const int64_t* const* d_field_offsets, const int* add, const int* prefix, const uint8_t* fill,
+                    uint8_t header, const int64_t* d_entry_offsets, int64_t total, uint8_t* d_out, void* stream);
+
 /* ---- reverse complement -----------------------------------------------------------
  * replaces get_reverse_complement = complement(sequence)[..., ::-1] (bionumpy/sequence/dna.py:36-65): every row
  * reversed, every base complemented.  d_offsets (n_rows+1) are the row offsets of the flat input; the output has

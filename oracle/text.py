@@ -291,3 +291,20 @@ def open_text(filename, fmt=None):
             raise RuntimeError("File format %s does not have a default buffer type" % suffix)
     f = gzip.open(name, "rb") if is_gzip else open(name, "rb")
     return ChunkReader(f, fmt, prepend_mode=is_gzip)
+
+
+def join_fields(fields, header, line_offsets):
+    """OneLineBuffer.join_fields (bionumpy/io/one_line_buffer.py:119-134): fields = list of (flat uint8 bytes, row
+    lengths), one per line of an entry; line i = line_offsets[i] header bytes (the HEADER on line 0) + the field's
+    row + "\n".  Returns the text as uint8."""
+    n = len(fields[0][1])
+    starts = [np.cumsum(np.asarray(l, dtype=np.int64)) - np.asarray(l, dtype=np.int64) for _, l in fields]
+    out = bytearray()
+    for r in range(n):
+        for i, (flat, lens) in enumerate(fields):
+            if line_offsets[i]:
+                out += bytes([header]) * line_offsets[i]
+            s0 = int(starts[i][r])
+            out += bytes(np.asarray(flat[s0:s0 + int(lens[r])], dtype=np.uint8).tobytes())
+            out += b"\n"
+    return np.frombuffer(bytes(out), dtype=np.uint8)

@@ -109,6 +109,18 @@ prof = dev.prof_report(); dev.prof_enable(False)
 out["quality_filter_compaction"] = {"reads": reads, "kept": n_kept, "bytes_out": n_bytes, "ms_per_step": round(dt * 1e3, 2),
                                     "gbases_per_s": round(reads * 150 / dt / 1e9, 2),
                                     "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
+def rewrite_step():
+    chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+    rc = bnp.sequence.get_reverse_complement(chunk.sequence)
+    return bnp.FastQBuffer.from_data(bnp.replace(chunk, sequence=rc)).size
+n_bytes = rewrite_step(); sync(); dev.prof_enable(True); dev.prof_reset()
+t0 = time.perf_counter()
+for _ in range(2):
+    rewrite_step()
+sync(); dt = (time.perf_counter() - t0) / 2
+prof = dev.prof_report(); dev.prof_enable(False)
+out["reverse_complement_rewrite_fastq"] = {"reads": reads, "bytes_out": n_bytes, "ms_per_step": round(dt * 1e3, 2),
+                                           "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
 del text, buf
 
 # ---- config 5: sacCer3 index + big.fq.gz lookups ---------------------------------------------------------------

@@ -183,6 +183,15 @@ class OracleOps:
         assert scores.size == n_out
         return _h(scores)
 
+    def join_lines(self, n_rows, lines, header):
+        fields = []
+        for data, off, add, prefix, fill in lines:
+            if data is None:
+                fields.append((np.full(n_rows, fill, dtype=np.uint8), np.ones(n_rows, dtype=np.int64)))
+            else:
+                fields.append(((data.host()[:int(off.host()[-1])].astype(np.int64) + add).astype(np.uint8), np.diff(off.host())))
+        return _h(oracle.join_fields(fields, header, [p for _, _, _, p, _ in lines]))
+
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         sums, mins, maxs = oracle.row_reduce(data.host(), np.diff(offsets.host()))
         full = {"sum": sums, "min": mins, "max": maxs}

@@ -453,6 +453,45 @@ def test_memory_mapped_encoded_reads(bnp, big_fq_gz, tmp_path):
     assert bnp.sequence.count_kmers(loaded, 31) == bnp.sequence.count_kmers(whole, 31)
 
 
+def test_reverse_complement_a_file(bnp, big_fq_gz, tmp_path):
+    # scripts/reverse_compliment_example.py:4-15: rc = get_reverse_complement(chunk.sequence);
+    # outfile.write(bnp.replace(chunk, sequence=rc)) — the text is rebuilt from the fields (join_fields)
+    import gzip
+    text = np.frombuffer(gzip.open(big_fq_gz, "rb").read(), dtype=np.uint8)
+    res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+    for name in ("rc.fq", "rc.fq.gz"):
+        out_name = str(tmp_path / name)
+        with bnp.open(out_name, "w") as out:
+            for chunk in bnp.open(big_fq_gz).read_chunks(100000):
+                rc = bnp.sequence.get_reverse_complement(chunk.sequence)
+                out.write(bnp.replace(chunk, sequence=rc))
+        assert bnp.count_entries(out_name) == bnp.count_entries(big_fq_gz)
+        got = np.frombuffer((gzip.open(out_name, "rb") if name.endswith(".gz") else open(out_name, "rb")).read(),
+                            dtype=np.uint8)
+        fields = []
+        for i in range(4):
+            flat = oracle.gather_rows(text, res.field_starts[:, i], res.field_lens[:, i])
+            if i == 1:
+                flat = oracle.reverse_complement(flat, res.field_lens[:, i], ascii_bytes=True)
+            if i == 2:                                              # the reference writes a bare "+" line
+                flat, lens = np.full(res.n_records, ord("+"), dtype=np.uint8), np.ones(res.n_records, dtype=np.int64)
+            else:
+                lens = res.field_lens[:, i]
+            fields.append((flat, lens))
+        expect = oracle.join_fields(fields, ord("@"), (1, 0, 0, 0))
+        assert np.array_equal(got, expect)
+    back = bnp.open(str(tmp_path / "rc.fq")).read()
+    whole = bnp.open(big_fq_gz).read()
+    assert bnp.sequence.get_reverse_complement(back.sequence).tolist()[:30] == whole.sequence.tolist()[:30]
+    assert np.array_equal(np.asarray(back.quality.ravel()), np.asarray(whole.quality.ravel()))
+    # a DNA-encoded sequence column is decoded on the way out; two-line FASTA
+    fa = str(tmp_path / "x.fa")
+    with bnp.open(fa, "w", buffer_type=bnp.TwoLineFastaBuffer) as out:
+        out.write(bnp.SequenceEntry(bnp.as_encoded_array(["r1", "read2"]),
+                                    bnp.as_encoded_array(["ACGT", "GGA"], bnp.DNAEncoding)))
+    assert open(fa, "rb").read() == b">r1\nACGT\n>read2\nGGA\n"
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()

@@ -381,6 +381,29 @@ def test_pwm_scores(ops, seed, n_rows, max_len, width):
     assert np.array_equal(got, expect)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 0), (2, 40, 5), (3, 30_000, 160), (4, 3, 50_000)])
+def test_join_lines(ops, seed, n_rows, max_len):
+    """record text from ragged fields (FASTQ shape: header prefix, a constant '+' line, scores + 33) vs the oracle;
+    empty fields, records longer than a tile"""
+    rng = np.random.default_rng(seed)
+    def field(add_range):
+        lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+        flat = rng.integers(add_range[0], add_range[1], size=int(lens.sum())).astype(np.uint8)
+        return flat, lens
+    name, seq, qual = field((48, 123)), field((65, 85)), field((0, 60))
+    def dev(f):
+        flat, lens = f
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        return _h(flat if flat.size else np.zeros(4, np.uint8)), _h(off)
+    (nd, no), (sd, so), (qd, qo) = dev(name), dev(seq), dev(qual)
+    lines = [(nd, no, 0, 1, 0), (sd, so, 0, 0, 0), (None, None, 0, 0, ord("+")), (qd, qo, 33, 0, 0)]
+    got = ops.join_lines(n_rows, lines, ord("@")).host()
+    plus = (np.full(n_rows, ord("+"), dtype=np.uint8), np.ones(n_rows, dtype=np.int64))
+    expect = oracle.join_fields([name, seq, plus, ((qual[0] + 33).astype(np.uint8), qual[1])], ord("@"), (1, 0, 0, 0))
+    assert np.array_equal(got, expect)
+
+
 def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
