@@ -83,9 +83,15 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
   int64_t r = row_of(off, lo, hi, p0);
   const int64_t p1 = min(p0 + RC_BYTES_PER_LANE, total);
   int64_t s = off[r], e = off[r + 1];
+  uint64_t word = 0;                                          // the lane's eight output bytes, stored once
   for (int64_t p = p0; p < p1; ++p) {
     while (e <= p) { ++r; s = e; e = off[r + 1]; }
-    out[p] = (uint8_t)ascii_complement(in[s + e - 1 - p]);
+    word |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)(p - p0));
+  }
+  if (p1 - p0 == RC_BYTES_PER_LANE) {
+    *reinterpret_cast<uint64_t*>(out + p0) = word;            // (p0 is a multiple of 8, the buffer 16-byte aligned)
+  } else {
+    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word >> (8 * j));
   }
 }
 

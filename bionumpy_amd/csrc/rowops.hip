@@ -106,6 +106,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
   const int64_t p1 = min(p0 + JL_BYTES_PER_LANE, total);
   int64_t e0 = entry_off[r], e1 = entry_off[r + 1];
   int64_t p = p0;
+  uint64_t word = 0;                                           // the lane's eight output bytes, stored once
   while (p < p1) {
     while (e1 <= p) { ++r; e0 = e1; e1 = entry_off[r + 1]; }
     int64_t t = p - e0;                                        // offset inside entry r
@@ -120,12 +121,17 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
         if (t < L.prefix) b = header;
         else if (t < L.prefix + flen) b = L.data ? (uint8_t)(L.data[fs + t - L.prefix] + L.add) : L.fill;
         else b = 10;
-        out[p] = b;
+        word |= (uint64_t)b << (8 * (int)(p - p0));
         ++p;
         ++t;
       }
       t = 0;                                                   // the next line starts at its first byte
     }
+  }
+  if (p1 - p0 == JL_BYTES_PER_LANE) {
+    *reinterpret_cast<uint64_t*>(out + p0) = word;             // (p0 is a multiple of 8, the buffer 16-byte aligned)
+  } else {
+    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word >> (8 * j));
   }
 }
 
