@@ -541,7 +541,7 @@ int bnpk_fastq_encode(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_
 
 int bnpk_kmer_starts_from_ends(bnpk_ctx* ctx, const uint64_t* d_row_ends, int64_t n_bases, int k, uint64_t* d_starts,
                                int64_t* d_count, void* stream) {
-  if (!ctx || n_bases < 0 || k < 1 || k > 32 || !d_row_ends || !d_starts || !d_count) return BNPK_ERR_ARG;
+  if (!ctx || n_bases < 0 || k < 1 || k > 64 || !d_row_ends || !d_starts || !d_count) return BNPK_ERR_ARG;   // (the window OR looks one word ahead)
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "kmer_starts_from_ends", s);
   BNPK_HIP(ctx, hipMemsetAsync(d_count, 0, 8, s));

@@ -219,6 +219,14 @@ class HipOps:
                                         n_out, ptr(out), self._s()))
         return HArray(dev=out)
 
+    def windows_from_mask(self, packed, start_mask, n_bases, n_out, k, window_size):
+        """hashes (window_size == k) / minimizers of the windows marked in ``start_mask`` (bnpk_windows_flat)"""
+        out = self._empty(n_out, np.int64)
+        if n_out:
+            self._chk(lib.bnpk_windows_flat(self.ctx, ptr(packed.dev()), ptr(start_mask.dev()), n_bases, k,
+                                            window_size - k + 1, n_out, ptr(out), self._s()))
+        return HArray(dev=out)
+
     def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
         return self._windows_flat(packed, in_offsets, n_rows, n_out, k, k)
 

@@ -91,6 +91,23 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
 
 
+def fastq_minimizers(text, k, window_size, buffer_type=FastQBuffer):
+    """BASELINE config 3 as a pipeline: text (HArray uint8, complete FASTQ records) -> the minimizers of every window
+    of ``window_size`` bases of every read, ragged-flat (get_minimizers, sequence/minimizers.py:8-54), through the
+    fused decode: no newline table, no field tables, no row offsets — the window starts come from the read-end mask.
+    Returns (int64 HArray, BatchStats)."""
+    assert 0 < k < 32 and window_size >= k
+    ops = get_ops()
+    if window_size - k + 1 > 26:                            # (HipOps.WINDOWS_FLAT_MAX: what bnpk_windows_flat covers)
+        raise NotImplementedError("windows of more than 26 k-mers: use get_minimizers")
+    packed, ends, n, n_bases = ops.fastq_encode(text, text.size, buffer_type.n_lines_per_entry, 1,
+                                                ord(buffer_type.HEADER), buffer_type._check_plus)
+    starts_mask, n_windows = ops.kmer_starts_from_ends(ends, n_bases, window_size)
+    del ends
+    out = ops.windows_from_mask(packed, starts_mask, n_bases, n_windows, k, window_size)
+    return out, BatchStats(n, n_bases, n_windows, text.size)
+
+
 def _world_size():
     try:
         import torch.distributed as dist

@@ -50,6 +50,18 @@ out["config3_minimizers"] = {"reads": reads, "k": 31, "window_size": 40, "n_mini
                              "minimizers_kernel_ms": round(prof["minimizers_flat"]["total_ms"] / 2, 2),
                              "minimizers_kernel_gbs": round((8 * n_out + reads * 150 / 4 + reads * 150 / 8) /
                                                             (prof["minimizers_flat"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
+from bionumpy_amd.pipeline import fastq_minimizers
+m, st = fastq_minimizers(text, 31, 40); assert st.n_kmers == n_out; del m
+sync(); dev.prof_enable(True); dev.prof_reset()
+t0 = time.perf_counter()
+for _ in range(2):
+    m, st = fastq_minimizers(text, 31, 40); del m
+sync(); dt = (time.perf_counter() - t0) / 2
+prof = dev.prof_report(); dev.prof_enable(False)
+out["config3_minimizers_fused_pipeline"] = {"reads": reads, "k": 31, "window_size": 40, "n_minimizers": st.n_kmers,
+                                            "ms_per_step": round(dt * 1e3, 2),
+                                            "gbases_per_s": round(reads * 150 / dt / 1e9, 2),
+                                            "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
 del text
 
 # ---- widening: reverse complement of the reads, quality filter + compaction of whole records ------------

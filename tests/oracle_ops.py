@@ -207,6 +207,20 @@ class OracleOps:
     def canonical_kmers(self, hashes, k):
         return _h(oracle.canonical_kmers(hashes.host(), k))
 
+    def windows_from_mask(self, packed, start_mask, n_bases, n_out, k, window_size):
+        flags = np.unpackbits(start_mask.host().view(np.uint8), bitorder="little")[:n_bases]
+        pos = np.flatnonzero(flags)
+        codes = _unpack(packed, n_bases).astype(np.int64)
+        per = window_size - k + 1
+        best = None
+        for i in range(per):
+            h = np.zeros(pos.size, dtype=np.int64)
+            for j in range(k):
+                h |= codes[pos + i + j] << (2 * j)
+            best = h if best is None else np.minimum(best, h)
+        assert pos.size == n_out
+        return _h(best if best is not None else np.zeros(0, dtype=np.int64))
+
     def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
         off = in_offsets.host()
         h, _ = oracle.get_kmers(_unpack(packed, int(off[-1])), np.diff(off), k)

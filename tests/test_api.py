@@ -492,6 +492,21 @@ def test_reverse_complement_a_file(bnp, big_fq_gz, tmp_path):
     assert open(fa, "rb").read() == b">r1\nACGT\n>read2\nGGA\n"
 
 
+def test_fused_minimizer_pipeline_equals_the_api_path(bnp, big_fq_gz):
+    # BASELINE config 3: the pipeline form (fused decode) gives exactly get_minimizers of the decoded reads
+    import gzip
+    from bionumpy_amd.pipeline import fastq_minimizers
+    from bionumpy_amd.device import HArray
+    text = np.frombuffer(gzip.open(big_fq_gz, "rb").read(), dtype=np.uint8)
+    whole = bnp.open(big_fq_gz).read()
+    seqs = bnp.change_encoding(whole.sequence, bnp.DNAEncoding)
+    for k, w in ((31, 40), (5, 5), (12, 30)):
+        got, stats = fastq_minimizers(HArray(host=text.copy()), k, w)
+        expect = np.asarray(bnp.get_minimizers(seqs, k, w).raw().ravel())
+        assert stats.n_reads == len(whole) and stats.n_kmers == expect.size
+        assert np.array_equal(got.host(), expect)
+
+
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     # scripts/kmer_counting_example.py:4-17: sum of per-chunk counts; k=31 through the sparse extension
     whole = bnp.open(big_fq_gz).read()
