@@ -165,3 +165,70 @@ extern "C" int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
+
+// ---- per-column sums of ragged uint8 data: np.sum / np.mean(ragged, axis=0) --------------------------------------
+// (scripts/small_example.py:20-22,49-52: mean match / base quality per read position).  Column c of row r is element
+// off[r] + c; sums[c] adds those bytes over the rows that are long enough, counts[c] counts them.  A lane owns 8
+// consecutive flat bytes, finds its row through the tile->row table and adds into an LDS-private table (columns
+// < CS_LDS_COLS; longer rows go to global atomics directly), flushed with 64-bit atomics.
+namespace {
+
+constexpr int CS_BYTES_PER_LANE = 8;
+constexpr int64_t CS_TILE = (int64_t)BNPK_BLOCK * CS_BYTES_PER_LANE;
+constexpr int CS_LDS_COLS = 4096;
+
+__global__ __launch_bounds__(BNPK_BLOCK) void col_sums_u8_kernel(const uint8_t* __restrict__ data,
+                                                                 const int64_t* __restrict__ off, int64_t n_rows,
+                                                                 int64_t total, const int64_t* __restrict__ tile_rows,
+                                                                 int64_t n_cols, unsigned long long* __restrict__ sums,
+                                                                 unsigned long long* __restrict__ counts) {
+  __shared__ unsigned lsum[CS_LDS_COLS];
+  __shared__ unsigned lcnt[CS_LDS_COLS];
+  const int lds_cols = (int)min((int64_t)CS_LDS_COLS, n_cols);
+  for (int c = threadIdx.x; c < lds_cols; c += BNPK_BLOCK) { lsum[c] = 0; lcnt[c] = 0; }
+  __syncthreads();
+  const int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * CS_BYTES_PER_LANE;
+  if (p0 < total) {
+    const int64_t lo = tile_rows[blockIdx.x];
+    const int64_t hi = ((int64_t)(blockIdx.x + 1) * CS_TILE < total) ? tile_rows[blockIdx.x + 1] : n_rows - 1;
+    int64_t r = jl_row_of(off, lo, hi, p0);
+    int64_t s = off[r], e = off[r + 1];
+    const int64_t p1 = min(p0 + CS_BYTES_PER_LANE, total);
+    for (int64_t p = p0; p < p1; ++p) {
+      while (e <= p) { ++r; s = e; e = off[r + 1]; }
+      const int64_t c = p - s;
+      const unsigned v = data[p];
+      if (c < lds_cols) { atomicAdd(&lsum[c], v); atomicAdd(&lcnt[c], 1u); }
+      else { atomicAdd(&sums[c], (unsigned long long)v); atomicAdd(&counts[c], 1ull); }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < lds_cols; c += BNPK_BLOCK) {
+    if (lcnt[c]) { atomicAdd(&sums[c], (unsigned long long)lsum[c]); atomicAdd(&counts[c], (unsigned long long)lcnt[c]); }
+  }
+}
+
+}  // namespace
+
+extern "C" int bnpk_col_sums_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t total,
+                                int64_t n_cols, int64_t* d_sums, int64_t* d_counts, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || n_cols < 0 || (n_cols > 0 && (!d_sums || !d_counts))) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (n_cols > 0) {
+    BNPK_HIP(ctx, hipMemsetAsync(d_sums, 0, (size_t)n_cols * 8, s));
+    BNPK_HIP(ctx, hipMemsetAsync(d_counts, 0, (size_t)n_cols * 8, s));
+  }
+  if (n_rows == 0 || total == 0 || n_cols == 0) return BNPK_OK;
+  if (!d_data || !d_offsets) return BNPK_ERR_ARG;
+  const int64_t n_tiles = ceil_div(total, CS_TILE);
+  if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  bnpk_timer t(ctx, "col_sums_u8", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, CS_TILE, (int64_t*)table, s));
+  hipLaunchKernelGGL(col_sums_u8_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_data, d_offsets, n_rows, total,
+                     (const int64_t*)table, n_cols, reinterpret_cast<unsigned long long*>(d_sums),
+                     reinterpret_cast<unsigned long long*>(d_counts));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}

@@ -271,6 +271,13 @@ class HipOps:
                                       m.ctypes.data_as(C.c_void_p), n_out, ptr(out), self._s()))
         return HArray(dev=out)
 
+    def col_sums_u8(self, data, offsets, n_rows, total, n_cols):
+        """(sums int64[n_cols], counts int64[n_cols]) over the columns of ragged uint8 rows"""
+        sums, counts = self._empty(n_cols, np.int64), self._empty(n_cols, np.int64)
+        self._chk(lib.bnpk_col_sums_u8(self.ctx, ptr(data.dev()), ptr(offsets.dev()), n_rows, total, n_cols, ptr(sums),
+                                       ptr(counts), self._s()))
+        return HArray(dev=sums), HArray(dev=counts)
+
     # -- join_fields: record text from fields (SURVEY 8f-3) ------------------------------------------------------
     def join_lines(self, n_rows, lines, header):
         """lines: per line (data HArray | None, offsets HArray | None, add, prefix, fill byte).  Returns the text

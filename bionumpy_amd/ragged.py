@@ -210,13 +210,28 @@ class RaggedArray:
     @staticmethod
     def _row_axis(axis):
         if axis not in (-1, 1):
-            raise NotImplementedError("reductions over ragged arrays: axis=-1 (per row)")
+            raise NotImplementedError("min / max over ragged arrays: axis=-1 (per row)")
+
+    def _col_sums(self):
+        """(sums, counts) per column: the rows that are long enough contribute (axis=0)"""
+        if self.dtype not in (np.uint8, np.bool_):
+            raise NotImplementedError("column reductions on the MI355X path cover uint8 / bool data")
+        self._compact()
+        data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
+        n_cols = int(self.lengths.max()) if self._n_rows else 0
+        sums, counts = get_ops().col_sums_u8(data, self.offsets(), self._n_rows, self.total(), n_cols)
+        return sums.host(), counts.host()
 
     def sum(self, axis=-1):
+        if axis == 0:
+            return self._col_sums()[0]
         self._row_axis(axis)
         return self._row_reduce("sum")
 
     def mean(self, axis=-1):
+        if axis == 0:
+            sums, counts = self._col_sums()
+            return sums / counts                                            # every column < max length has a row
         self._row_axis(axis)
         with np.errstate(invalid="ignore", divide="ignore"):
             return self._row_reduce("sum") / self.lengths                   # an empty row gives nan, as in numpy

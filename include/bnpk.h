@@ -184,6 +184,12 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
                        int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
 
+/* Per-column sums of ragged uint8 data: np.sum / np.mean(ragged, axis=0) (scripts/small_example.py:20-22,49-52).
+ * d_sums[c] = sum over the rows with more than c elements of their element c, d_counts[c] = number of such rows,
+ * c < n_cols (= the longest row). */
+int bnpk_col_sums_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t total,
+                     int64_t n_cols, int64_t* d_sums, int64_t* d_counts, void* stream);
+
 /* ---- join_fields: the text of records from their fields ----------------------------
  * replaces OneLineBuffer.join_fields / from_data (bionumpy/io/one_line_buffer.py:99-134, io/fastq_buffer.py:46-61):
  * entry r is its n_lines <= 4 lines; line i = prefix[i] (0 or 1) bytes `header`, row r of field i

@@ -25,7 +25,7 @@ against the reference's own golden vectors instead (tests/test_oracle_goldens.py
 
 Every function cites the reference file:line it follows.
 """
-from .ragged import row_starts, row_reduce
+from .ragged import row_starts, row_reduce, col_sums
 from .text import (FormatException, IncompleteEntryException, EncodingError,
                    scan_one_line_buffer, FASTQ, TWO_LINE_FASTA,
                    scan_multiline_fasta, ChunkReader, open_text, join_fields)

@@ -52,3 +52,16 @@ def row_reduce(flat, lengths):
         mins[nz] = np.minimum.reduceat(data, starts)
         maxs[nz] = np.maximum.reduceat(data, starts)
     return sums, mins, maxs
+
+
+def col_sums(flat, lengths):
+    """np.sum(ragged, axis=0) and the number of rows that reach every column (npstructures RaggedArray.sum/mean over
+    axis 0, scripts/small_example.py:20-22,49-52) -> (sums int64[max_len], counts int64[max_len])"""
+    flat = np.asarray(flat)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n_cols = int(lengths.max()) if lengths.size else 0
+    starts = np.cumsum(lengths) - lengths
+    cols = np.arange(int(lengths.sum()), dtype=np.int64) - np.repeat(starts, lengths)
+    sums = np.bincount(cols, weights=flat[:cols.size].astype(np.float64), minlength=n_cols).astype(np.int64)
+    counts = np.bincount(cols, minlength=n_cols).astype(np.int64)
+    return sums, counts

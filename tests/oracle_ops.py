@@ -192,6 +192,10 @@ class OracleOps:
                 fields.append(((data.host()[:int(off.host()[-1])].astype(np.int64) + add).astype(np.uint8), np.diff(off.host())))
         return _h(oracle.join_fields(fields, header, [p for _, _, _, p, _ in lines]))
 
+    def col_sums_u8(self, data, offsets, n_rows, total, n_cols):
+        sums, counts = oracle.col_sums(data.host()[:total], np.diff(offsets.host()))
+        return _h(sums[:n_cols]), _h(counts[:n_cols])
+
     def row_reduce_u8(self, data, offsets, n_rows, want=("sum",)):
         sums, mins, maxs = oracle.row_reduce(data.host(), np.diff(offsets.host()))
         full = {"sum": sums, "min": mins, "max": maxs}

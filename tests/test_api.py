@@ -374,6 +374,13 @@ def test_filter_reads_on_base_quality_and_write_back(bnp, big_fq_gz, tmp_path):
         again = bnp.open(out_name).read()
         assert again.sequence.tolist() == [whole.sequence[int(r)].to_string() for r in expect_rows[:50]] + \
             again.sequence.tolist()[50:]
+    # mean base quality / match rate per read position (scripts/small_example.py:20-22,49-52)
+    col_sums, col_counts = oracle.col_sums(qual, res.field_lens[:, 3])
+    assert np.array_equal(np.sum(whole.quality, axis=0), col_sums)
+    assert np.array_equal(np.mean(whole.quality, axis=0), col_sums / col_counts)
+    matches = bnp.match_string(bnp.change_encoding(whole.sequence, bnp.DNAEncoding), "AC")
+    per_base = np.mean(matches, axis=0)
+    assert per_base.size == int(whole.sequence.lengths.max()) - 1 and 0 < per_base[0] < 1
     with pytest.raises(ValueError):
         np.min(bnp.encodings.QualityEncoding.encode(["II", "", "I"]), axis=1)
 

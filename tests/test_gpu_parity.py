@@ -332,6 +332,10 @@ def test_row_reductions(ops, seed, n_rows, max_len):
     es, emn, emx = oracle.row_reduce(data, lens)
     assert np.array_equal(got["sum"].host(), es)
     assert np.array_equal(got["min"].host(), emn) and np.array_equal(got["max"].host(), emx)
+    # per-column sums / counts (axis=0): rows longer than the LDS table take the global-atomic path
+    cs, cc = oracle.col_sums(data, lens)
+    gs, gc = ops.col_sums_u8(_h(data if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, total, cs.size)
+    assert np.array_equal(gs.host(), cs) and np.array_equal(gc.host(), cc)
 
 
 @pytest.mark.gpu
