@@ -111,6 +111,15 @@ struct mem_source {
     }
     return vm;
   }
+  // only the digit (key >> shift) & mask of every item: what the histogram pass needs
+  __device__ __forceinline__ unsigned digits(int64_t t0, int64_t hi, const raw_t& raw, int shift, unsigned mask,
+                                             unsigned d[RP_MAXITEMS]) const {
+    uint64_t k[RP_MAXITEMS];
+    const unsigned vm = finish(t0, hi, RP_MAXITEMS, raw, k);
+#pragma unroll
+    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(k[q] >> shift) & mask;
+    return vm;
+  }
 };
 
 // The k-mer hashes of the ragged read set, generated on the fly from the packed 2-bit reads (A8).  Items are the
@@ -162,6 +171,29 @@ struct kmer_source {
     }
     return valid;
   }
+  // The histogram pass only needs the digit.  For plain hashes bits [shift, shift + bits) of the k-mer at position p
+  // are bits [2p + shift, ..) of the packed stream itself: one 64-bit window serves the lane's eight positions and
+  // nothing is rolled.  (Canonical hashes have to be built.)
+  __device__ __forceinline__ unsigned digits(int64_t t0, int64_t hi, const raw_t& raw, int shift, unsigned dmask,
+                                             unsigned d[RP_MAXITEMS]) const {
+    if (CANON) {
+      uint64_t kk[RP_MAXITEMS];
+      const unsigned vm = finish(t0, hi, RP_MAXITEMS, raw, kk);
+#pragma unroll
+      for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(kk[q] >> shift) & dmask;
+      return vm;
+    }
+    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
+    const int64_t end = min(t0 + (int64_t)RP_TILE, hi);
+    if (o >= end) return 0;
+    unsigned valid = raw.v;
+    if (end - o < RP_MAXITEMS) valid &= (1u << (int)(end - o)) - 1u;
+    if (valid == 0) return 0;
+    const uint64_t win = window(raw, 2 * (int)(o & 31) + shift);       // (< 128: shift <= 2k - bits <= 61)
+#pragma unroll
+    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(win >> (2 * q)) & dmask;
+    return valid;
+  }
 };
 
 // ---- pass 1 of a level: digit counts per slab ------------------------------------------------------------------
@@ -182,11 +214,11 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
   src.issue(sl.lo, sl.hi, raw);
   for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += RP_TILE) {
     if (t0 + RP_TILE < sl.hi) src.issue(t0 + RP_TILE, sl.hi, raw_next);      // one tile ahead
-    uint64_t k[RP_MAXITEMS];
-    const unsigned vm = src.finish(t0, sl.hi, RP_MAXITEMS, raw, k);
+    unsigned d[RP_MAXITEMS];
+    const unsigned vm = src.digits(t0, sl.hi, raw, shift, (unsigned)(B - 1), d);
 #pragma unroll
     for (int q = 0; q < RP_MAXITEMS; ++q)
-      if ((vm >> q) & 1u) atomicAdd(&h[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+      if ((vm >> q) & 1u) atomicAdd(&h[d[q]], 1u);
     raw = raw_next;
   }
   __syncthreads();
