@@ -199,8 +199,8 @@ def main():
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
         cfg = pmc.get("_config", {})
-        if (cfg.get("reads_per_gpu"), cfg.get("read_len"), cfg.get("k"), cfg.get("mode")) == \
-                (args.reads, args.read_len, args.k, args.mode) and world == 1:
+        if (cfg.get("reads_per_gpu"), cfg.get("read_len"), cfg.get("k"), cfg.get("mode"), bool(cfg.get("canonical", False))) == \
+                (args.reads, args.read_len, args.k, args.mode, bool(args.canonical)) and world == 1:
             names = {"finish_sorted": "finish_sorted", "radix_scatter": "rp_scatter<mem_source>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
                      "fastq_encode": "fq_encode", "fastq_census": "fq_census"}
