@@ -32,6 +32,10 @@ struct bnpk_ctx {
   std::vector<bnpk_pending_event> pending;
   std::vector<hipEvent_t> event_pool;
   hipError_t last_err = hipSuccess;
+  // finishing kernels (finish.hip): launch attributes set / co-resident workgroups of the fast kernel / forced path
+  bool finish_ready = false;
+  int finish_fast_grid = 0;
+  int finish_mode = 0;           // 0 = choose per call, 1 = general kernel only, 2 = fast kernel + redo list only
 };
 
 #define BNPK_HIP(ctx, call)                          \
@@ -134,6 +138,15 @@ __device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v) {
   return v;
 }
 __device__ __forceinline__ int wave_inclusive_scan(int v) { return (int)wave_inclusive_scan((unsigned)v); }
+__device__ __forceinline__ unsigned wave_max(unsigned v) {          // largest of the 64 lanes, in every lane
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ unsigned wave_sum(unsigned v) {          // total of the 64 lanes, in every lane
   return (unsigned)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63);
 }

@@ -626,504 +626,12 @@ __global__ __launch_bounds__(RS_THREADS) void rp_split_small_kernel(const uint64
   }
 }
 
-// ===================================================================================================================
-// Finishing kernel: every bucket of the partitioned keys (equal top bits, <= FN_CAP keys, arbitrary order inside)
-// is sorted in LDS, its duplicates are counted and the distinct (key, count) pairs are written in sorted order.
-// Single pass: buckets are handed out in ticket order; the output offset of a bucket (= number of distinct keys
-// in all earlier buckets) comes from a decoupled look-back over one 64-bit {flag, value} word per bucket, walked
-// by wavefront 0 (64 predecessors per poll) while the other wavefronts rank the bucket's keys, so its latency
-// is hidden.  The next bucket's keys are loaded while the current one is processed.
-constexpr int FN_THREADS = 1024;
-constexpr int FN_CAP = 8192;
-constexpr int FN_ITEMS = FN_CAP / FN_THREADS;
-constexpr int FN_MAXBITS = 12;
-constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
-constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask words
-constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
-constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
-static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
-// d_state words: [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
-// [2] number of distinct keys, [8 + b] status word of bucket b
-constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_BUCKETS = 8;
-constexpr unsigned long long FN_AGG = 1ull << 62, FN_INC = 2ull << 62, FN_VALUE = (1ull << 62) - 1;
-constexpr unsigned FN_SPIN_LIMIT = 1u << 22;
-#ifndef FN_SLEEP
-#define FN_SLEEP 1
-#endif
-
-#define FN_SLOT(w) ((w) & 0x1fffu)
-#define FN_RANK(w) (((w) >> 13) & 0x1fffu)
-#define FN_LESS(w) ((w) >> 26)
-
-constexpr size_t FN_BINS_BYTES = (size_t)(FN_MAXBINS + 4) * 4;
-constexpr size_t FN_OFF_BINS = (size_t)FN_CAP * 8;                      // two bin arrays (ping-pong between buckets)
-constexpr size_t FN_OFF_AUX = FN_OFF_BINS + 2 * FN_BINS_BYTES;          // per slot {rank increments : 16 | duplicates seen : 16}
-constexpr size_t FN_OFF_MASK = FN_OFF_AUX + (size_t)FN_CAP * 4;
-constexpr size_t FN_OFF_LIST = FN_OFF_MASK + (size_t)FN_WORDS * 8;       // per wavefront: slots of the keys with long walks
-constexpr size_t FN_OFF_WSUM = FN_OFF_LIST + (size_t)FN_CAP * 2;
-constexpr size_t FN_OFF_SH = FN_OFF_WSUM + 32 * 4;
-constexpr size_t FN_LDS = FN_OFF_SH + 8 * 8;
-
-// a value every lane holds identically -> scalar registers (the compiler cannot prove that what was read from LDS /
-// global memory is wave-uniform and would keep it in vector registers)
-__device__ __forceinline__ int64_t fn_uniform(int64_t v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
-  return (int64_t)(((uint64_t)hi << 32) | lo);
-}
-
-// the same value, but opaque to the optimiser: what is derived from it is recomputed where it is used (two or three
-// VALU instructions) instead of being hoisted out of the bucket loop and held in — or spilled from — registers
-__device__ __forceinline__ int fn_fresh(int x) {
-  asm volatile("" : "+v"(x));
-  return x;
-}
-
-struct fn_bucket {
-  int64_t b, lo;
-  int nb;          // keys in the bucket; 0 = nothing to sort (empty, past the end, or over capacity)
-  bool over;
-};
-
-// bucket b from its two offsets (loaded one iteration earlier, so nothing waits on them here)
-__device__ __forceinline__ fn_bucket fn_open(int64_t n_buckets, int64_t b, int64_t lo, int64_t hi) {
-  fn_bucket x;
-  x.b = b;
-  x.lo = 0;
-  x.nb = 0;
-  x.over = false;
-  if (b < n_buckets) {
-    x.lo = lo;
-    const int64_t m = hi - lo;
-    x.over = m > FN_CAP;
-    x.nb = x.over ? 0 : (int)m;
-  }
-  return x;
-}
-
-__global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_t* __restrict__ A,
-                                                                   const int64_t* __restrict__ bucket_off,
-                                                                   int64_t n_buckets, int sshift, int sbits,
-                                                                   unsigned long long* __restrict__ state,
-                                                                   uint64_t* __restrict__ keys_out,
-                                                                   int64_t* __restrict__ counts_out,
-                                                                   const int64_t* __restrict__ big_table, int n_big,
-                                                                   const uint64_t* __restrict__ big_keys,
-                                                                   const int64_t* __restrict__ big_counts) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
-  unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);            // bins of the bucket being sorted
-  unsigned* bins_next = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS + FN_BINS_BYTES);   // ... of the one after it
-  unsigned* aux = reinterpret_cast<unsigned*>(smem + FN_OFF_AUX);
-  unsigned long long* fmask = reinterpret_cast<unsigned long long*>(smem + FN_OFF_MASK);
-  unsigned short* wlist = reinterpret_cast<unsigned short*>(smem + FN_OFF_LIST) + (threadIdx.x >> 6) * (FN_ITEMS * 64);
-  unsigned* wsum = reinterpret_cast<unsigned*>(smem + FN_OFF_WSUM);
-  long long* sh = reinterpret_cast<long long*>(smem + FN_OFF_SH);       // [0] next ticket, [1] output base, [2] 2nd ticket
-  unsigned* sh_dups = reinterpret_cast<unsigned*>(sh + 4);              // duplicate counters, alternating between buckets
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: scalar
-  const unsigned SB = 1u << sbits;
-
-  unsigned* fmask32 = reinterpret_cast<unsigned*>(fmask);
-
-  // ---- decoupled look-back, off the critical path.  A bucket's distinct count is published as soon as it is known;
-  // the walk over the predecessors' status words (wavefront 0) starts at the end of the iteration and its first poll
-  // (the 64 nearest words) stays in flight, in a register, across the barrier until the start of the next
-  // iteration, so the latency of the device-scope loads is hidden.  The result is needed when the NEXT bucket is
-  // about to be placed in the stage; until then the sorted keys wait in LDS.  A poll uses every word up to the first
-  // one that has not been published yet (nearest predecessor first); 0.6 further, blocking polls per bucket are
-  // what a late predecessor costs today.
-  // (Measured per 3e9 keys: blocking walk before the final placement 36.0 ms, this 23 ms, no waiting at all 20;
-  // every wavefront polling for itself: 52 ms — the status words are a hot spot.)
-  auto lb_poll = [&](int64_t top) -> unsigned long long {          // lane l: the status word at distance l behind `top`
-    const unsigned long long* first = state + FS_BUCKETS + (top - 63);   // (scalar; only dereferenced where it is valid)
-    const bool in_range = top >= 63 || lane <= (int)top;
-    return in_range ? __hip_atomic_load(first + (63 - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : FN_INC;
-  };
-  unsigned long long lb_v = FN_INC;                    // the poll in flight
-  auto lb_resolve = [&](int64_t b) -> long long {      // distinct keys in all buckets before b
-    long long base = 0;
-    int64_t top = b - 1;
-    unsigned long long v = lb_v;
-    unsigned spins = 0;
-    while (true) {
-      const uint64_t incm = __ballot((v & ~FN_VALUE) == FN_INC);
-      const uint64_t badm = __ballot((v & ~FN_VALUE) == 0);
-      const int first_inc = incm ? __ffsll((long long)incm) - 1 : 64;
-      const int first_bad = badm ? __ffsll((long long)badm) - 1 : 64;
-      const int use = first_inc < first_bad ? first_inc + 1 : first_bad;    // words usable, nearest first
-      long long contrib = lane < use ? (long long)(v & FN_VALUE) : 0ll;
-      contrib = wave_reduce_sum(contrib);
-      base += fn_uniform(__shfl(contrib, 0, 64));
-      if (first_inc < first_bad) break;
-      top -= use;
-      if (use == 0) {
-        if (++spins > FN_SPIN_LIMIT) { if (lane == 0) atomicOr(&state[FS_FLAGS], 2ull); break; }
-        __builtin_amdgcn_s_sleep(FN_SLEEP);
-      }
-      v = lb_poll(top);
-    }
-    return base;
-  };
-
-  // a bucket's own distinct count, published as soon as it is known (nobody waits for the look-back of another bucket)
-  auto publish_count = [&](int64_t b, unsigned D) {
-    if (b > 0 && tid == 0)
-      __hip_atomic_store(&state[FS_BUCKETS + b], FN_AGG | (unsigned long long)D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-
-  for (unsigned i = tid; i <= SB; i += FN_THREADS) { bins[i] = 0; bins_next[i] = 0; }
-  if (tid < FN_WORDS) fmask[tid] = 0;
-  if (tid < 2) sh_dups[tid] = 0;
-  // Software pipeline over tickets: while bucket `cur` is sorted, the keys of the next one are in flight (and get
-  // their bin ranks at the end of the iteration) and the offsets of the one after that are being loaded.
-  // Tickets are taken ONE PER ITERATION at a fixed phase (the second one only after the first bucket's keys have
-  // arrived), so that the i-th buckets of all workgroups form one "round" of consecutive tickets.  Taking two
-  // tickets back to back at the start interleaves the rounds: a workgroup's first bucket then waits for its
-  // neighbour's second one and the launch degenerates into a staircase (measured: 46 vs 37 ms per 3e9 keys).
-  if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
-  __syncthreads();
-  fn_bucket cur;
-  {
-    const int64_t b0 = fn_uniform(sh[0]);
-    cur = fn_open(n_buckets, b0, b0 < n_buckets ? fn_uniform(bucket_off[b0]) : 0, b0 < n_buckets ? fn_uniform(bucket_off[b0 + 1]) : 0);
-  }
-  uint64_t k[FN_ITEMS];
-  unsigned r[FN_ITEMS];
-  unsigned valid = 0;
-#pragma unroll
-  for (int q = 0; q < FN_ITEMS; ++q) {
-    const int i = tid + q * FN_THREADS;
-    if (i < cur.nb) {
-      k[q] = (A + cur.lo)[(unsigned)i];
-      r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
-      valid |= 1u << q;
-    }
-  }
-  __syncthreads();                                    // the ranks are taken
-  if (tid == 0) sh[2] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
-  __syncthreads();
-  int64_t nn_b = fn_uniform(sh[2]), nn_lo = 0, nn_hi = 0;          // the bucket after `cur`: ticket + offsets
-  if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }
-  unsigned parity = 0;
-  // The sorted keys of a bucket stay in LDS until the NEXT bucket is about to be placed there: its look-back runs
-  // at the start of the following iteration, so the predecessors have had the rest of an iteration to publish
-  // their counts, and the workgroups no longer wait for the slowest one of every round.
-  bool have_prev = false, prev_one = true;
-  int64_t prev_b = 0, prev_big = -1;
-  unsigned prev_D = 0;
-  auto resolve_prev = [&]() {                          // wavefront 0: where the previous bucket's output goes
-    const long long base = lb_resolve(prev_b);
-    if (lane == 0) {
-      sh[1] = base;
-      __hip_atomic_store(&state[FS_BUCKETS + prev_b], FN_INC | (unsigned long long)(base + prev_D), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      if (prev_b == n_buckets - 1) state[FS_UNIQUE] = (unsigned long long)(base + prev_D);
-    }
-  };
-  auto emit_prev = [&]() {
-    const int64_t base = fn_uniform(sh[1]);
-    uint64_t* ko = keys_out + base;                    // scalar bases, 32-bit lane offsets
-    int64_t* co = counts_out + base;
-    const unsigned t0 = (unsigned)fn_fresh(tid);
-    if (prev_big >= 0) {                               // pre-counted bucket: copy its (key, count) pairs into place
-      const uint64_t* bk = big_keys + prev_big;
-      const int64_t* bc = big_counts + prev_big;
-      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
-        ko[i] = bk[i];
-        co[i] = bc[i];
-      }
-    } else if (prev_one) {
-      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
-        __builtin_nontemporal_store(stage[i], &ko[i]);
-        __builtin_nontemporal_store((int64_t)1, &co[i]);
-      }
-    } else {
-      for (unsigned i = t0; i < prev_D; i += FN_THREADS) {
-        __builtin_nontemporal_store(stage[i], &ko[i]);
-        __builtin_nontemporal_store((int64_t)aux[i], &co[i]);
-      }
-    }
-  };
-
-  while (cur.b < n_buckets) {
-    const int nb = cur.nb;
-    // A bucket over capacity (heavy-hitter k-mers) has been counted by the caller beforehand: big_table holds
-    // {bucket, distinct keys, offset into big_keys / big_counts} triples sorted by bucket.
-    int64_t big_src = -1;
-    unsigned big_D = 0;
-    if (cur.over) {                                    // uniform
-      int lo_i = 0, hi_i = n_big;
-      while (lo_i < hi_i) {
-        const int mid = (lo_i + hi_i) >> 1;
-        if (big_table[3 * mid] < cur.b) lo_i = mid + 1; else hi_i = mid;
-      }
-      if (lo_i < n_big && big_table[3 * lo_i] == cur.b) {
-        big_D = (unsigned)fn_uniform(big_table[3 * lo_i + 1]);
-        big_src = fn_uniform(big_table[3 * lo_i + 2]);
-      } else if (tid == 0) {
-        atomicOr(&state[FS_FLAGS], 1ull);
-      }
-    }
-
-    // (before this wavefront's loads of the next keys: the memory counter is in-order, younger loads would be waited for)
-    if (have_prev && wave == 0) resolve_prev();
-    // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
-    const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi));
-    uint64_t kn[FN_ITEMS];
-    {
-      const int t = fn_fresh(tid);
-#pragma unroll
-      for (int q = 0; q < FN_ITEMS; ++q) {
-        const int i = t + q * FN_THREADS;
-        if (i < nxt.nb) kn[q] = __builtin_nontemporal_load(&(A + nxt.lo)[(unsigned)i]);   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
-      }
-    }
-    unsigned D = 0;
-    bool all_one = true;                               // every multiplicity of the bucket is 1
-    if (nb == 0) {                                     // empty (or over-capacity) bucket: only its place in the chain
-      D = big_D;
-      publish_count(cur.b, D);
-      __syncthreads();                                 // keeps the reads of the ticket word a barrier away from its next write
-      if (have_prev) emit_prev();
-    } else {
-      // counting sort on the next sbits bits: exclusive scan of the bin counts, keys to their bins
-      {
-        unsigned c[FN_BINS_PER_LANE], sum = 0;
-        const int t = fn_fresh(tid);
-#pragma unroll
-        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-          const unsigned bi = t * FN_BINS_PER_LANE + j;
-          c[j] = (bi < SB) ? bins[bi] : 0;
-          sum += c[j];
-        }
-        const unsigned inc = wave_inclusive_scan(sum);
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned run = inc - sum;
-        for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-        for (int j = 0; j < FN_BINS_PER_LANE; ++j) {
-          const unsigned bi = t * FN_BINS_PER_LANE + j;
-          if (bi < SB) bins[bi] = run;
-          run += c[j];
-        }
-        if (tid == 0) bins[SB] = (unsigned)nb;
-      }
-      if (have_prev) emit_prev();                      // the stage is free for this bucket after the next barrier
-      __syncthreads();
-      // From here on r[q] packs what the ranking needs about a key, in ONE register (the kernel sits at the 128-VGPR
-      // limit of 1024-thread workgroups and every spilled value costs a wait for all loads in flight):
-      // {slot in the stage : 13 | rank in its bin : 13 | earlier keys that are smaller (dense steps) : 6}
-      static_assert(FN_CAP <= 8192, "slot and rank are packed in 13 bits each");
-#pragma unroll
-      for (int q = 0; q < FN_ITEMS; ++q) {
-        if ((valid >> q) & 1u) {
-          const unsigned slot = bins[(unsigned)(k[q] >> sshift) & (SB - 1)] + r[q];
-          stage[slot] = k[q];
-          aux[slot] = 0;
-          r[q] = slot | (r[q] << 13);
-        }
-      }
-      __syncthreads();
-      // Triangular pass over the (tiny) bins: every key meets the keys in EARLIER slots of its bin exactly once.
-      // An earlier key that is smaller adds to this key's rank; one that is larger gets its own rank bumped (LDS
-      // atomic); an equal one — the first hit of the ascending walk is that key's first occurrence — makes this
-      // key a duplicate: it adds itself to the first occurrence's counter and drops out.  The eight keys of a lane
-      // advance together (eight independent LDS reads per step instead of eight latency-bound loops).
-      unsigned active = 0, dup = 0;
-#pragma unroll
-      for (int q = 0; q < FN_ITEMS; ++q)
-        if (((valid >> q) & 1u) && FN_RANK(r[q]) > 0) active |= 1u << q;
-      // Two dense steps (most walks are that short) ...
-      for (unsigned step = 0; step < 2 && __any(active != 0); ++step) {
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          if ((active >> q) & 1u) {
-            const unsigned j = FN_SLOT(r[q]) - FN_RANK(r[q]) + step;
-            const uint64_t y = stage[j];
-            if (y == k[q]) { atomicAdd(&aux[j], 0x10000u); dup |= 1u << q; active &= ~(1u << q); }
-            else {
-              if (y < k[q]) r[q] += 1u << 26; else atomicAdd(&aux[j], 1u);
-              if (step + 1 >= FN_RANK(r[q])) active &= ~(1u << q);
-            }
-          }
-        }
-      }
-      {
-        const unsigned nd = wave_sum((unsigned)__popc(dup));
-        if (lane == 0 && nd) atomicAdd(&sh_dups[parity], nd);
-      }
-      // ... then the few keys with longer walks (~10 %) are compacted into a list private to the wavefront, ONE
-      // per lane, instead of sweeping all eight register slots of every lane for a handful of stragglers.  Their
-      // results travel through LDS: rank increments in aux (low half), "I am a duplicate" in bit 31.
-      if (__any(active != 0)) {                        // wave-uniform
-        unsigned n_items = 0;
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          const bool a = (active >> q) & 1u;
-          const uint64_t m = __ballot(a);
-          if (a) wlist[n_items + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)FN_SLOT(r[q]);
-          n_items += (unsigned)__popcll(m);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (unsigned i0 = 0; i0 < n_items; i0 += 64) {
-          if (i0 + lane < n_items) {
-            const unsigned slot = wlist[i0 + lane];
-            const uint64_t x = stage[slot];
-            const unsigned b0 = bins[(unsigned)(x >> sshift) & (SB - 1)];
-            for (unsigned j = b0 + 2; j < slot; ++j) {
-              const uint64_t y = stage[j];
-              if (y == x) {
-                atomicAdd(&aux[j], 0x10000u);
-                atomicOr(&aux[slot], 0x80000000u);
-                atomicAdd(&sh_dups[parity], 1u);
-                break;
-              }
-              atomicAdd(&aux[y < x ? slot : j], 1u);
-            }
-          }
-        }
-      }
-      __syncthreads();
-      const unsigned n_dups = (unsigned)__builtin_amdgcn_readfirstlane((int)sh_dups[parity]);
-      D = (unsigned)nb - n_dups;                       // distinct keys of the bucket
-      if (n_dups) {                                    // uniform: duplicates found by the list walkers above
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q)
-          if (((valid >> q) & 1u) && (aux[FN_SLOT(r[q])] >> 31)) dup |= 1u << q;
-      }
-      const unsigned first_bits = valid & ~dup;
-      unsigned idx[FN_ITEMS];
-      publish_count(cur.b, D);
-      if (n_dups == 0) {                               // uniform: the common case for well-spread k-mers
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q)
-          if ((valid >> q) & 1u) idx[q] = FN_SLOT(r[q]) - FN_RANK(r[q]) + FN_LESS(r[q]) + (aux[FN_SLOT(r[q])] & 0xffffu);
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q)
-          if ((valid >> q) & 1u) stage[idx[q]] = k[q];
-      } else {
-        // Buckets with duplicates: the first occurrences (bit mask + popcount prefix) are compacted to the front of
-        // the stage in slot order (bins stay contiguous) and ranked among themselves, so the work per key does not
-        // grow with the multiplicities; a first occurrence's multiplicity is 1 + the duplicates that found it above.
-        all_one = false;
-        unsigned bs[FN_ITEMS], lt[FN_ITEMS];           // (this rarely taken branch works on the unpacked fields)
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          const unsigned slot = FN_SLOT(r[q]);
-          r[q] = FN_RANK(r[q]);
-          bs[q] = slot - r[q];
-          lt[q] = 0;
-          if ((first_bits >> q) & 1u) atomicOr(&fmask32[slot >> 5], 1u << (slot & 31));
-        }
-        __syncthreads();
-        // every wavefront scans the popcounts of the mask words in its own registers (lane l: words FN_WPL*l ..)
-        const unsigned c0 = __popcll(fmask[FN_WPL * lane]);
-        const unsigned c1 = FN_WPL == 2 ? __popcll(fmask[FN_WPL * lane + 1]) : 0u;
-        const unsigned pinc = wave_inclusive_scan(c0 + c1);
-        const unsigned pex = pinc - c0 - c1;
-        auto distinct_before = [&](unsigned x) -> unsigned {   // first occurrences in slots < x (all lanes must call)
-          const unsigned w = min(x >> 6, (unsigned)FN_WORDS - 1);
-          const unsigned pw = __shfl(pex, w / FN_WPL, 64), cw = __shfl(c0, w / FN_WPL, 64);
-          const uint64_t below = x >= (unsigned)FN_CAP ? ~0ull : ((1ull << (x & 63)) - 1ull);
-          return pw + ((FN_WPL == 2 && (w & 1)) ? cw : 0u) + __popcll(fmask[w] & below);
-        };
-        unsigned todo = 0;                             // idx[q] = compact start of the bin, r[q] = first occurrences in it,
-#pragma unroll                                         // lt[q] = compact slot | multiplicity << 16
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          const bool is_first = (first_bits >> q) & 1u;
-          unsigned e = bs[q];
-          if (is_first) e = bins[((unsigned)(k[q] >> sshift) & (SB - 1)) + 1];
-          const unsigned slot = bs[q] + r[q];
-          const unsigned cs = distinct_before(bs[q]), ce = distinct_before(e), c = distinct_before(slot);
-          const unsigned m = is_first ? 1u + ((aux[slot] >> 16) & 0x7fffu) : 0u;
-          idx[q] = cs;
-          r[q] = is_first ? ce - cs : 0u;
-          lt[q] = c | (m << 16);
-          if (is_first && ce - cs > 1) todo |= 1u << q;
-        }
-        __syncthreads();                               // every lane has read its slot's counter
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q)
-          if ((first_bits >> q) & 1u) stage[lt[q] & 0xffffu] = k[q];
-        __syncthreads();
-        for (unsigned step = 0; __any(todo != 0); ++step) {            // rank inside the compacted bin, in r[q] >> 16
-#pragma unroll
-          for (int q = 0; q < FN_ITEMS; ++q) {
-            if ((todo >> q) & 1u) {
-              r[q] += (stage[idx[q] + step] < k[q]) ? 0x10000u : 0u;
-              if (step + 1 >= (r[q] & 0xffffu)) todo &= ~(1u << q);
-            }
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          if ((first_bits >> q) & 1u) {
-            stage[idx[q] + (r[q] >> 16)] = k[q];
-            aux[idx[q] + (r[q] >> 16)] = lt[q] >> 16;
-          }
-        }
-        if (tid < FN_WORDS) fmask[tid] = 0;
-        // (the prefetched keys of the next bucket are loaded again here, so that their registers are free
-        // throughout this rarely taken branch)
-#pragma unroll
-        for (int q = 0; q < FN_ITEMS; ++q) {
-          const int i = tid + q * FN_THREADS;
-          if (i < nxt.nb) kn[q] = (A + nxt.lo)[(unsigned)i];
-        }
-      }
-    }
-    // ---- tail: this bucket's bins are free; the next bucket takes its ranks in the other bin array (zeroed one
-    // iteration ago), so its counting sort can start right after the output below
-    const int tt = fn_fresh(tid);
-    for (unsigned i = tt; i <= SB; i += FN_THREADS) bins[i] = 0;
-    if (tid == 0) sh_dups[parity ^ 1] = 0;
-    valid = 0;
-#pragma unroll
-    for (int q = 0; q < FN_ITEMS; ++q) {
-      const int i = tt + q * FN_THREADS;
-      if (i < nxt.nb) {
-        k[q] = kn[q];
-        r[q] = atomicAdd(&bins_next[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
-        valid |= 1u << q;
-      }
-    }
-    // This iteration's ticket (the bucket after the next one).  Taken by wavefront 0 AFTER its look-back: the
-    // order of the tickets then follows the order in which the buckets complete, which keeps the rounds intact
-    // (taken by another wavefront, or earlier in the iteration, the launch becomes unstable: 35-44 / 57-67 ms
-    // instead of 37.4 per 3e9 keys).
-    // The walk over the predecessors' counts starts here, as late as possible: a predecessor that has not published
-    // yet costs a second, blocking poll at the top of the next iteration (measured: 0.61 extra polls per bucket
-    // from here, 0.82 when the poll is issued before the ranks above).
-    if (wave == 0) lb_v = lb_poll(cur.b - 1);
-    if (tid == 0) sh[0] = (long long)atomicAdd(&state[FS_TICKET], 1ull);
-    __syncthreads();
-    nn_b = fn_uniform(sh[0]);
-    if (nn_b < n_buckets) { nn_lo = bucket_off[nn_b]; nn_hi = bucket_off[nn_b + 1]; }   // consumed (made scalar) next iteration
-    have_prev = true;
-    prev_b = cur.b;
-    prev_D = D;
-    prev_one = all_one;
-    prev_big = big_src;
-    unsigned* t = bins; bins = bins_next; bins_next = t;
-    parity ^= 1;
-    cur = nxt;
-  }
-  if (have_prev) {                                     // the last bucket of this workgroup
-    if (wave == 0) resolve_prev();
-    __syncthreads();
-    emit_prev();
-  }
-}
 
 }  // namespace
 
 extern "C" {
 
 int64_t bnpk_radix_max_bits(void) { return RP_MAXBITS; }
-int64_t bnpk_finish_capacity(void) { return FN_CAP; }
 
 int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
                          int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream) {
@@ -1191,47 +699,6 @@ int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, 
   BNPK_HIP(ctx, hipMemcpyAsync(&flag, scratch, 8, hipMemcpyDeviceToHost, s));
   BNPK_HIP(ctx, hipStreamSynchronize(s));
   return flag ? BNPK_ERR_RANGE : BNPK_OK;
-}
-
-int64_t bnpk_finish_state_words(int64_t n_buckets) { return FS_BUCKETS + std::max<int64_t>(n_buckets, 0) + 1; }
-
-int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
-                       int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
-                       const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
-                       int64_t* h_n_unique, int* h_overflow, void* stream) {
-  if (!ctx || n < 0 || n_buckets < 1 || low_bits < 0 || low_bits > 63 || !h_n_unique || !h_overflow || !d_state ||
-      !d_bucket_offsets || n_big < 0 || (n_big > 0 && (!d_big_table || !d_big_keys || !d_big_counts)))
-    return BNPK_ERR_ARG;
-  *h_n_unique = 0;
-  *h_overflow = 0;
-  if (n == 0) return BNPK_OK;
-  if (!d_part || !d_keys_out || !d_counts_out || d_keys_out == d_part) return BNPK_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  const int sbits = std::min(low_bits, FN_MAXBITS);
-  const int sshift = low_bits - sbits;
-  static bool attr_set = false;
-  if (!attr_set) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)FN_LDS));
-    attr_set = true;
-  }
-  BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)bnpk_finish_state_words(n_buckets) * sizeof(int64_t), s));
-  // one workgroup per CU fits (LDS); the ticket order keeps the look-back deadlock-free for any grid size
-  const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
-  {
-    bnpk_timer t(ctx, "finish_sorted", s);
-    hipLaunchKernelGGL(finish_sorted_kernel, dim3(grid), dim3(FN_THREADS), FN_LDS, s,
-                       reinterpret_cast<const uint64_t*>(d_part), d_bucket_offsets, n_buckets, sshift, sbits,
-                       reinterpret_cast<unsigned long long*>(d_state), reinterpret_cast<uint64_t*>(d_keys_out),
-                       d_counts_out, d_big_table, n_big, reinterpret_cast<const uint64_t*>(d_big_keys), d_big_counts);
-    BNPK_HIP(ctx, hipGetLastError());
-  }
-  int64_t host[3] = {0, 0, 0};
-  BNPK_HIP(ctx, hipMemcpyAsync(host, d_state, sizeof(host), hipMemcpyDeviceToHost, s));
-  BNPK_HIP(ctx, hipStreamSynchronize(s));
-  *h_overflow = host[FS_FLAGS] != 0;
-  *h_n_unique = host[FS_UNIQUE];
-  return BNPK_OK;
 }
 
 }  // extern "C"

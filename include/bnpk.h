@@ -61,6 +61,12 @@ int bnpk_prof_reset(bnpk_ctx* ctx);
 int bnpk_prof_count(bnpk_ctx* ctx);                 /* resolves pending events (synchronises) */
 int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t* launches);
 
+/* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
+ * "finish_mode": which finishing kernel bnpk_finish_sorted launches — 0 = chosen per call from a probe of
+ *                the first buckets (default), 1 = the general kernel only, 2 = the fast kernel + redo list only.
+ * Unknown names return BNPK_ERR_ARG. */
+int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value);
+
 /* ---- host staging: pinned buffers and async copies ----------------------------------- */
 /* replaces np.frombuffer(file.read(n)) + cp.asanyarray(chunk)
  * (bionumpy/io/parser.py:203-206, bionumpy/cupy_compatible/parser.py:11-17) */
