@@ -572,7 +572,7 @@ constexpr size_t FF_OFF_STAGE = (size_t)FF_NEAR * 8;                            
 constexpr size_t FF_OFF_P = FF_OFF_STAGE + (size_t)(FF_CAP + FF_NEAR) * 8;          // ... and behind it
 constexpr size_t FF_OFF_WSUM = FF_OFF_P + (((size_t)(FF_MAXBINS + 2) * 2 + 15) & ~(size_t)15);
 constexpr size_t FF_OFF_SH = FF_OFF_WSUM + 3 * FF_WAVES * 4;
-constexpr size_t FF_LDS = FF_OFF_SH + 2 * 8;
+constexpr size_t FF_LDS = FF_OFF_SH + 4 * 8;
 static_assert(2 * FF_LDS <= 160 * 1024, "two workgroups per CU");
 static_assert(FF_CAP <= (1 << 13), "slot / rank are packed in 13 bits");
 // d_state words (fast path): [0] flags (1 = over-capacity bucket without a pre-counted entry, 2 = general kernel's
@@ -580,7 +580,9 @@ static_assert(FF_CAP <= (1 << 13), "slot / rank are packed in 13 bits");
 // [8, 8 + FF_LOG) the announcements {valid : 1 | bucket : 31 | duplicates : 32}, then per bucket: distinct count
 // (int64, scanned in place afterwards), {not emitted : 1 | duplicates known when emitted : 31}, redo mark, and the
 // redo list (ids, bases).
-constexpr int FS_REDO = 3, FS_NLOG = 4, FS_LOG = 8, FS_SPARE = FS_LOG + FF_LOG, FS_FAST = FS_SPARE + 8;
+// The fast kernel's ticket counter has a 128-byte line of its own ([96, 112)): every workgroup hits it once per bucket,
+// and the flags / announcements, which every workgroup reads once per bucket, must not share a line with it.
+constexpr int FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_LOG = 8, FS_SPARE = FS_LOG + FF_LOG, FS_FTICKET = 96, FS_FAST = 112;
 constexpr unsigned FF_BAD = 0x80000000u;
 
 template <int N> struct ff_int { static constexpr int value = N; };
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   unsigned* P32 = reinterpret_cast<unsigned*>(smem + FF_OFF_P);                 // bins: counts, then exclusive offsets
   const unsigned short* P16 = reinterpret_cast<const unsigned short*>(smem + FF_OFF_P);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FF_OFF_WSUM);             // [0..7] scan, [8..15] duplicates, [16..23] long bins
-  long long* sh = reinterpret_cast<long long*>(smem + FF_OFF_SH);               // [0] duplicates known before this bucket, [1] abort
+  long long* sh = reinterpret_cast<long long*>(smem + FF_OFF_SH);               // [0] duplicates known before this bucket, [1] abort, [2] next ticket
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned SB = 1u << sbits;
   const unsigned n_dw = SB > 1 ? SB >> 1 : 1u;           // words holding the bins (+ one for the end offset P[SB])
@@ -654,9 +656,22 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   bucket_t cur = open_bucket(f0, f1, fo);
   load_keys(cur);
   fetch_offsets((int64_t)blockIdx.x + G, f0, f1, fo);
-  for (int64_t b = blockIdx.x; b < n_buckets; b += G) {
-    const bucket_t nxt = open_bucket(f0, f1, fo);        // bucket b + G (its offsets were fetched an iteration ago)
-    fetch_offsets(b + 2 * G, f0, f1, fo);
+  // The first two buckets of a workgroup are blockIdx and blockIdx + G; after that the buckets are handed out by a
+  // ticket counter, three iterations ahead (ticket -> offsets -> keys -> sort), so that the buckets in flight stay
+  // within a few rounds of each other however unevenly the workgroups run: a bucket emitted before an EARLIER
+  // bucket's announcement has to be redone, and without this the fast workgroups run tens of rounds ahead.
+  int64_t b = blockIdx.x, b_nxt = b + G, b_n2 = b_nxt + G;
+  if (tid == 0) b_n2 = 2 * G + (int64_t)atomicAdd(&header[FS_FTICKET], 1ull);
+  if (tid == 0) sh[2] = b_n2;
+  __syncthreads();
+  b_n2 = fn_uniform(sh[2]);
+  for (; b < n_buckets;) {
+    const bucket_t nxt = open_bucket(f0, f1, fo);        // bucket b_nxt (its offsets were fetched an iteration ago)
+    fetch_offsets(b_n2, f0, f1, fo);
+    unsigned long long tk = 0;                           // the ticket after b_n2: in flight until the keys are placed
+    if (tid == 0) tk = atomicAdd(&header[FS_FTICKET], 1ull);
+    int64_t b_n3_latched = 0;
+    auto b_nxt_shift = [&](int64_t v) { b_n3_latched = v; };
     const int nb = cur.nb;
     // wavefront 0: the announcements so far (in flight until the keys are placed)
     unsigned long long lv = 0, fl = 0;
@@ -672,9 +687,12 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
     unsigned D = 0, bad = 0;
     if (nb == 0) {                                       // empty, or a heavy-hitter bucket counted by the caller beforehand
       if (wave == 0) publish_known();
+      if (tid == 0) sh[2] = 2 * G + (long long)tk;
       __syncthreads();
       const unsigned known = (unsigned)fn_uniform(sh[0]);
+      const int64_t b_n3 = fn_uniform(sh[2]);
       if (fn_uniform(sh[1])) return;
+      b_nxt_shift(b_n3);
       if (cur.size > 0) {
         int lo_i = 0, hi_i = n_big;
         while (lo_i < hi_i) {
@@ -782,12 +800,15 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
         }
       }
       if (wave == FF_WAVES - 1) stage[nb + fn_fresh(lane)] = ~0ull;   // guard keys behind the bucket (nobody places a key there)
+      if (tid == 0) sh[2] = 2 * G + (long long)tk;       // (before the loads below: older than them in the memory counter)
       load_keys(nxt);                                    // k[] is free: the next bucket's keys, in flight until the next iteration
       if (wave == 0) publish_known();
       __syncthreads();                                   // (4) the keys are grouped by bin
       FF_MARK(3)
       const unsigned known = (unsigned)fn_uniform(sh[0]);
+      const int64_t b_n3 = fn_uniform(sh[2]);
       if (fn_uniform(sh[1])) return;                     // (uniform) too many buckets with duplicates: the general kernel takes over
+      b_nxt_shift(b_n3);
       uint64_t* ko = keys_out + (cur.out - known);       // scalar bases, 32-bit lane offsets
       int64_t* co = counts_out + (cur.out - known);
       // ---- slot owners.  The keys are grouped by bin, and the bins ascend: among the t keys on either side of a slot
@@ -893,6 +914,9 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
       FF_MARK(5)
     }
     cur = nxt;
+    b = b_nxt;
+    b_nxt = b_n2;
+    b_n2 = b_n3_latched;
   }
 #ifdef FF_PHASES
   if (tid == 64) for (int i = 0; i < 8; ++i) atomicAdd(header + FS_SPARE + i, ph_t[i]);      // (experiment builds only)
@@ -941,6 +965,19 @@ __global__ void finish_collect_kernel(const int64_t* __restrict__ T, const unsig
   }
 }
 
+// How many buckets are too large for the fast kernel but not for the general one (the caller pre-counts only buckets
+// over the general kernel's capacity): with any of them the general kernel takes the call.
+__global__ void finish_fit_kernel(const int64_t* __restrict__ bucket_off, int64_t n_buckets, unsigned long long* __restrict__ header) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned misfits = 0;
+  for (; b < n_buckets; b += stride) {
+    const int64_t m = bucket_off[b + 1] - bucket_off[b];
+    misfits += (m > FF_CAP && m <= FN_CAP) ? 1u : 0u;
+  }
+  if (__any(misfits != 0) && (threadIdx.x & 63) == 0) atomicAdd(&header[FS_MISFIT], 1ull);
+}
+
 // out_off[b] = bucket_off[b] - (keys - distinct keys) of the pre-counted buckets before b: where bucket b starts in the
 // output if no other bucket holds a duplicate.  big_table: {bucket, distinct keys, offset} triples sorted by bucket.
 constexpr int FF_MAXBIG = 1024;
@@ -976,7 +1013,7 @@ __global__ __launch_bounds__(256) void finish_out_offsets_kernel(const int64_t* 
 
 extern "C" {
 
-int64_t bnpk_finish_capacity(void) { return FF_CAP; }
+int64_t bnpk_finish_capacity(void) { return FN_CAP; }
 
 // d_state: the header words; then either the general kernel's 64-bit status words, or the fast path's bookkeeping
 // (announcements, distinct counts, per-bucket notes, redo marks); the redo list; the adjusted output offsets.
@@ -1025,7 +1062,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
   const uint64_t* part = reinterpret_cast<const uint64_t*>(d_part);
   uint64_t* keys_out = reinterpret_cast<uint64_t*>(d_keys_out);
   const uint64_t* big_keys = reinterpret_cast<const uint64_t*>(d_big_keys);
-  int64_t host[4] = {0, 0, 0, 0};
+  int64_t host[6] = {0, 0, 0, 0, 0, 0};
   auto read_header = [&]() -> int {
     BNPK_HIP(ctx, hipMemcpyAsync(host, d_state, sizeof(host), hipMemcpyDeviceToHost, s));
     BNPK_HIP(ctx, hipStreamSynchronize(s));
@@ -1055,8 +1092,14 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
   {
     bnpk_timer t(ctx, "finish_sorted", s);
     if (!use_general) {
-      const int sbits = std::min(low_bits, FF_MAXBITS), sshift = low_bits - sbits;
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+      hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
+                         d_bucket_offsets, n_buckets, state);
+      BNPK_CHECK(read_header());
+      use_general = host[FS_MISFIT] != 0;
+    }
+    if (!use_general) {
+      const int sbits = std::min(low_bits, FF_MAXBITS), sshift = low_bits - sbits;
       BNPK_HIP(ctx, hipMemsetAsync(marks, 0, (size_t)n_buckets * 4, s));
       const int64_t* out_off = d_bucket_offsets;
       if (n_big > 0) {
