@@ -147,24 +147,39 @@ def main():
     dev.prof_enable(False)
     prof = dev.prof_report()
 
-    # ---- sanity on the last step's result (outside the timed region) ----------------------------------------
+    # ---- parity of the FULL-SIZE result of the last step (outside the timed region; tests/fullsize.py) ------------
+    # sparse: order-independent checksums of the whole histogram against the k-mers in read order (another kernel),
+    # plus the k-mers of reads sampled at the start / middle / end computed by the numpy oracle and looked up in the keys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize
+    parity = None
     if isinstance(hist, tuple):
         keys, counts = hist
-        total_counted = int(counts.dev().sum().item())
         n_distinct = keys.size
-        sorted_ok = bool((keys.dev()[1:] > keys.dev()[:-1]).all().item()) if n_distinct > 1 else True
+        hs = fullsize.histogram_sums(keys, counts)
+        rs = fullsize.reads_sums(ops, text, args.reads, args.read_len, args.k, args.canonical)
+        both = torch.tensor([[x - (1 << 64) if x >= (1 << 63) else x for x in hs],
+                             [x - (1 << 64) if x >= (1 << 63) else x for x in rs]], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(both)                    # range-partitioned histogram: the sums must match globally (mod 2^64)
+        assert bool((both[0] == both[1]).all().item()), "full-size parity: checksums differ %s" % both.tolist()
+        sampled = 0
+        if world == 1:
+            sampled = fullsize.sampled_reads_check(ops, keys, counts, args.reads, args.read_len, args.k, args.seed, mode,
+                                                   args.genome_len, rank * args.reads, args.canonical)
+        parity = {"ok": True, "kmers_checked": int(both[1][0].item()), "sampled_kmers_vs_oracle": sampled,
+                  "checks": "count, sum, sum of squares, sum of mixed hashes (mod 2^64) of (key, count) == the same over "
+                            "bnpk_windows_flat in read order; keys strictly increasing; sampled reads' k-mers from the "
+                            "numpy oracle found with equal counts"}
     else:
         total_counted = int(hist.dev().sum().item())
         n_distinct = int((hist.dev() > 0).sum().item())
-        sorted_ok = True
-    counted = torch.tensor([total_counted, stats.n_kmers], dtype=torch.int64, device="cuda")
+        counted = torch.tensor([total_counted, stats.n_kmers], dtype=torch.int64, device="cuda")
+        if world == 1:
+            assert int(counted[0]) == int(counted[1]), "histogram does not account for every k-mer: %s" % counted
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
-        dist.all_reduce(counted)                     # range-partitioned histogram: totals must match globally
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    if args.k > 13 or world == 1:
-        assert int(counted[0]) == int(counted[1]), "histogram does not account for every k-mer: %s" % counted
-    assert sorted_ok, "sparse histogram keys are not strictly increasing"
     dt = float(tmax.item())
 
     if rank != 0:
@@ -232,6 +247,8 @@ def main():
                    "parallelism": "chunk-sharded x%d%s" % (world, ", key-range all-to-all" if world > 1 else "")},
         "roofline": roofline,
         "kernels": kernels,
+        "parity_fullsize": bool(parity and parity["ok"]),
+        "parity": parity,
     }
     if world == 1 and not args.no_cpu_baseline:
         m = min(args.reads, args.cpu_sample_reads)

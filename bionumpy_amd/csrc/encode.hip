@@ -2,6 +2,8 @@
 // Output-flat mapping: one lane produces one packed uint64 (32 bases) so that a wavefront stores
 // 512 contiguous bytes of packed words (and 2 KiB of 1-byte codes); the lane walks the source rows
 // it overlaps, finding its first row by a binary search narrowed to the rows the workgroup touches.
+#include <algorithm>
+
 #include "common.h"
 #include "rows.h"
 
@@ -254,6 +256,44 @@ __global__ void take_bytes_kernel(const uint8_t* __restrict__ buf, const int64_t
   for (; i < m; i += stride) out[i] = buf[pos[i] + delta];
 }
 
+
+// A7 for any alphabet: out[i] = lut[in[i]] (AlphabetEncoding._encode, encodings/alphabet_encoding.py:37-46).  The
+// 256-entry table sits in LDS; a lane translates 16 bytes (one aligned 16-byte load, four table look-ups per dword,
+// one 16-byte store).  A byte whose table entry is 255 is invalid: the smallest such offset is kept in *err.
+__global__ __launch_bounds__(BNPK_BLOCK) void lut_bytes_kernel(const uint8_t* __restrict__ in, int64_t n,
+                                                               const uint8_t* __restrict__ lut_dev,
+                                                               uint8_t* __restrict__ out,
+                                                               unsigned long long* __restrict__ err) {
+  __shared__ uint8_t lut[256];
+  lut[threadIdx.x] = lut_dev[threadIdx.x];
+  __syncthreads();
+  const int64_t n16 = n >> 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+    uint32_t w[4] = {v.x, v.y, v.z, v.w}, r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      r[q] = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t c = lut[(w[q] >> (8 * b)) & 0xffu];
+        if (c == 255u) bad = min(bad, (unsigned long long)(16 * i + 4 * q + b));
+        r[q] |= c << (8 * b);
+      }
+    }
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 15)) {                    // tail bytes
+    const int64_t i = (n16 << 4) + threadIdx.x;
+    const uint8_t c = lut[in[i]];
+    if (c == 255) bad = min(bad, (unsigned long long)i);
+    out[i] = c;
+  }
+  if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
+}
+
 }  // namespace
 
 extern "C" {
@@ -357,6 +397,25 @@ int bnpk_unpack_codes(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n, int to
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   bnpk_timer t(ctx, "unpack_codes", s);
   hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, n, to_ascii, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_lut_bytes(bnpk_ctx* ctx, const uint8_t* d_in, int64_t n, const uint8_t* h_lut256, uint8_t* d_out,
+                   int64_t* d_err_offset, void* stream) {
+  if (!ctx || n < 0 || !h_lut256 || !d_err_offset) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_in || !d_out) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return BNPK_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  void* lut = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, 256, &lut));
+  BNPK_HIP(ctx, hipMemcpyAsync(lut, h_lut256, 256, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));              // (the table is the caller's host memory)
+  bnpk_timer t(ctx, "lut_bytes", s);
+  const int64_t blocks = std::min<int64_t>(std::max<int64_t>(ceil_div(n >> 4, BNPK_BLOCK), 1), (int64_t)ctx->compute_units * 16);
+  hipLaunchKernelGGL(lut_bytes_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_in, n, (const uint8_t*)lut, d_out,
+                     reinterpret_cast<unsigned long long*>(d_err_offset));
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

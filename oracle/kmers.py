@@ -166,15 +166,21 @@ def merge_sparse(parts):
     return ukeys, out
 
 
-def build_kmer_index(codes, lengths, k):
-    """KmerIndex.create_index (kmer_indexing.py:24-47): {int kmer: sorted unique row ids containing it}."""
+def kmer_index_pairs(codes, lengths, k):
+    """the distinct (kmer, row) pairs behind KmerIndex.create_index (kmer_indexing.py:24-47), sorted by kmer then row:
+    for every k-mer value the reference stores np.unique of the rows that contain it."""
     hashes, new_lengths = get_kmers(codes, lengths, k)
     rows = np.repeat(np.arange(len(new_lengths), dtype=np.int64), new_lengths)
     order = np.lexsort((rows, hashes))
     h, r = hashes[order], rows[order]
     keep = np.ones(h.size, dtype=bool)
     keep[1:] = (h[1:] != h[:-1]) | (r[1:] != r[:-1])
-    h, r = h[keep], r[keep]
+    return h[keep], r[keep]
+
+
+def build_kmer_index(codes, lengths, k):
+    """KmerIndex.create_index (kmer_indexing.py:24-47): {int kmer: sorted unique row ids containing it}."""
+    h, r = kmer_index_pairs(codes, lengths, k)
     ukeys, first = np.unique(h, return_index=True)
     bounds = np.concatenate((first, [h.size]))
     return {int(key): r[bounds[i]:bounds[i + 1]] for i, key in enumerate(ukeys)}

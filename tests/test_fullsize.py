@@ -1,0 +1,99 @@
+"""-m gpu: the hot path at sizes the oracle cannot (or can barely) reach, and BASELINE config 5 at its configuration.
+
+* more than 2^32 base positions in one batch (the regression test for the 32-bit position overflow that
+  scripts/debug_large.py chased in round 1): size-independent checks of tests/fullsize.py;
+* S-genome (reads of a fixed genome, every 31-mer ~60 times): the WHOLE histogram of 1 M reads against
+  oracle.count_sparse (np.unique) — the duplicate-heavy path: general finishing kernel, pre-counted buckets;
+* config 5: the 31-mer index of sacCer3 (12 Mbases, 17 records, multi-line FASTA) pair for pair against the oracle's
+  restatement of KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47), and the lookups of all
+  31-mers of big.fq.gz against np.searchsorted / np.isin on the oracle's pairs (kmer_indexing.py:49-55).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import fullsize
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    return ops_mod.get_ops()
+
+
+def test_histogram_of_more_than_2_pow_32_base_positions(ops):
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    n_reads, read_len, k, seed = 30_000_000, 150, 31, 77
+    assert n_reads * read_len > 1 << 32
+    text = ops.synth_fastq(n_reads, read_len, seed, 0, 0, 0)
+    (keys, counts), stats = fastq_kmer_histogram(text, k)
+    assert stats.n_reads == n_reads and stats.n_bases == n_reads * read_len
+    assert stats.n_kmers == n_reads * (read_len - k + 1)
+    done = fullsize.check_histogram(ops, text, n_reads, read_len, k, seed, 0, 0, 0, keys, counts)
+    assert done["kmers"] == stats.n_kmers and done["sampled_kmers_vs_oracle"] > 300_000
+
+
+@pytest.mark.parametrize("canonical,n_reads,genome_len", [(False, 1_000_000, 2_000_000), (True, 300_000, 600_000)])
+def test_genome_reads_whole_histogram_equals_the_oracle(ops, canonical, n_reads, genome_len):
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    from bionumpy_amd import synth
+    read_len, k, seed = 150, 31, 5
+    text = ops.synth_fastq(n_reads, read_len, seed, 1, genome_len, 0)
+    (keys, counts), stats = fastq_kmer_histogram(text, k, canonical=canonical)
+    codes = synth.read_codes(n_reads, read_len, seed, 1, genome_len, 0)
+    h, _ = oracle.get_kmers(codes.reshape(-1), np.full(n_reads, read_len, dtype=np.int64), k)
+    if canonical:
+        h = oracle.canonical_kmers(h, k)
+    ek, ec = oracle.count_sparse(h)
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+    assert ek.size < 2 * genome_len and int(ec.max()) > 20            # (duplicate-heavy indeed)
+
+
+def _oracle_fasta(path):
+    raw, res = oracle.open_text(path).read()
+    codes = oracle.encode_dna(oracle.gather_rows(raw, res.line_starts, res.line_lens))
+    return codes, res.seq_lens
+
+
+def test_config5_saccer3_index_and_lookup(ops):
+    import bionumpy_amd as bnp
+    k = 31
+    path = os.path.join(GOLD, "sacCer3.fa.gz")
+    genome = bnp.open(path).read()
+    seqs = bnp.change_encoding(genome.sequence, bnp.DNAEncoding)
+    codes, lens = _oracle_fasta(path)
+    assert len(genome) == 17 == lens.size and int(seqs.total()) == 12_157_105 == int(lens.sum())
+    index = bnp.KmerIndex.create_index(seqs, k=k)
+    eh, er = oracle.kmer_index_pairs(codes, lens, k)
+    assert np.array_equal(index._keys.host(), eh) and np.array_equal(index._rows.host(), er)          # the whole index
+    # lookups: all 31-mers of big.fq.gz (187 598 of them)
+    reads = bnp.open(os.path.join(GOLD, "big.fq.gz")).read()
+    q = bnp.get_kmers(bnp.change_encoding(reads.sequence, bnp.DNAEncoding), k)
+    q._compact()
+    qh = q._flat_data().host()
+    assert qh.size == 187_598
+    lo, hi = index.get_indices_batch(q._flat_data())
+    assert np.array_equal(lo.host(), np.searchsorted(eh, qh, side="left"))
+    assert np.array_equal(hi.host(), np.searchsorted(eh, qh, side="right"))
+    assert np.array_equal(hi.host() > lo.host(), np.isin(qh, eh))
+    # the scalar API on sampled present and absent k-mers (kmer_indexing.py:49-55: ndarray of rows, [] if unseen)
+    rng = np.random.default_rng(5)
+    ukeys, first = np.unique(eh, return_index=True)
+    bounds = np.concatenate((first, [eh.size]))
+    for i in rng.integers(0, ukeys.size, size=200):
+        np.testing.assert_array_equal(index.get_indices(int(ukeys[i])), er[bounds[i]:bounds[i + 1]])
+    multi = np.flatnonzero(np.diff(bounds) > 1)                          # k-mers shared by several chromosomes
+    for i in multi[:50]:
+        np.testing.assert_array_equal(index.get_indices(int(ukeys[i])), er[bounds[i]:bounds[i + 1]])
+    for x in rng.integers(0, 1 << 62, size=200):
+        if not np.isin(x, ukeys):
+            assert index.get_indices(int(x)) == []
+    text = "".join("ACGT"[c] for c in codes[1000:1000 + k])
+    np.testing.assert_array_equal(index.get_indices(text), er[np.searchsorted(eh, oracle.kmer_from_string(text)):
+                                                               np.searchsorted(eh, oracle.kmer_from_string(text), side="right")])
