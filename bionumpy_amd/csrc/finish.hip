@@ -582,7 +582,7 @@ static_assert(FF_CAP <= (1 << 13), "slot / rank are packed in 13 bits");
 // redo list (ids, bases).
 // The fast kernel's ticket counter has a 128-byte line of its own ([96, 112)): every workgroup hits it once per bucket,
 // and the flags / announcements, which every workgroup reads once per bucket, must not share a line with it.
-constexpr int FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_LOG = 8, FS_SPARE = FS_LOG + FF_LOG, FS_FTICKET = 96, FS_FAST = 112;
+constexpr int FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_LOG = 8, FS_SPARE [[maybe_unused]] = FS_LOG + FF_LOG, FS_FTICKET = 96, FS_FAST = 112;
 constexpr unsigned FF_BAD = 0x80000000u;
 
 template <int N> struct ff_int { static constexpr int value = N; };

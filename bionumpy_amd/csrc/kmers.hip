@@ -288,6 +288,32 @@ __global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t 
   }
 }
 
+// A8 for alphabets that are not 4 letters wide (KmerEncoder.__call__ over a sliding window view, sequence/kmers.py:17-27
+// + rollable.py:46-66): hash = sum_j code[p + j] * A^j in wrapping int64 arithmetic, exactly what numpy's
+// uint8-window.dot(int64 weights) gives.  One lane per output, the row found like in kmer_kernel; the k code bytes of
+// neighbouring lanes overlap, so they come out of L1/L2.
+__global__ __launch_bounds__(BNPK_BLOCK) void kmer_generic_kernel(const uint8_t* __restrict__ codes,
+                                                                  const int64_t* __restrict__ in_off,
+                                                                  const int64_t* __restrict__ out_off, int64_t n_rows,
+                                                                  int64_t n_out, int k, uint64_t alphabet_size,
+                                                                  const int64_t* __restrict__ tile_rows,
+                                                                  int64_t* __restrict__ out) {
+  int64_t rr[2];
+  const int64_t tile = (int64_t)blockIdx.x * TILE_OUT;
+  if (tile >= n_out) return;
+  tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
+  for (int64_t o = tile + threadIdx.x; o < min(tile + (int64_t)TILE_OUT, n_out); o += BNPK_BLOCK) {
+    const int64_t row = find_row(out_off, rr[0], rr[1], o);
+    const uint8_t* src = codes + in_off[row] + (o - out_off[row]);
+    uint64_t h = 0, w = 1;
+    for (int j = 0; j < k; ++j) {
+      h += (uint64_t)src[j] * w;
+      w *= alphabet_size;
+    }
+    out[o] = (int64_t)h;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -415,6 +441,24 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
   BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL((kmer_kernel<false>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
                      d_out_offsets, n_rows, n_out, k, 1, (const int64_t*)table, d_hashes);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_kmers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
+                       int64_t n_rows, int64_t n_out, int k, int alphabet_size, int64_t* d_hashes, void* stream) {
+  if (!ctx || k < 1 || k > 31 || alphabet_size < 1 || alphabet_size > 255 || n_rows < 0 || n_out < 0) return BNPK_ERR_ARG;
+  if (n_out == 0) return BNPK_OK;
+  if (!d_codes || !d_in_offsets || !d_out_offsets || !d_hashes || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n_out, TILE_OUT);
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  bnpk_timer t(ctx, "kmers_generic", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
+  hipLaunchKernelGGL(kmer_generic_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, d_in_offsets,
+                     d_out_offsets, n_rows, n_out, k, (uint64_t)alphabet_size, (const int64_t*)table, d_hashes);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

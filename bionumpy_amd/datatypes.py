@@ -70,6 +70,16 @@ class SequenceEntry:
     def __repr__(self):
         return "%s with %d entries" % (self.__class__.__name__, len(self))
 
+    def __array_function__(self, func, types, args, kwargs):
+        """np.concatenate(chunks) (bnpdataclass/lazybnpdataclass.py:178-196, bnpdataclass.py:477-493): the entries of
+        all chunks, every field joined (on the device) in chunk order"""
+        if func is not np.concatenate:
+            return NotImplemented
+        chunks = list(args[0])
+        if not chunks or not all(isinstance(c, SequenceEntry) and c._fields == self._fields for c in chunks):
+            return NotImplemented
+        return self.__class__(**{f: np.concatenate([getattr(c, f) for c in chunks]) for f in self._fields})
+
 
 class SequenceEntryWithQuality(SequenceEntry):
     _fields = ("name", "sequence", "quality")

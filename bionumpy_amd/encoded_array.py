@@ -169,20 +169,29 @@ class AlphabetEncoding(OneToOneEncoding):
     def get_labels(self):
         return self.get_alphabet()
 
-    def _require_dna(self):
-        if "".join(self._raw_alphabet) != "ACGT":
-            raise NotImplementedError("only AlphabetEncoding('ACGT') (DNAEncoding) has a device encoder on this path")
+    def _is_dna(self):
+        return "".join(self._raw_alphabet) == "ACGT"
+
+    def _lookup(self):
+        """the reference's 256-entry table (alphabet_encoding.py:19-32): both cases of a letter -> its code, else 255"""
+        lut = np.full(256, 255, dtype=np.uint8)
+        lut[self._alphabet] = np.arange(self._alphabet.size)
+        lut[self._alphabet + (ord("a") - ord("A"))] = np.arange(self._alphabet.size)
+        return lut
 
     def _encode_flat(self, harray):
-        self._require_dna()
-        codes, packed = get_ops().encode_dna_flat(harray, want_codes=False, want_packed=True)
-        return _PackedDna(packed, harray.size)
+        if self._is_dna():                                   # fused LUT + 2-bit packing
+            codes, packed = get_ops().encode_dna_flat(harray, want_codes=False, want_packed=True)
+            return _PackedDna(packed, harray.size)
+        return get_ops().lut_bytes(harray, self._lookup(), str(self))
 
     def _encode_gather(self, data, starts, offsets, n_rows, total):
-        self._require_dna()
-        codes, packed = get_ops().gather_encode_dna(data, starts, offsets, n_rows, total, want_codes=False,
-                                                    want_packed=True)
-        return _PackedDna(packed, total)
+        if self._is_dna():
+            codes, packed = get_ops().gather_encode_dna(data, starts, offsets, n_rows, total, want_codes=False,
+                                                        want_packed=True)
+            return _PackedDna(packed, total)
+        return get_ops().lut_bytes(get_ops().gather_rows(data, starts, offsets, n_rows, total, 0), self._lookup(),
+                                   str(self))
 
     def _decode_codes(self, codes):
         return self._alphabet[np.asarray(codes)]
@@ -362,6 +371,58 @@ class EncodedArray:
 
     def __array__(self, dtype=None, copy=None):
         return self.raw() if dtype is None else self.raw().astype(dtype)
+
+    def _n_codes(self):
+        """number of distinct codes of the encoding, where it says (letters, k-mers), else 0"""
+        enc = self.encoding
+        if hasattr(enc, "alphabet_size"):
+            return int(enc.alphabet_size)
+        if hasattr(enc, "_alphabet_encoding"):
+            return int(enc._alphabet_encoding.alphabet_size) ** int(enc.k)
+        return 0
+
+    def __array_function__(self, func, types, args, kwargs):
+        """the numpy functions the reference answers for EncodedArrays (encoded_array.py:454-486).  np.concatenate joins
+        1-D arrays in HBM, np.bincount with minlength is the device histogram; the others (index arithmetic on small
+        arrays in the reference's own use) run on the host copy of the codes."""
+        cls = self.__class__
+        if func is np.concatenate:
+            parts = list(args[0])
+            if not all(isinstance(e, EncodedArray) for e in parts):
+                return NotImplemented
+            assert all(e.encoding == self.encoding for e in parts), "arrays of different encodings"
+            if all(e.ndim == 1 for e in parts) and kwargs.get("axis", 0) == 0:
+                stores = [e._store._unpacked() if isinstance(e._store, _PackedDna) else e._store for e in parts]
+                return cls(get_ops().concat(stores), self.encoding)
+            return cls(func([e.raw() for e in parts], *args[1:], **kwargs), self.encoding)
+        if func is np.bincount:
+            minlength = int(kwargs.get("minlength", args[1] if len(args) > 1 else 0) or 0)
+            n_codes = self._n_codes()
+            if n_codes and n_codes <= (1 << 26) and len(args) <= 2 and set(kwargs) <= {"minlength"} and self.ndim == 1:
+                store = self._store._unpacked() if isinstance(self._store, _PackedDna) else self._store
+                if store.dtype != np.int64:
+                    store = HArray(host=store.host().astype(np.int64))
+                hist = get_ops().count_dense(store, max(n_codes, minlength)).host()
+                used = np.flatnonzero(hist)
+                return hist[:max(minlength, int(used[-1]) + 1 if used.size else 0)].copy()     # numpy's length: max(minlength, max + 1)
+            return np.bincount(args[0].raw(), *args[1:], **kwargs)
+        if func is np.argsort:
+            return np.argsort(args[0].raw(), *args[1:], **kwargs)
+        if func is np.where:
+            return cls(func(args[0], args[1].raw(), args[2].raw()), self.encoding)
+        if func is np.zeros_like:
+            return cls(func(args[0].raw(), *args[1:], **kwargs), self.encoding)
+        if func is np.append:
+            return cls(func(args[0].raw(), args[1].raw(), *args[2:], **kwargs), self.encoding)
+        if func is np.lexsort:
+            if not all(issubclass(t, (EncodedArray, np.ndarray)) for t in types):
+                return NotImplemented
+            return func([a.raw() if isinstance(a, EncodedArray) else np.asarray(a) for a in args[0]], *args[1:], **kwargs)
+        if func is np.insert:
+            return cls(func(args[0].raw(), args[1], args[2].raw(), *args[3:], **kwargs), self.encoding)
+        if func is np.lib.stride_tricks.sliding_window_view:
+            return cls(func(args[0].raw(), *args[1:], **kwargs), self.encoding)
+        return NotImplemented
 
 
 class EncodedRaggedArray(RaggedArray):

@@ -230,6 +230,30 @@ class HipOps:
     def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
         return self._windows_flat(packed, in_offsets, n_rows, n_out, k, k)
 
+    def kmers_generic(self, codes, in_offsets, out_offsets, n_rows, n_out, k, alphabet_size):
+        """hashes sum_j code[p + j] * alphabet_size^j of every window of k codes (bnpk_kmers_generic): the k-mers of
+        alphabets that are not 4 letters wide"""
+        out = self._empty(n_out, np.int64)
+        if n_out:
+            self._chk(lib.bnpk_kmers_generic(self.ctx, ptr(codes.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
+                                             n_rows, n_out, k, alphabet_size, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def lut_bytes(self, data, lut, what="AlphabetEncoding"):
+        """lut[data] on the device (bnpk_lut_bytes); EncodingError(offset of the first byte that maps to 255)"""
+        n = data.size
+        out = self._empty(n, np.uint8)
+        if n:
+            table = np.ascontiguousarray(lut, dtype=np.uint8)
+            assert table.size == 256
+            cell = self._err_cell()
+            self._chk(lib.bnpk_lut_bytes(self.ctx, ptr(data.dev()), n, table.ctypes.data_as(C.c_void_p), ptr(out), ptr(cell),
+                                         self._s()))
+            off = int(cell.item())
+            if off != NONE:
+                raise EncodingError("Error when encoding to %s: invalid character at flat offset %d" % (what, off), off)
+        return HArray(dev=out)
+
     def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
         if window_size - k + 1 <= self.WINDOWS_FLAT_MAX:
             return self._windows_flat(packed, in_offsets, n_rows, n_out, k, window_size)

@@ -248,7 +248,25 @@ class RaggedArray:
     def max(self, axis=-1):
         return self._extreme("max", axis)
 
+    @staticmethod
+    def _concatenate(arrays):
+        """np.concatenate of ragged arrays == the rows of all of them, in order (npstructures RaggedArray
+        __array_function__; what np.concatenate(chunks) does to every field): flat data joined on the device."""
+        for a in arrays:
+            a._compact()
+        ops = get_ops()
+        flats = [a._flat_data() for a in arrays]
+        flats = [f._unpacked() if hasattr(f, "_unpacked") else f for f in flats]
+        lens = np.concatenate([a.lengths for a in arrays]) if arrays else np.zeros(0, dtype=np.int64)
+        data = ops.concat(flats) if sum(f.size for f in flats) else flats[0]
+        return arrays[0]._like(data, None, as_harray(lens.astype(np.int64)), None, lens.size, int(lens.sum()))
+
     def __array_function__(self, func, types, args, kwargs):
+        if func is np.concatenate:
+            arrays = list(args[0])
+            if not all(isinstance(a, RaggedArray) for a in arrays) or kwargs.get("axis", 0) != 0:
+                return NotImplemented
+            return self._concatenate(arrays)
         name = {np.sum: "sum", np.mean: "mean", np.min: "min", np.max: "max", np.amin: "min", np.amax: "max"}.get(func)
         if name is None or not args or args[0] is not self:
             return NotImplemented

@@ -156,7 +156,11 @@ def count_encoded(values, weights=None, axis=-1):
     k = getattr(encoding, "k", None)
     if flat_request and k is not None and k > 8:
         store = _flat_store(values)
-        keys, counts = ops.count_sparse(store, key_bits=2 * k)
+        n_letters = encoding._alphabet_encoding.alphabet_size
+        key_bits = 2 * k if n_letters == 4 else (n_letters ** k - 1).bit_length()
+        if key_bits > 62:
+            raise NotImplementedError("sparse counts need k-mer hashes below 2^62 (%d letters, k = %d)" % (n_letters, k))
+        keys, counts = ops.count_sparse(store, key_bits=key_bits)
         return SparseKmerCounts(encoding, keys, counts)
     alphabet = encoding.get_alphabet() if hasattr(encoding, "get_alphabet") else encoding.get_labels()
     n_bins = len(alphabet)

@@ -37,7 +37,8 @@ def _rolling(sequence, window, kernel):
 
 
 def _as_four_letter(sequence):
-    """the encoding checks get_kmers makes (kmers.py:66-81), returning the 2-bit encoded sequence"""
+    """the encoding checks get_kmers makes (kmers.py:66-81): base-encoded input becomes DNA, anything else must carry an
+    AlphabetEncoding"""
     if sequence.encoding == BaseEncoding:
         try:
             sequence = change_encoding(sequence, DNAEncoding)
@@ -48,10 +49,46 @@ def _as_four_letter(sequence):
     assert isinstance(sequence.encoding, AlphabetEncoding), \
         "Sequence needs to be encoded with an AlphabetEncoding, e.g. DNAEncoding. " \
         "Change encoding of your sequences by using e.g. bnp.change_encoding(sequences, bnp.DNAEncoding)"
-    if sequence.encoding.alphabet_size != 4:
-        raise NotImplementedError("only 4-letter alphabets (the 2-bit fast path, kmers.py:82-85) are on the "
-                                  "MI355X path")
     return sequence
+
+
+def _get_kmers_generic(sequence, k):
+    """KmerEncoder(k, encoding).rolling_window(sequence) (sequence/kmers.py:17-27,87; rollable.py:29-69): the path of
+    alphabets that are not 4 letters wide — hash = codes . alphabet_size ** arange(k), trimmed per row."""
+    ops = get_ops()
+    single = isinstance(sequence, EncodedArray)
+    if single:
+        sequence = EncodedRaggedArray(sequence.ravel(), [sequence.size])
+    sequence._compact()
+    lens, n_rows = sequence._lens, len(sequence)
+    out_off, n_out = ops.row_offsets(lens, k)
+    hashes = ops.kmers_generic(sequence._data, sequence.offsets(), out_off, n_rows, n_out, k,
+                               sequence.encoding.alphabet_size)
+    encoding = KmerEncoding(sequence.encoding, k)
+    if single:
+        return EncodedArray(hashes, encoding)
+    return EncodedRaggedArray._from_parts(hashes, None, _trimmed_lens(out_off, lens, k), out_off, n_rows, n_out, encoding)
+
+
+class KmerEncoder:
+    """KmerEncoder (sequence/kmers.py:17-33): the generic rolling k-mer hash of any AlphabetEncoding.  get_kmers uses it
+    for alphabets that are not 4 letters wide; for 4 letters it gives the same hashes as the 2-bit path
+    (tests/test_kmer.py:27-30)."""
+
+    def __init__(self, k, alphabet_encoding):
+        assert isinstance(alphabet_encoding, AlphabetEncoding), alphabet_encoding
+        self.window_size = k
+        self._k = k
+        self._encoding = alphabet_encoding
+
+    def rolling_window(self, sequence):
+        return _get_kmers_generic(as_encoded_array(sequence, self._encoding), self._k)
+
+    def __call__(self, sequence):
+        """the hash of one window of exactly k letters"""
+        sequence = as_encoded_array(sequence, self._encoding)
+        assert sequence.size == self._k
+        return _get_kmers_generic(sequence, self._k)
 
 
 def get_kmers(sequence, k, canonical=False):
@@ -63,6 +100,8 @@ def get_kmers(sequence, k, canonical=False):
     sequence = _as_four_letter(sequence)
     if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":
         raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
+    if sequence.encoding.alphabet_size != 4:                 # (kmers.py:82-87: only 4-letter alphabets take the 2-bit path)
+        return _get_kmers_generic(sequence, k)
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
         sequence, k, lambda ops, p, i, o, n, m: ops.kmers(p, i, o, n, m, k))
     if canonical and n_out:
@@ -109,7 +148,7 @@ def count_kmers(sequence, k, axis=None, canonical=False):
     For the flattened sparse histogram the hashes are never laid out row by row: they are generated straight
     into the first radix level of the counting sort (bnpk_kmers_partition), as in pipeline.py."""
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
-    if axis is None and k > 8:
+    if axis is None and k > 8 and _as_four_letter(sequence).encoding.alphabet_size == 4:
         from .count_encoded import SparseKmerCounts
         sequence = _as_four_letter(sequence)
         if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":

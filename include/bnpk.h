@@ -156,6 +156,12 @@ int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d
                            const int64_t* d_offsets, int64_t n_rows, int64_t total,
                            uint8_t* d_codes, uint64_t* d_packed, int64_t* d_err_offset,
                            void* stream);
+/* A7 for any alphabet: d_out[i] = h_lut256[d_in[i]] — `self._lookup[byte_array]` of AlphabetEncoding._encode
+ * (bionumpy/encodings/alphabet_encoding.py:19-46; the table maps both cases of every letter to its code and
+ * everything else to 255).  *d_err_offset = smallest offset of a byte that maps to 255 (EncodingError.offset), or
+ * BNPK_NONE (initialised by the caller).  In place (d_out == d_in) is allowed; both 16-byte aligned. */
+int bnpk_lut_bytes(bnpk_ctx* ctx, const uint8_t* d_in, int64_t n, const uint8_t* h_lut256, uint8_t* d_out,
+                   int64_t* d_err_offset, void* stream);
 /* plain ragged gather with an optional constant subtracted (33 -> QualityEncoding,
  * bionumpy/encodings/__init__.py:15-16,26; 0 -> names / raw text) */
 int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
@@ -263,6 +269,12 @@ int bnpk_pwm_scores(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_s
 int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_kmer_starts, int64_t n_bases, int k,
                          int canonical, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
 
+/* A8 for alphabets that are not 4 letters wide: KmerEncoder.__call__ over every window of k codes
+ * (bionumpy/sequence/kmers.py:17-27,87; sequence/rollable.py:46-66): hash = sum_j code[p + j] * alphabet_size^j in
+ * wrapping int64 arithmetic (numpy's uint8 windows .dot(int64 weights)), trimmed per row like bnpk_kmers.
+ * d_codes: 1 byte per letter, rows at d_in_offsets. */
+int bnpk_kmers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
+                       int64_t n_rows, int64_t n_out, int k, int alphabet_size, int64_t* d_hashes, void* stream);
 /* ---- A11: minimizers -----------------------------------------------------------------------------
  * replaces get_minimizers / Minimizers.__call__ (bionumpy/sequence/minimizers.py:8-54): for every
  * window of `window_size` bases the minimum raw hash of its window_size-k+1 k-mers.

@@ -231,6 +231,18 @@ class OracleOps:
         assert h.size == n_out
         return _h(h)
 
+    def kmers_generic(self, codes, in_offsets, out_offsets, n_rows, n_out, k, alphabet_size):
+        off = in_offsets.host()
+        h, _ = oracle.get_kmers_generic(codes.host()[:int(off[-1])], np.diff(off), k, alphabet_size)
+        assert h.size == n_out
+        return _h(h)
+
+    def lut_bytes(self, data, lut, what="AlphabetEncoding"):
+        try:
+            return _h(oracle.encode_dna(data.host(), np.asarray(lut, dtype=np.uint8), 255))
+        except otext.EncodingError as e:
+            raise EncodingError(e.message, e.offset)
+
     def minimizers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, window_size):
         off = in_offsets.host()
         m, _ = oracle.get_minimizers(_unpack(packed, int(off[-1])), np.diff(off), k, window_size)

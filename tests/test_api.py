@@ -41,6 +41,69 @@ def test_get_kmers_docstring(bnp):
                            "                      [TTG, TGG, GGC]], 3merEncoding(AlphabetEncoding('ACGT')))")
 
 
+def test_generic_alphabets(bnp):
+    # any AlphabetEncoding encodes (encodings/alphabet_encoding.py:19-46) and hashes (sequence/kmers.py:17-27,82-87)
+    acgtn = bnp.AlphabetEncoding("ACGTN")
+    enc = bnp.as_encoded_array("ACGTNacgtn", acgtn)
+    assert enc.raw().tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4] and str(enc) == "ACGTNACGTN"
+    with pytest.raises(bnp.EncodingError) as e:
+        bnp.as_encoded_array(["ACGT", "NNX", "A"], acgtn)
+    assert e.value.offset == 6
+    seqs = bnp.as_encoded_array(["ACGTN", "NN", "", "GATTACANNNGATTACA"], acgtn)
+    kmers = bnp.sequence.get_kmers(seqs, 3)
+    assert [[str(k) for k in row] for row in kmers][:3] == [["ACG", "CGT", "GTN"], [], []]
+    codes = np.concatenate([r for r in seqs.raw()]).astype(np.uint8)
+    lens = np.array([5, 2, 0, 17])
+    expect, new_lens = oracle.get_kmers_generic(codes, lens, 3, 5)
+    assert np.array_equal(np.concatenate([np.asarray(r) for r in kmers.raw()]), expect)
+    assert [len(r) for r in kmers] == new_lens.tolist() == [3, 0, 0, 15]
+    counts = bnp.count_encoded(kmers, axis=None)
+    assert counts["NNN"] == 1 and counts["TAC"] == 2 and counts["AAA"] == 0
+    # amino acids, k large enough for the int64 hash to wrap like numpy's dot
+    protein = bnp.AlphabetEncoding("ACDEFGHIKLMNPQRSTVWY")
+    text = "MKVLAAGIVGLHRHSWYWYWYMKVLAAGIVGLHRHSWY"
+    one = bnp.as_encoded_array(text, protein)
+    for k in (1, 5, 14, 20):
+        got = bnp.sequence.get_kmers(one, k).raw()
+        expect, _ = oracle.get_kmers_generic(one.raw().astype(np.uint8), np.array([len(text)]), k, 20)
+        assert np.array_equal(got, expect), k
+    # tests/test_kmer.py:27-30: the generic encoder agrees with the 2-bit path on DNA
+    dna = bnp.as_encoded_array(["cgtt", "AacACtggatcggacTTATCTGACG", "G"], bnp.DNAEncoding)
+    fast = bnp.sequence.get_kmers(dna, 3)
+    generic = bnp.sequence.kmers.KmerEncoder(3, bnp.DNAEncoding).rolling_window(dna)
+    assert fast.tolist() == generic.tolist() and fast.encoding == generic.encoding
+    assert int(bnp.sequence.kmers.KmerEncoder(3, bnp.DNAEncoding)("ACG").raw()[0]) == 0 + 1 * 4 + 2 * 16
+
+
+def test_numpy_functions_on_encoded_arrays(bnp, big_fq_gz):
+    # encoded_array.py:454-486 (__array_function__) and np.concatenate(chunks) (lazybnpdataclass.py:178-196)
+    a = bnp.as_encoded_array("ACGT", bnp.DNAEncoding)
+    b = bnp.as_encoded_array("TTG", bnp.DNAEncoding)
+    both = np.concatenate([a, b])
+    assert isinstance(both, bnp.EncodedArray) and both.encoding == bnp.DNAEncoding and str(both) == "ACGTTTG"
+    assert np.bincount(both, minlength=4).tolist() == [1, 1, 2, 3] and np.bincount(both).tolist() == [1, 1, 2, 3]
+    assert np.argsort(both).tolist() == np.argsort(both.raw()).tolist()
+    assert str(np.append(a, b)) == "ACGTTTG" and str(np.zeros_like(a)) == "AAAA"
+    assert str(np.where(np.array([True, False, True, False]), a, bnp.as_encoded_array("TTTT", bnp.DNAEncoding))) == "ATGT"
+    assert np.lexsort((a, np.array([1, 0, 1, 0]))).tolist() == [1, 3, 0, 2]
+    ragged = [bnp.as_encoded_array(["ACG", "", "T"], bnp.DNAEncoding), bnp.as_encoded_array(["GG", "TTTT"], bnp.DNAEncoding)]
+    joined = np.concatenate(ragged)
+    assert isinstance(joined, bnp.EncodedRaggedArray) and joined.tolist() == ["ACG", "", "T", "GG", "TTTT"]
+    kmers = np.concatenate([bnp.sequence.get_kmers(r, 2) for r in ragged])
+    assert [[str(k) for k in row] for row in kmers] == [["AC", "CG"], [], [], ["GG"], ["TT", "TT", "TT"]]
+    # chunks of a file, joined again: the same entries as one read of the whole file
+    chunks = list(bnp.open(big_fq_gz).read_chunks(min_chunk_size=100_000))
+    assert len(chunks) > 1
+    whole = bnp.open(big_fq_gz).read()
+    glued = np.concatenate(chunks)
+    assert len(glued) == len(whole) == 1000
+    for field in ("name", "sequence"):
+        assert getattr(glued, field).tolist() == getattr(whole, field).tolist()
+    assert np.array_equal(np.asarray(glued.quality.ravel()), np.asarray(whole.quality.ravel()))
+    counts = bnp.count_encoded(bnp.sequence.get_kmers(bnp.change_encoding(glued.sequence, bnp.DNAEncoding), 3), axis=None)
+    assert counts["AAA"] == 3920 and counts["ACT"] == 3038                 # SURVEY §8c derived goldens
+
+
 def test_kmers_topic_doc(bnp):
     # docs_source/topics/kmers.rst:11-27
     sequences = bnp.as_encoded_array(["ACTG", "GGGACT", "G"], bnp.DNAEncoding)
