@@ -158,6 +158,16 @@ __device__ __forceinline__ T wave_reduce_sum(T v) {
   return v;
 }
 
+template <typename T>
+__device__ __forceinline__ T wave_reduce_max(T v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    const T o = __shfl_down(v, d, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
 // largest r in [lo, hi] with offsets[r] <= pos (offsets non-decreasing, offsets[lo] <= pos).
 // With runs of equal offsets (empty rows) this returns the LAST such r, i.e. the non-empty row
 // that actually contains pos.

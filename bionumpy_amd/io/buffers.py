@@ -220,30 +220,37 @@ class FastQBuffer(OneLineBuffer):
 
 
 class MultiLineFastaBuffer(FileBuffer):
-    """multiline_buffer.py:15-106.  The newline scan and the '>' probes run on the device; the per-line
-    bookkeeping (a few int64 per *line*) follows the reference's numpy expressions on the host, and the
-    sequence lines are joined by the device gather when the field is encoded / ravelled."""
+    """multiline_buffer.py:15-106.  Everything per line happens on the device: the newline scan, the cut at the last
+    newline that is followed by '>' (bnpk_multiline_cut), the header / sequence-line / record-length tables
+    (bnpk_multiline_table: classification, three scans, one scatter) and the join of a record's sequence lines (ragged
+    gather).  ``from_data`` (the writer: lines of 80 letters) is one output-flat kernel (bnpk_multiline_wrap)."""
 
     SKIP_LAZY = True
     _new_entry_marker = ">"
+    n_characters_per_line = 80
     n_lines_per_entry = 2
     dataclass = SequenceEntry
 
-    def __init__(self, data, size, new_lines, new_entries):
+    def __init__(self, data, size, newlines, n_newlines, n_entries):
         self._data = data
         self._size = size
-        self._new_lines = new_lines            # host int64
-        self._new_entries = new_entries        # host int64 (indices into new_lines)
+        self._newlines = newlines              # HArray int64: positions of the newlines of the chunk (device)
+        self._n_newlines = n_newlines          # ... of which the cut chunk keeps this many
+        self._n_entries = n_entries
 
     @property
     def n_lines(self):
-        return len(self._new_lines)
+        return self._n_newlines
+
+    @property
+    def size(self):
+        return self._size
 
     def count_entries(self):
-        return len(self._new_entries) + 1
+        return self._n_entries
 
     def __len__(self):
-        return self.count_entries()
+        return self._n_entries
 
     @classmethod
     def contains_complete_entry(cls, chunks):
@@ -266,46 +273,42 @@ class MultiLineFastaBuffer(FileBuffer):
         ops = get_ops()
         data = _chunk_to_harray(chunk)
         n = data.size
-        newlines, _ = ops.newline_positions(data, n - 1, 1)          # chunk[:-1] == "\n"  (:93)
+        marker = ord(cls._new_entry_marker)
         first = ops.take_bytes(data, HArray(host=np.zeros(1, dtype=np.int64)), 0).host()[0]
-        assert first == ord(cls._new_entry_marker), "multi-line FASTA chunk must start with '>'"
-        marks = ops.take_bytes(data, newlines, 1).host()              # chunk[new_lines + 1]     (:94)
-        new_lines = newlines.host()
-        new_entries = np.flatnonzero(marks == ord(cls._new_entry_marker))
-        if new_entries.size == 0:
+        assert first == marker, "multi-line FASTA chunk must start with '>'"
+        newlines, _ = ops.newline_positions(data, n - 1, 1)          # chunk[:-1] == "\n"            (:93)
+        last, count = ops.multiline_cut(data, newlines, marker)      # chunk[new_lines + 1] == ">"    (:94)
+        if count == 0:
             raise RuntimeError("No complete entry found in %s. This can be due to badly formatted file, or "
                                "because the buffer_size (%d) is too low. Try increasing buffer_size"
                                % (cls.__name__, n))
-        entry_starts = new_lines[new_entries] + 1
-        return cls(data, int(entry_starts[-1]), new_lines[:new_entries[-1]], new_entries[:-1])
+        # cut at entry_starts[-1] = new_lines[new_entries[-1]] + 1; keep new_lines[:new_entries[-1]] (:98-101)
+        cut = int(ops.read_i64(newlines, [last])[0]) + 1
+        return cls(data, cut, newlines, last, count)
 
     def get_data(self):
         # multiline_buffer.py:46-62
         ops = get_ops()
-        size = self._size
-        line_starts = np.insert(self._new_lines + 1, 0, 0)
-        line_ends = np.append(self._new_lines, size - 1)
-        probe = HArray(host=np.ascontiguousarray(line_ends[:10]))
-        if np.any(ops.take_bytes(self._data, probe, -1).host() == ord("\r")):          # :103-106
-            cr = ops.take_bytes(self._data, HArray(host=np.ascontiguousarray(line_ends)), -1).host() == ord("\r")
-            line_ends = line_ends - cr
-        line_lens = line_ends - line_starts
-        header_lines = np.insert(self._new_entries + 1, 0, 0)
-        n_lines_per_entry = np.diff(np.append(header_lines, self._new_lines.size + 1)) - 1
-        is_header = np.zeros(line_starts.size, dtype=bool)
-        is_header[header_lines] = True
-        seq_starts, seq_lens = line_starts[~is_header], line_lens[~is_header]
-        line_offsets = np.insert(np.cumsum(n_lines_per_entry), 0, 0)
-        csum = np.insert(np.cumsum(seq_lens), 0, 0)
-        record_lens = csum[line_offsets[1:]] - csum[line_offsets[:-1]]
-        n = header_lines.size
-        headers = EncodedRaggedArray._from_parts(
-            self._data, HArray(host=line_starts[header_lines] + 1), HArray(host=line_lens[header_lines] - 1), None,
-            n, None, BaseEncoding)
+        n_nl = self._n_newlines
+        ends = ops.read_i64(self._newlines, np.arange(min(10, n_nl)))                     # ends of the first ten lines (:103-106)
+        if n_nl < 10:
+            ends = np.append(ends, self._size - 1)
+        has_cr = bool(np.any(ops.take_bytes(self._data, HArray(host=np.ascontiguousarray(ends, dtype=np.int64)), -1).host()
+                             == ord("\r")))
+        hs, hl, rec_lens, ss, sl, n_bytes = ops.multiline_table(self._data, self._size, self._newlines, n_nl,
+                                                                ord(self._new_entry_marker), has_cr)
+        n = hs.size
+        headers = EncodedRaggedArray._from_parts(self._data, hs, hl, None, n, None, BaseEncoding)
         # join the sequence lines of every record: gather the line views once on the device
-        lines = EncodedRaggedArray._from_parts(self._data, HArray(host=seq_starts), HArray(host=seq_lens), None,
-                                               seq_starts.size, int(seq_lens.sum()), BaseEncoding)
+        lines = EncodedRaggedArray._from_parts(self._data, ss, sl, None, ss.size, n_bytes, BaseEncoding)
         lines._compact()
-        sequences = EncodedRaggedArray._from_parts(lines._data, None, HArray(host=record_lens.astype(np.int64)), None,
-                                                   n, int(record_lens.sum()), BaseEncoding)
+        sequences = EncodedRaggedArray._from_parts(lines._data, None, rec_lens, None, n, n_bytes, BaseEncoding)
         return SequenceEntry(headers, sequences)
+
+    @classmethod
+    def from_data(cls, entries):
+        """the text of the entries (multiline_buffer.py:68-86): '>' name, then the sequence in lines of 80 letters"""
+        names, name_off, _ = OneLineBuffer._text_column(entries.name)
+        seq, seq_off, _ = OneLineBuffer._text_column(entries.sequence)
+        return get_ops().multiline_wrap(names, name_off, seq, seq_off, len(entries.name), cls.n_characters_per_line,
+                                        ord(cls._new_entry_marker))

@@ -143,6 +143,48 @@ class HipOps:
         self._chk(lib.bnpk_take_bytes(self.ctx, ptr(buf.dev()), ptr(positions.dev()), m, delta, ptr(out), self._s()))
         return HArray(dev=out)
 
+    def read_i64(self, arr, indices):
+        """a few elements of a device int64 array, on the host"""
+        idx = np.asarray(indices, dtype=np.int64)
+        if idx.size == 0:
+            return np.zeros(0, dtype=np.int64)
+        t = torch_mod()
+        return arr.dev()[t.from_numpy(idx).to(arr.dev().device)].cpu().numpy()
+
+    # -- A13: multi-line FASTA ------------------------------------------------------------------------
+    def multiline_cut(self, buf, newlines, marker):
+        """(index of the last newline followed by ``marker`` or -1, number of such newlines) — bnpk_multiline_cut"""
+        last, count = C.c_int64(-1), C.c_int64(0)
+        self._chk(lib.bnpk_multiline_cut(self.ctx, ptr(buf.dev()), ptr(newlines.dev()), newlines.size, marker,
+                                         C.byref(last), C.byref(count), self._s()))
+        return int(last.value), int(count.value)
+
+    def multiline_table(self, buf, size, newlines, n_newlines, marker, strip_cr):
+        """header views, record lengths and sequence-line views of a cut multi-line FASTA chunk (bnpk_multiline_table):
+        (header_starts, header_lens, record_lens, seq_line_starts, seq_line_lens) HArrays + total sequence bytes"""
+        m = n_newlines + 2
+        outs = [self._empty(m, np.int64) for _ in range(5)]
+        totals = (C.c_int64 * 3)()
+        self._chk(lib.bnpk_multiline_table(self.ctx, ptr(buf.dev()), size, ptr(newlines.dev()) if n_newlines else None,
+                                           n_newlines, marker, 1 if strip_cr else 0, *[ptr(o) for o in outs], totals,
+                                           self._s()))
+        n_rec, n_seq, n_bytes = int(totals[0]), int(totals[1]), int(totals[2])
+        hs, hl, rl, ss, sl = outs
+        return (HArray(dev=hs[:n_rec]), HArray(dev=hl[:n_rec]), HArray(dev=rl[:n_rec]), HArray(dev=ss[:n_seq]),
+                HArray(dev=sl[:n_seq]), n_bytes)
+
+    def multiline_wrap(self, names, name_offsets, seq, seq_offsets, n_records, width, marker):
+        """the text of multi-line FASTA records (bnpk_multiline_wrap): '>' name, then the sequence in lines of ``width``"""
+        out_off = self._empty(n_records + 1, np.int64)
+        total = C.c_int64(0)
+        args = (ptr(names.dev()), ptr(name_offsets.dev()), ptr(seq.dev()), ptr(seq_offsets.dev()), n_records, width, marker,
+                ptr(out_off))
+        self._chk(lib.bnpk_multiline_wrap(self.ctx, *args, None, 0, C.byref(total), self._s()))
+        out = self._empty(int(total.value), np.uint8)
+        if total.value:
+            self._chk(lib.bnpk_multiline_wrap(self.ctx, *args, ptr(out), out.numel(), C.byref(total), self._s()))
+        return HArray(dev=out)
+
     # -- ragged offsets ------------------------------------------------------------------------------
     def row_offsets(self, lens, window=1):
         """(offsets[n+1], total) of rows trimmed by window-1 (RaggedShape; kmers.py:100)"""

@@ -202,6 +202,32 @@ int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_of
 int bnpk_col_sums_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t total,
                      int64_t n_cols, int64_t* d_sums, int64_t* d_counts, void* stream);
 
+/* ---- A13: multi-line FASTA (bionumpy/io/multiline_buffer.py:33-106) ---------------------------------------------
+ * bnpk_multiline_cut: `new_entries = np.flatnonzero(chunk[new_lines + 1] == ">")` reduced to what from_raw_buffer
+ * (multiline_buffer.py:89-101) needs of it: the index (into d_newlines) of the LAST newline that is followed by the
+ * marker (-1 if none: "No complete entry found") and how many there are.  d_newlines: the ordered positions of the
+ * newlines of chunk[:-1] (bnpk_byte_positions).
+ * bnpk_multiline_table: get_data (multiline_buffer.py:46-62) for the cut chunk d_buf[0, size) and its n_newlines
+ * newlines: line i is [newline[i-1] + 1, newline[i]) (the last line ends at size - 1), minus a trailing '\r' if
+ * strip_cr (_modify_ends_for_carriage_returns :103-106, the caller probes the first ten lines); a line is a header if
+ * it is line 0 or starts with the marker.  Record r: header text d_header_starts/lens[r] (without the marker), its
+ * sequence = the concatenation of its sequence lines, d_record_lens[r] bytes; the sequence lines of all records in
+ * order: d_seq_line_starts/lens.  All five outputs sized n_newlines + 2; h_totals3 = {records, sequence lines,
+ * sequence bytes}. */
+int bnpk_multiline_cut(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines, int64_t n_newlines, uint8_t marker,
+                       int64_t* h_last_entry_newline, int64_t* h_n_entry_newlines, void* stream);
+int bnpk_multiline_table(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t size, const int64_t* d_newlines, int64_t n_newlines,
+                         uint8_t marker, int strip_cr, int64_t* d_header_starts, int64_t* d_header_lens,
+                         int64_t* d_record_lens, int64_t* d_seq_line_starts, int64_t* d_seq_line_lens, int64_t* h_totals3,
+                         void* stream);
+/* MultiLineFastaBuffer.from_data (multiline_buffer.py:68-86): record r = marker, its name, '\n', then its sequence
+ * (ASCII, rows of d_seq at d_seq_offsets) in lines of `width` letters (n_characters_per_line = 80), every line ended
+ * by '\n'.  d_out_offsets (n_records + 1) receives the byte offset of every record; *h_total the size of the text.
+ * Call with d_out == NULL to get the sizes, then with a buffer of *h_total bytes. */
+int bnpk_multiline_wrap(bnpk_ctx* ctx, const uint8_t* d_names, const int64_t* d_name_offsets, const uint8_t* d_seq,
+                        const int64_t* d_seq_offsets, int64_t n_records, int width, uint8_t marker, int64_t* d_out_offsets,
+                        uint8_t* d_out, int64_t out_capacity, int64_t* h_total, void* stream);
+
 /* ---- join_fields: the text of records from their fields ----------------------------
  * replaces OneLineBuffer.join_fields / from_data (bionumpy/io/one_line_buffer.py:99-134, io/fastq_buffer.py:46-61):
  * entry r is its n_lines <= 4 lines; line i = prefix[i] (0 or 1) bytes `header`, row r of field i

@@ -28,7 +28,7 @@ Every function cites the reference file:line it follows.
 from .ragged import row_starts, row_reduce, col_sums
 from .text import (FormatException, IncompleteEntryException, EncodingError,
                    scan_one_line_buffer, FASTQ, TWO_LINE_FASTA,
-                   scan_multiline_fasta, ChunkReader, open_text, join_fields)
+                   scan_multiline_fasta, multiline_from_data, ChunkReader, open_text, join_fields)
 from .encode import (dna_lut, gather_rows, encode_dna, decode_dna,
                      quality_scores)
 from .kmers import (pack_2bit, sliding_window_2bit, kmer_hashes_flat,

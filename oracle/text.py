@@ -14,6 +14,8 @@ from collections import namedtuple
 
 import numpy as np
 
+from .ragged import flat_indices
+
 NEWLINE = 10
 CR = 13
 
@@ -162,6 +164,37 @@ def scan_multiline_fasta(chunk, marker=ord(">")):
                            (line_lens[header_lines] - 1).astype(np.int64),
                            seq_line_starts.astype(np.int64), seq_line_lens.astype(np.int64),
                            seq_lens.astype(np.int64))
+
+
+def multiline_from_data(names, name_lens, seq_ascii, seq_lens, width=80, marker=ord(">")):
+    """MultiLineFastaBuffer.from_data (io/multiline_buffer.py:68-86): the text of the records — '>' name newline, then the
+    sequence in lines of n_characters_per_line = 80 letters.  (Records with an empty sequence, which the reference's index
+    arithmetic does not handle, are written as their header line only.)"""
+    names = np.asarray(names, dtype=np.uint8)
+    seq_ascii = np.asarray(seq_ascii, dtype=np.uint8)
+    name_lens = np.asarray(name_lens, dtype=np.int64)
+    seq_lens = np.asarray(seq_lens, dtype=np.int64)
+    n_lines = (seq_lens - 1) // width + 1                                     # :71
+    last_length = (seq_lens - 1) % width + 1                                  # :72
+    line_lengths = np.full(int(np.sum(n_lines)) + n_lines.size, width + 1, dtype=np.int64)   # :73
+    entry_starts = np.insert(np.cumsum(n_lines + 1), 0, 0)                    # :74
+    nonempty = seq_lens > 0
+    line_lengths[entry_starts[1:][nonempty] - 1] = last_length[nonempty] + 1  # :76
+    line_lengths[entry_starts[:-1]] = name_lens + 2                           # :75
+    out = np.zeros(int(line_lengths.sum()), dtype=np.uint8)
+    line_off = np.insert(np.cumsum(line_lengths), 0, 0)
+    out[line_off[1:] - 1] = NEWLINE                                           # :85
+    head = line_off[entry_starts[:-1]]
+    out[head] = marker                                                        # :80
+    name_off = np.insert(np.cumsum(name_lens), 0, 0)
+    for r in range(name_lens.size):                                           # :79
+        out[head[r] + 1: head[r] + 1 + name_lens[r]] = names[name_off[r]:name_off[r + 1]]
+    is_seq_line = np.ones(line_lengths.size, dtype=bool)
+    is_seq_line[entry_starts[:-1]] = False                                    # :81
+    idx = np.flatnonzero(is_seq_line)
+    dst = flat_indices(line_off[idx], line_lengths[idx] - 1)                  # :84
+    out[dst] = seq_ascii[:dst.size]
+    return out
 
 
 class ChunkReader:

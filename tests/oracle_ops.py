@@ -132,6 +132,35 @@ class OracleOps:
     def take_bytes(self, buf, positions, delta):
         return _h(buf.host()[positions.host() + delta])
 
+    def read_i64(self, arr, indices):
+        return arr.host()[np.asarray(indices, dtype=np.int64)]
+
+    # -- multi-line FASTA ----------------------------------------------------------------------------
+    def multiline_cut(self, buf, newlines, marker):
+        hits = np.flatnonzero(buf.host()[newlines.host() + 1] == marker)
+        return (int(hits[-1]) if hits.size else -1), int(hits.size)
+
+    def multiline_table(self, buf, size, newlines, n_newlines, marker, strip_cr):
+        data = buf.host()[:size]
+        nl = newlines.host()[:n_newlines]
+        line_starts = np.concatenate(([0], nl + 1))
+        line_ends = np.concatenate((nl, [size - 1]))
+        if strip_cr:
+            line_ends = line_ends - (data[line_ends - 1] == 13)
+        is_header = data[line_starts] == marker
+        is_header[0] = True
+        line_lens = line_ends - line_starts
+        rec_of_line = np.cumsum(is_header) - 1
+        seq = ~is_header
+        rec_lens = np.bincount(rec_of_line[seq], weights=line_lens[seq], minlength=int(is_header.sum())).astype(np.int64)
+        return (_h(line_starts[is_header] + 1), _h(line_lens[is_header] - 1), _h(rec_lens), _h(line_starts[seq]),
+                _h(line_lens[seq]), int(line_lens[seq].sum()))
+
+    def multiline_wrap(self, names, name_offsets, seq, seq_offsets, n_records, width, marker):
+        no, so = name_offsets.host(), seq_offsets.host()
+        return _h(oracle.multiline_from_data(names.host()[:int(no[-1])], np.diff(no), seq.host()[:int(so[-1])],
+                                             np.diff(so), width, marker))
+
     # -- offsets -----------------------------------------------------------------------------------
     def row_offsets(self, lens, window=1):
         l = lens.host().astype(np.int64)

@@ -275,6 +275,37 @@ def test_multiline_fasta(bnp, tmp_path):
     assert kmers.lengths.tolist() == [8, 11]
 
 
+def test_multiline_fasta_writer_and_tables(bnp, tmp_path, golden_dir):
+    # multiline_buffer.py:46-62 (get_data) and :68-86 (from_data: lines of 80 letters)
+    rng = np.random.default_rng(3)
+    names = ["chrI", "x", "a_rather_long_header with spaces", "last"]
+    lens = [1, 80, 81, 333]
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in lens]
+    entries = bnp.SequenceEntry(bnp.as_encoded_array(names), bnp.as_encoded_array(seqs, bnp.DNAEncoding))
+    text = bnp.MultiLineFastaBuffer.from_data(entries).host().tobytes().decode("ascii")
+    expect = "".join(">%s\n%s" % (n, "".join(s[i:i + 80] + "\n" for i in range(0, len(s), 80))) for n, s in zip(names, seqs))
+    assert text == expect
+    flat_names = np.frombuffer("".join(names).encode(), dtype=np.uint8)
+    flat_seqs = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    assert text.encode() == oracle.multiline_from_data(flat_names, [len(n) for n in names], flat_seqs, lens).tobytes()
+    # written through bnp.open(.., "w") and read back (with CRLF line ends too)
+    p = tmp_path / "out.fa"
+    with bnp.open(str(p), "w") as f:
+        f.write(entries)
+    assert p.read_text() == expect
+    back = bnp.open(str(p)).read()
+    assert back.name.tolist() == names and back.sequence.tolist() == seqs
+    crlf = tmp_path / "crlf.fa"
+    crlf.write_bytes(expect.replace("\n", "\r\n").encode())
+    back = bnp.open(str(crlf)).read()
+    assert back.name.tolist() == names and back.sequence.tolist() == seqs
+    # the reference's fixture file and the oracle's tables
+    raw, res = oracle.open_text(os.path.join(golden_dir, "multi_line.fa")).read()
+    data = bnp.open(os.path.join(golden_dir, "multi_line.fa")).read()
+    assert [len(s) for s in data.sequence.tolist()] == res.seq_lens.tolist()
+    assert "".join(data.sequence.tolist()).encode() == oracle.gather_rows(raw, res.line_starts, res.line_lens).tobytes()
+
+
 def test_carriage_returns(bnp):
     # tests/test_io.py:233-249
     data = _reader(bnp, FASTQ_TEXT.replace("\n", "\r\n"), bnp.FastQBuffer).read()

@@ -61,6 +61,32 @@ def _oracle_fasta(path):
     return codes, res.seq_lens
 
 
+def test_saccer3_decoded_on_the_device_equals_the_oracle(ops, tmp_path):
+    """A13 at the size of config 5: the device line tables (bnpk_multiline_cut / _table) of the 12 Mbase genome against
+    oracle.scan_multiline_fasta, in one piece and in 1 MB chunks, and the writer's round trip"""
+    import bionumpy_amd as bnp
+    path = os.path.join(GOLD, "sacCer3.fa.gz")
+    raw, res = oracle.open_text(path).read()
+    seq = oracle.gather_rows(raw, res.line_starts, res.line_lens)
+    names = oracle.gather_rows(raw, res.header_starts, res.header_lens)
+    whole = bnp.open(path).read()
+    assert np.array_equal(whole.sequence.lengths, res.seq_lens) and np.array_equal(whole.name.lengths, res.header_lens)
+    assert np.array_equal(np.asarray(whole.sequence.ravel()), seq) and np.array_equal(np.asarray(whole.name.ravel()), names)
+    n, got = 0, []
+    for chunk in bnp.open(path).read_chunks(min_chunk_size=1_000_000):
+        n += len(chunk)
+        got.append(np.asarray(chunk.sequence.ravel()))
+    assert n == 17 and np.array_equal(np.concatenate(got), seq)
+    out = tmp_path / "again.fa"
+    with bnp.open(str(out), "w") as f:
+        f.write(whole)
+    assert np.array_equal(np.fromfile(str(out), dtype=np.uint8),
+                          oracle.multiline_from_data(names, res.header_lens, seq, res.seq_lens))
+    again = bnp.open(str(out)).read()
+    assert again.name.tolist() == whole.name.tolist()
+    assert np.array_equal(np.asarray(again.sequence.ravel()), seq)
+
+
 def test_config5_saccer3_index_and_lookup(ops):
     import bionumpy_amd as bnp
     k = 31
