@@ -20,6 +20,11 @@ class IncompleteEntryException(Exception):
     pass
 
 
+class NoCompleteEntry(RuntimeError, IncompleteEntryException):
+    """MultiLineFastaBuffer.from_raw_buffer found no complete entry (a RuntimeError in the reference,
+    multiline_buffer.py:95-96); the reader reads on when it sees it"""
+
+
 class EncodingError(Exception):
     def __init__(self, message, offset=0):
         super().__init__(message)

@@ -17,7 +17,7 @@ import numpy as np
 from ..datatypes import SequenceEntry, SequenceEntryWithQuality
 from ..device import HArray
 from ..encoded_array import EncodedArray, EncodedRaggedArray, BaseEncoding, QualityEncoding, as_encoded_array
-from ..exceptions import FormatException, IncompleteEntryException  # noqa: F401
+from ..exceptions import FormatException, IncompleteEntryException, NoCompleteEntry  # noqa: F401
 from ..ops import get_ops
 
 NEWLINE = 10
@@ -32,8 +32,8 @@ def _chunk_to_harray(chunk):
     chunk = np.asarray(chunk, dtype=np.uint8)
     ops = get_ops()
     if not getattr(ops, "host_only", False):
-        from .pinned import pool
-        owner = pool().owner_of(chunk)
+        from .pinned import owner_of
+        owner = owner_of(chunk)
         if owner is not None:                        # page-locked staging buffer -> hipMemcpyAsync into HBM
             return ops.upload_pinned(chunk, owner)
     return HArray(host=chunk)
@@ -279,9 +279,9 @@ class MultiLineFastaBuffer(FileBuffer):
         newlines, _ = ops.newline_positions(data, n - 1, 1)          # chunk[:-1] == "\n"            (:93)
         last, count = ops.multiline_cut(data, newlines, marker)      # chunk[new_lines + 1] == ">"    (:94)
         if count == 0:
-            raise RuntimeError("No complete entry found in %s. This can be due to badly formatted file, or "
-                               "because the buffer_size (%d) is too low. Try increasing buffer_size"
-                               % (cls.__name__, n))
+            raise NoCompleteEntry("No complete entry found in %s. This can be due to badly formatted file, or "
+                                  "because the buffer_size (%d) is too low. Try increasing buffer_size"
+                                  % (cls.__name__, n))
         # cut at entry_starts[-1] = new_lines[new_entries[-1]] + 1; keep new_lines[:new_entries[-1]] (:98-101)
         cut = int(ops.read_i64(newlines, [last])[0]) + 1
         return cls(data, cut, newlines, last, count)

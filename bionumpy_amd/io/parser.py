@@ -1,97 +1,96 @@
-"""NumpyFileReader: the chunk loop between a file object and the device buffers
-(bionumpy/io/parser.py:36-206), statement by statement.
+"""NumpyFileReader: from a file object to device buffers of complete entries.
 
-Host side: ``file.read(min_chunk_size)`` into a uint8 array, append '\\n' at EOF, carry the
-unconsumed tail (``seek`` back on plain files, ``_prepend`` on gzip streams).  Device side: the
-buffer class's ``from_raw_buffer`` uploads the chunk and runs the newline scan / validation kernels,
-and reports how many bytes the complete entries cover (``buff.size``).
+What a caller of the reference's reader (bionumpy/io/parser.py:36-206) can observe is kept — ``read`` / ``read_chunk``
+/ ``read_chunks`` / iteration, which entries a chunk of ``min_chunk_size`` bytes holds (a plain file is read in
+windows of ``min_chunk_size`` bytes that start at the first unconsumed byte, a gzip stream gets ``min_chunk_size``
+new bytes on top of what was left over), the newline (and '>' for multi-line FASTA) appended at the end of the file,
+``Exception("No complete entry found")`` beyond ``max_chunk_size``, ``n_bytes_read`` / ``n_lines_read`` and the
+``FormatException.line_number`` that counts from the start of the file — but the mechanism is built for batches of
+gigabytes going to a device, not for 5 MB numpy chunks:
+
+* the bytes are read (``readinto``) straight into page-locked staging buffers, two of them, so that the file read
+  of the next batch overlaps the ``hipMemcpyAsync`` of the current one; the end-of-file newline / marker is written
+  in place behind the data;
+* nothing is ever seeked back or re-read, for plain files and gzip streams alike: the bytes behind the last complete
+  entry (less than one entry) are carried over, by offset, to the front of the other staging buffer;
+* whether a batch holds a complete entry, and where its last one ends, is decided by the device scan of the buffer
+  class (``from_raw_buffer``) on the uploaded bytes — the host never looks at them (the reference counts the
+  newlines of every chunk with numpy before it parses it).
 """
 import numpy as np
 
-from ..exceptions import FormatException
+from ..exceptions import FormatException, IncompleteEntryException
 from ..ops import get_ops
+
+NEWLINE = 10
+
+
+class _Staging:
+    """where the bytes of a batch are gathered: page-locked buffers on the GPU path (io/pinned.py), plain numpy arrays
+    under the host-only test backend.  ``room(n)`` returns a writable uint8 array of at least n bytes that does not
+    alias the array returned by the previous call."""
+
+    def __init__(self):
+        self._pool = None
+        if not getattr(get_ops(), "host_only", False):
+            from .pinned import PinnedPool
+            self._pool = PinnedPool(2)
+
+    def room(self, n):
+        if self._pool is not None:
+            return self._pool.acquire(n).array
+        return np.empty(n, dtype=np.uint8)
+
+    def release(self):
+        if self._pool is not None:
+            self._pool.release()
 
 
 class NumpyFileReader:
     def __init__(self, file_obj, buffer_type, has_header=False):
         self._file_obj = file_obj
-        self._is_finished = False
         self._buffer_type = buffer_type
         self._has_header = has_header
         self._f_name = self._file_obj.name if hasattr(self._file_obj, "name") else str(self._file_obj)
         self._header_data = self._buffer_type.read_header(self._file_obj)
         self._buffer_type = self._buffer_type.modify_class_with_header_data(self._header_data)
-        self._do_prepend = False
-        self._prepend = []
+        self._marker = getattr(self._buffer_type, "_new_entry_marker", None)
+        self._is_finished = False
+        self._stream_mode = False          # gzip: every batch takes min_chunk_size NEW bytes (parser.py:164-165)
+        self._left_over = None             # bytes behind the last complete entry of the previous batch (a staging view)
+        self._staging = None
         self.n_bytes_read = 0
         self.n_lines_read = 0
 
+    # -- the reference's surface ---------------------------------------------------------------------------------
     def __enter__(self):
         return self
 
     def __exit__(self, *args):
-        self._file_obj.close()
+        self.close()
 
     def __iter__(self):
         return self.read_chunks()
 
     def set_prepend_mode(self):
-        self._do_prepend = True
+        self._stream_mode = True
 
     def close(self):
         self._file_obj.close()
+        if self._staging is not None:
+            self._staging.release()
+            self._staging = None
+        self._left_over = None
 
     def read(self):
-        # parser.py:89-94
-        chunk = np.frombuffer(self._file_obj.read(), dtype=np.uint8)
-        if chunk.size == 0:
+        """the whole file as one buffer (parser.py:89-94)"""
+        raw = self._file_obj.read()
+        if len(raw) == 0:
             return None
-        chunk, _ = self.__add_newline_to_end(chunk, chunk.size)
-        return self._buffer_type.from_raw_buffer(chunk, header_data=self._header_data)
-
-    def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
-        # parser.py:96-171
-        complete_entry_found = False
-        temp_chunks = []
-        if len(self._prepend):
-            temp_chunks.append(self._prepend)
-        made_buffer = None
-        chunk = None
-        while not complete_entry_found:
-            # chunks that must outlive the next read cannot stay views of a (recycled) pinned staging buffer
-            temp_chunks = [self._detach(c) for c in temp_chunks]
-            chunk = self._get_buffer(min_chunk_size, max_chunk_size)
-            if chunk is None:
-                return None
-            temp_chunks.append(chunk)
-            if max_chunk_size is not None and sum(c.size for c in temp_chunks) > max_chunk_size:
-                raise Exception("No complete entry found")
-            try:
-                complete_entry_found = self._buffer_type.contains_complete_entry(temp_chunks)
-            except FormatException as e:
-                e.line_number += self.n_lines_read
-                raise e
-            if isinstance(complete_entry_found, tuple):
-                complete_entry_found, made_buffer = complete_entry_found
-        if made_buffer is not None:
-            buff = made_buffer
-        else:
-            chunk = temp_chunks[0] if len(temp_chunks) == 1 else np.concatenate(temp_chunks)
-            try:
-                buff = self._buffer_type.from_raw_buffer(chunk, header_data=self._header_data)
-            except FormatException as e:
-                e.line_number += self.n_lines_read
-                raise e
-        self._prepend = []
-        if not self._is_finished:
-            if not self._do_prepend:
-                self._file_obj.seek(buff.size - chunk.size, 1)
-            else:
-                self._prepend = self._detach(chunk[buff.size:])
-        if chunk is not None and chunk.size:
-            self.n_bytes_read += buff.size
-            self.n_lines_read += buff.n_lines
-            return buff
+        batch = np.empty(len(raw) + 2, dtype=np.uint8)
+        batch[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+        n = self._terminate(batch, len(raw))
+        return self._buffer_type.from_raw_buffer(batch[:n], header_data=self._header_data)
 
     def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
         while not self._is_finished:
@@ -100,49 +99,74 @@ class NumpyFileReader:
                 break
             yield chunk
 
-    def __add_newline_to_end(self, chunk, bytes_read):
-        # parser.py:183-190
-        if chunk[bytes_read - 1] != ord("\n"):
-            chunk = np.append(chunk, np.uint8(ord("\n")))
-            bytes_read += 1
-        if hasattr(self._buffer_type, "_new_entry_marker"):
-            chunk = np.append(chunk, np.uint8(ord(self._buffer_type._new_entry_marker)))
-            bytes_read += 1
-        return chunk, bytes_read
+    def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
+        """the next buffer of complete entries, or None at the end of the file (parser.py:96-171)"""
+        if self._staging is None:
+            self._staging = _Staging()
+        held = self._left_over if self._left_over is not None else np.zeros(0, dtype=np.uint8)
+        self._left_over = None
+        # a plain file is read in windows of min_chunk_size bytes from the first unconsumed byte (what the reference's
+        # seek-back amounts to); a stream, or a window without a complete entry, takes min_chunk_size more
+        want = min_chunk_size if (self._stream_mode or held.size >= min_chunk_size) else min_chunk_size - held.size
+        while True:
+            batch, n_new = self._extend(held, want)
+            if n_new == 0:
+                return None                                  # (as in the reference, an incomplete tail is dropped)
+            if max_chunk_size is not None and batch.size > max_chunk_size:
+                raise Exception("No complete entry found")
+            buff = self._parse(batch)
+            if buff is not None:
+                break
+            held, want = batch, min_chunk_size
+        if not self._is_finished:
+            self._left_over = batch[buff.size:]
+        self.n_bytes_read += buff.size
+        self.n_lines_read += buff.n_lines
+        return buff
 
-    def _get_buffer(self, min_chunk_size=5000000, max_chunk_size=None):
-        # parser.py:192-206; on the GPU the bytes land in a pinned staging buffer (io/pinned.py) so that the
-        # upload in from_raw_buffer is one hipMemcpyAsync out of page-locked memory
-        if hasattr(self._file_obj, "readinto") and not getattr(get_ops(), "host_only", False):
-            return self._get_pinned_buffer(min_chunk_size)
-        a = np.frombuffer(self._file_obj.read(min_chunk_size), dtype="uint8")
-        bytes_read = a.size
-        self._is_finished = bytes_read < min_chunk_size
-        if bytes_read == 0:
+    # -- mechanism ---------------------------------------------------------------------------------------------------
+    def _terminate(self, array, n):
+        """end of file: a final newline if the file lacks one, and the entry marker for multi-line FASTA (parser.py:183-190),
+        written in place behind the n bytes of data; returns the new length"""
+        if array[n - 1] != NEWLINE:
+            array[n] = NEWLINE
+            n += 1
+        if self._marker is not None:
+            array[n] = ord(self._marker)
+            n += 1
+        return n
+
+    def _extend(self, held, want):
+        """held bytes + up to ``want`` new bytes of the file, contiguous in a fresh staging buffer"""
+        room = self._staging.room(held.size + want + 2)
+        room[:held.size] = held
+        got = self._fill(room[held.size:held.size + want])
+        self._is_finished = got < want
+        n = held.size + got
+        if got and self._is_finished:
+            n = self._terminate(room, n)
+        return room[:n], got
+
+    def _fill(self, target):
+        """file.readinto(target) until it is full or the file ends (buffered / gzip readers return short reads)"""
+        if not hasattr(self._file_obj, "readinto"):
+            raw = self._file_obj.read(target.size)
+            target[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
+            return len(raw)
+        view, got = memoryview(target), 0
+        while got < target.size:
+            n = self._file_obj.readinto(view[got:])
+            if not n:
+                break
+            got += n
+        return got
+
+    def _parse(self, batch):
+        """the buffer over the complete entries of the batch, or None if it does not hold one yet"""
+        try:
+            return self._buffer_type.from_raw_buffer(batch, header_data=self._header_data)
+        except IncompleteEntryException:
             return None
-        if self._is_finished:
-            a, bytes_read = self.__add_newline_to_end(a, bytes_read)
-        return a[:bytes_read]
-
-    @staticmethod
-    def _detach(chunk):
-        from .pinned import pool
-        if isinstance(chunk, np.ndarray) and pool().owner_of(chunk) is not None:
-            return chunk.copy()
-        return chunk
-
-    def _get_pinned_buffer(self, min_chunk_size):
-        from .pinned import read_into_pinned
-        a, buf = read_into_pinned(self._file_obj, min_chunk_size, headroom=2)
-        bytes_read = a.size
-        self._is_finished = bytes_read < min_chunk_size
-        if bytes_read == 0:
-            return None
-        if self._is_finished:                       # same rule as __add_newline_to_end, written in place
-            if buf.array[bytes_read - 1] != ord("\n"):
-                buf.array[bytes_read] = ord("\n")
-                bytes_read += 1
-            if hasattr(self._buffer_type, "_new_entry_marker"):
-                buf.array[bytes_read] = ord(self._buffer_type._new_entry_marker)
-                bytes_read += 1
-        return buf.array[:bytes_read]
+        except FormatException as e:
+            e.line_number += self.n_lines_read
+            raise

@@ -1,16 +1,19 @@
 """Pinned host staging for the chunk reader: file bytes are read straight into page-locked buffers
 (``bnpk_host_alloc`` = hipHostMalloc) and streamed to HBM with ``hipMemcpyAsync`` (``bnpk_copy_h2d_async``).
 
-Two buffers alternate so that the next ``file.readinto`` can fill one buffer while the DMA out of the
-other is still in flight; a buffer is only reused after its copy has completed (stream sync).
+Every reader owns two buffers that alternate, so that the next ``file.readinto`` fills one buffer while the DMA out of
+the other is still in flight; a buffer is only reused after its copy has completed (stream sync).
 This replaces ``np.frombuffer(file.read(n))`` + ``cp.asanyarray(chunk)`` of the reference
 (bionumpy/io/parser.py:203-206, bionumpy/cupy_compatible/parser.py:11-17).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from .._native import lib, check
+
+_live = weakref.WeakSet()          # every pinned buffer that exists: lets an upload recognise page-locked memory
 
 
 class PinnedBuffer:
@@ -21,9 +24,17 @@ class PinnedBuffer:
         self.nbytes = nbytes
         self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr.value))
         self.in_flight = False
+        _live.add(self)
+
+    def wait(self):
+        """until the H2D copy out of this buffer (if any) has landed"""
+        if self.in_flight:
+            check(lib.bnpk_stream_sync(getattr(self, "stream", None)))
+            self.in_flight = False
 
     def free(self):
         if self.ptr:
+            self.wait()
             lib.bnpk_host_free(self.ptr)
             self.ptr = None
 
@@ -35,56 +46,39 @@ class PinnedBuffer:
 
 
 class PinnedPool:
-    """two page-locked staging buffers, grown on demand"""
+    """page-locked staging buffers that take turns, grown on demand"""
 
     def __init__(self, n_buffers=2):
         self._buffers = [None] * n_buffers
         self._next = 0
 
     def acquire(self, nbytes):
+        """the next buffer in turn, at least nbytes large, with no copy out of it in flight"""
         i = self._next
         self._next = (self._next + 1) % len(self._buffers)
         buf = self._buffers[i]
-        if buf is not None and buf.in_flight:
-            check(lib.bnpk_stream_sync(getattr(buf, "stream", None)))   # its H2D copy must have landed first
-            buf.in_flight = False
+        if buf is not None:
+            buf.wait()
         if buf is None or buf.nbytes < nbytes:
             if buf is not None:
                 buf.free()
-            buf = PinnedBuffer(max(nbytes, 1 << 20))
+            buf = PinnedBuffer(max(nbytes + (nbytes >> 3), 1 << 20))
             self._buffers[i] = buf
         return buf
 
-    def owner_of(self, array):
-        """the pinned buffer a numpy view lives in (None for ordinary pageable arrays)"""
-        if not isinstance(array, np.ndarray) or array.size == 0:
-            return None
-        addr = array.__array_interface__["data"][0]
-        for buf in self._buffers:
-            if buf is not None and buf.ptr and buf.ptr.value <= addr and addr + array.nbytes <= buf.ptr.value + buf.nbytes:
-                return buf
+    def release(self):
+        for i, buf in enumerate(self._buffers):
+            if buf is not None:
+                buf.free()
+                self._buffers[i] = None
+
+
+def owner_of(array):
+    """the pinned buffer a numpy view lives in (None for ordinary pageable arrays)"""
+    if not isinstance(array, np.ndarray) or array.size == 0:
         return None
-
-
-_pool = None
-
-
-def pool():
-    global _pool
-    if _pool is None:
-        _pool = PinnedPool()
-    return _pool
-
-
-def read_into_pinned(file_obj, nbytes, headroom=2):
-    """``file.read(nbytes)`` into a pinned buffer; returns a uint8 numpy view of the bytes read.
-    ``headroom`` spare bytes after the data let the reader append the EOF newline / marker in place."""
-    buf = pool().acquire(nbytes + headroom)
-    view = memoryview(buf.array)[:nbytes]
-    got = 0
-    while got < nbytes:                                 # gzip/BufferedReader may return short reads
-        n = file_obj.readinto(view[got:])
-        if not n:
-            break
-        got += n
-    return buf.array[:got], buf
+    addr = array.__array_interface__["data"][0]
+    for buf in list(_live):
+        if buf.ptr and buf.ptr.value <= addr and addr + array.nbytes <= buf.ptr.value + buf.nbytes:
+            return buf
+    return None
