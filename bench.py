@@ -80,6 +80,44 @@ def cpu_baseline(host_text, k, budget_s=20.0):
                       % (res.n_records, int(lens[0]) if len(lens) else 0, dt)}
 
 
+def host_fed_leg(args, text, expected_sums):
+    """the batch copied once into page-locked host memory, then streamed back --host-fed-batches times through
+    bionumpy_amd.hostfed.HostFedCounter (1 GiB chunks, copy stream + compute stream); every histogram is checked
+    against the checksums of the k-mers in read order"""
+    import ctypes as C
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize
+    from bionumpy_amd._native import lib, check
+    from bionumpy_amd.hostfed import HostFedCounter
+    from bionumpy_amd.io.pinned import PinnedBuffer
+    n = text.size
+    t0 = time.perf_counter()
+    pinned = PinnedBuffer(n + 64)
+    t_alloc = time.perf_counter() - t0
+    check(lib.bnpk_copy_d2h_async(pinned.ptr, C.c_void_p(text.dev().data_ptr()), n, None))
+    torch.cuda.synchronize()
+    host_text = pinned.array[:n]
+    counter = HostFedCounter(args.k, chunk_bytes=1 << 30, ring=6, canonical=args.canonical)
+    for (keys, counts), st in counter.run([host_text]):      # warm-up batch (allocator, first touch of the ring)
+        del keys, counts
+    n_bases, ok = 0, True
+    for (keys, counts), st in counter.run([host_text] * args.host_fed_batches):
+        n_bases += st.n_bases
+        ok = ok and fullsize.histogram_sums(keys, counts) == expected_sums
+        del keys, counts
+    tm = counter.timing
+    assert ok, "host-fed histogram differs from the device-resident one"
+    del counter
+    pinned.free()
+    return {"gbases_per_s": round(n_bases / tm.seconds / 1e9, 3), "h2d_gb_per_s": round(tm.h2d_gb_per_s, 2),
+            "overlap_frac": round(tm.overlap_frac, 3), "source": "pinned RAM", "batches": args.host_fed_batches,
+            "bytes": tm.bytes, "seconds": round(tm.seconds, 4), "h2d_busy_s": round(tm.h2d_seconds, 4),
+            "compute_host_s": round(tm.compute_seconds, 4), "chunks": tm.chunks, "chunk_bytes": 1 << 30,
+            "pinned_alloc_s": round(t_alloc, 3), "parity": "checksums of every batch == k-mers in read order",
+            "link_bound_gbases_per_s": round(tm.h2d_gb_per_s / (n / n_bases * args.host_fed_batches), 2) if n_bases else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +131,8 @@ def main():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned RAM -> HBM) measurement")
+    ap.add_argument("--host-fed-batches", type=int, default=2)
     ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
     ap.add_argument("--canonical", action="store_true",
                     help="count strand-independent k-mers min(h, rc(h)) (extension; not the headline workload)")
@@ -250,6 +290,15 @@ def main():
         "parity_fullsize": bool(parity and parity["ok"]),
         "parity": parity,
     }
+    # ---- the same workload fed from page-locked host memory (never `value`): H2D on its own stream, overlapped ----------
+    out["host_fed"] = None
+    if world == 1 and not args.no_host_fed and args.k > 13 and isinstance(hist, tuple):
+        hist = keys = counts = None                          # (the resident result: 96 GB that the next batches need)
+        torch.cuda.empty_cache()
+        try:
+            out["host_fed"] = host_fed_leg(args, text, rs)
+        except Exception as e:                               # (e.g. the box cannot page-lock 16 GB)
+            out["host_fed"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and not args.no_cpu_baseline:
         m = min(args.reads, args.cpu_sample_reads)
         sample = text.dev()[:m * (2 * args.read_len + 16)].cpu().numpy()

@@ -112,6 +112,26 @@ class HipOps:
                                 "offset %d" % int(e[2]), int(e[2]))
         return HArray(dev=packed), HArray(dev=ends), n_lines // lines_per_entry, n_bases
 
+    def fastq_encode_into(self, text_t, n, lines_per_entry, seq_line, header, check_plus, packed_t, ends_t, base_offset):
+        """fused decode of one chunk (torch uint8 tensor, n bytes of whole records) into the flat 2-bit stream /
+        read-end mask of a batch at ``base_offset`` (a multiple of 64).  Returns (records, bases, error cell): the cell
+        {bad header entry, bad '+' entry, bad base offset} is left on the device for the caller to look at later —
+        nothing here waits for the encoder."""
+        assert base_offset % 64 == 0
+        table = self._empty(lib.bnpk_fastq_table_words(n), np.int64)
+        totals = (C.c_int64 * 4)()
+        self._chk(lib.bnpk_fastq_census(self.ctx, ptr(text_t), n, lines_per_entry, seq_line, ptr(table), totals, self._s()))
+        n_newlines, n_lines, n_bases = int(totals[0]), int(totals[1]), int(totals[2])
+        if n_lines != n_newlines or n_lines % lines_per_entry:
+            raise FormatException("a chunk of the host-fed path must hold whole records", line_number=0)
+        assert base_offset + n_bases + 128 <= packed_t.numel() * 32, "batch buffer too small"
+        err = self._empty(3, np.int64)
+        packed = packed_t[base_offset // 32:]
+        ends = ends_t[base_offset // 64:]
+        self._chk(lib.bnpk_fastq_encode(self.ctx, ptr(text_t), n, lines_per_entry, seq_line, header, 1 if check_plus else 0,
+                                        ptr(table), n_lines, n_bases, ptr(packed), ptr(ends), ptr(err), self._s()))
+        return n_lines // lines_per_entry, n_bases, err
+
     def kmer_starts_from_ends(self, row_ends, n_bases, k):
         """(k-mer start mask, number of k-mers) from the read-end mask"""
         mask = self._empty(n_bases // 64 + 2, np.int64)

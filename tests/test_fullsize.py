@@ -15,6 +15,7 @@ import pytest
 
 import oracle
 import fullsize
+from bionumpy_amd.device import HArray
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -59,6 +60,61 @@ def _oracle_fasta(path):
     raw, res = oracle.open_text(path).read()
     codes = oracle.encode_dna(oracle.gather_rows(raw, res.line_starts, res.line_lens))
     return codes, res.seq_lens
+
+
+def _pinned_copy(array):
+    from bionumpy_amd.io.pinned import PinnedBuffer
+    buf = PinnedBuffer(array.size + 64)
+    buf.array[:array.size] = array
+    return buf, buf.array[:array.size]
+
+
+def test_host_fed_pipeline_equals_the_oracle_and_the_resident_path(ops):
+    """text in page-locked host memory, streamed in chunks on the copy stream (bionumpy_amd/hostfed.py): ragged reads
+    (chunk cuts at arbitrary record boundaries, padding between the chunks' 2-bit streams) against the oracle, and two
+    synthetic batches back to back against the device-resident pipeline"""
+    from bionumpy_amd.hostfed import HostFedCounter, cut_points
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    from bionumpy_amd import synth
+    k = 31
+    rng = np.random.default_rng(11)
+    lens = rng.integers(1, 400, size=30_000)
+    recs = []
+    for i, n in enumerate(lens):
+        seq = "".join(rng.choice(list("ACGTacgt"), size=n))
+        recs.append("@read%d with @ and + in the name\n%s\n+\n%s\n" % (i, seq, "".join(rng.choice(list("@+IJ5"), size=n))))
+    ragged = np.frombuffer("".join(recs).encode(), dtype=np.uint8)
+    keep1, text1 = _pinned_copy(ragged)
+    bounds = set(np.cumsum([0] + [len(r) for r in recs]).tolist())
+    cuts = cut_points(text1, 1 << 20)
+    assert len(cuts) > 5 and all(c in bounds for c in cuts)
+    counter = HostFedCounter(k, chunk_bytes=1 << 20, ring=3)
+    (keys, counts), stats = list(counter.run([text1]))[0]
+    res = oracle.scan_one_line_buffer(ragged, oracle.FASTQ)
+    codes = oracle.encode_dna(oracle.gather_rows(ragged, res.field_starts[:, 1], res.field_lens[:, 1]))
+    h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], k)
+    ek, ec = oracle.count_sparse(h)
+    assert stats.n_reads == 30_000 and stats.n_bases == int(lens.sum()) and stats.n_kmers == h.size
+    assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+    assert counter.timing.chunks == len(cuts) and counter.timing.bytes == ragged.size
+    # two batches back to back (the second one's copies overlap the first one's counting stage)
+    batches = [synth.fastq_bytes(200_000, 150, 3, 0, 0, 0), synth.fastq_bytes(150_000, 150, 4, 1, 300_000, 0)]
+    pinned = [_pinned_copy(b) for b in batches]
+    counter = HostFedCounter(k, chunk_bytes=8 << 20, ring=4)
+    got = list(counter.run([p[1] for p in pinned]))
+    assert len(got) == 2
+    for ((keys, counts), stats), text in zip(got, batches):
+        (rk, rc), rstats = fastq_kmer_histogram(HArray(host=text), k)
+        assert stats.n_reads == rstats.n_reads and stats.n_kmers == rstats.n_kmers and stats.n_bases == rstats.n_bases
+        assert np.array_equal(keys.host(), rk.host()) and np.array_equal(counts.host(), rc.host())
+    assert counter.timing.h2d_gb_per_s > 0 and 0.0 <= counter.timing.overlap_frac <= 1.0
+    # a bad base is reported with the reference's exception
+    bad = batches[0].copy()
+    bad[316 * 777 + 20] = ord("N")
+    kb, tb = _pinned_copy(bad)
+    from bionumpy_amd.exceptions import EncodingError
+    with pytest.raises(EncodingError):
+        list(HostFedCounter(k, chunk_bytes=8 << 20, ring=2).run([tb]))
 
 
 def test_saccer3_decoded_on_the_device_equals_the_oracle(ops, tmp_path):
