@@ -118,6 +118,44 @@ def host_fed_leg(args, text, expected_sums):
             "link_bound_gbases_per_s": round(tm.h2d_gb_per_s / (n / n_bases * args.host_fed_batches), 2) if n_bases else None}
 
 
+def virtual_ranks_mode(args, ops, dev, mode):
+    """--virtual-ranks N: shard -> k-mers partitioned by the send cuts -> (the exchange's result) -> every rank's key range
+    counted; the concatenation is checked against the k-mers of all reads (tests/fullsize.py) and one JSON line is printed"""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize
+    from bionumpy_amd.device import HArray
+    from bionumpy_amd.pipeline import fastq_kmer_histogram_virtual_ranks
+    n = args.virtual_ranks
+    per = -(-args.reads // n)
+    texts = [ops.synth_fastq(min(per, args.reads - r * per), args.read_len, args.seed, mode, args.genome_len, r * per)
+             for r in range(n)]
+    for _ in range(args.warmup):
+        fastq_kmer_histogram_virtual_ranks(texts, args.k, canonical=args.canonical)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        hists, stats, received = fastq_kmer_histogram_virtual_ranks(texts, args.k, canonical=args.canonical)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    sums = [0, 0, 0, 0]
+    for keys, counts in hists:
+        sums = [(a + b) & ((1 << 64) - 1) if i else a + b for i, (a, b) in enumerate(zip(sums, fullsize.histogram_sums(keys, counts)))]
+    flat = [0, 0, 0, 0]
+    for text, st in zip(texts, stats):
+        flat = [(a + b) & ((1 << 64) - 1) if i else a + b
+                for i, (a, b) in enumerate(zip(flat, fullsize.reads_sums(ops, text, st.n_reads, args.read_len, args.k, args.canonical)))]
+    assert sums == flat, "virtual ranks: checksums differ %s vs %s" % (sums, flat)
+    bounds = [(int(k.dev()[0]), int(k.dev()[-1])) for k, _ in hists if k.size]
+    assert all(a[1] < b[0] for a, b in zip(bounds[:-1], bounds[1:])), "key ranges of the ranks overlap"
+    print(json.dumps({"mode": "virtual ranks (one GPU plays N ranks; functional, not a scaling number)", "virtual_ranks": n,
+                      "reads_total": args.reads, "k": args.k, "ms_per_step": round(dt * 1e3, 2),
+                      "gbases_per_s_one_gpu_doing_all_ranks": round(sum(s.n_bases for s in stats) / dt / 1e9, 3),
+                      "keys_received_per_rank": received, "distinct_per_rank": [k.size for k, _ in hists],
+                      "parity": "count / sum / sum of squares / mixed sum of all ranks' (key, count) == k-mers in read order; "
+                                "key ranges disjoint and ascending"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +169,10 @@ def main():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--virtual-ranks", type=int, default=0,
+                    help="play the N-GPU sparse path on this one GPU: the batch is sharded N ways, the exchange is replaced "
+                         "by its result, every rank's key range is counted (functional check of the N > 1 kernels, "
+                         "not a scaling measurement)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned RAM -> HBM) measurement")
     ap.add_argument("--host-fed-batches", type=int, default=2)
     ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
@@ -149,6 +191,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, "RCCL sees %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus)
 
     from bionumpy_amd.device import Device, HArray
     from bionumpy_amd.ops import get_ops
@@ -165,6 +208,10 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.virtual_ranks > 1:
+        virtual_ranks_mode(args, ops, dev, mode)
+        return
 
     def step():
         hist, stats = fastq_kmer_histogram(text, args.k, canonical=args.canonical)
@@ -218,8 +265,13 @@ def main():
         if world == 1:
             assert int(counted[0]) == int(counted[1]), "histogram does not account for every k-mer: %s" % counted
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    per_rank = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([n_distinct, stats.n_kmers], dtype=torch.int64, device="cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank = {"distinct_keys_held": [int(g[0]) for g in gathered], "kmers_generated": [int(g[1]) for g in gathered]}
     dt = float(tmax.item())
 
     if rank != 0:
@@ -287,6 +339,7 @@ def main():
                    "parallelism": "chunk-sharded x%d%s" % (world, ", key-range all-to-all" if world > 1 else "")},
         "roofline": roofline,
         "kernels": kernels,
+        "per_rank": per_rank,
         "parity_fullsize": bool(parity and parity["ok"]),
         "parity": parity,
     }

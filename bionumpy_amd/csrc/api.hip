@@ -42,6 +42,7 @@ void bnpk_ctx_destroy(bnpk_ctx* ctx) {
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
   delete ctx;
 }
 
@@ -152,7 +153,16 @@ int bnpk_stream_sync(void* stream) {
 }  // extern "C"
 
 // ---- internals ----------------------------------------------------------------------------------
-int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out) {
+int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out, hipStream_t stream) {
+  // One arena, any number of streams: a call that arrives on another stream than the arena's last user first waits
+  // (on the device) for everything that user has enqueued.  A ctx serves one host thread at a time.
+  if (ctx->scratch_in_use && ctx->scratch_stream != stream) {
+    if (!ctx->scratch_event) BNPK_HIP(ctx, hipEventCreateWithFlags(&ctx->scratch_event, hipEventDisableTiming));
+    BNPK_HIP(ctx, hipEventRecord(ctx->scratch_event, ctx->scratch_stream));
+    BNPK_HIP(ctx, hipStreamWaitEvent(stream, ctx->scratch_event, 0));
+  }
+  ctx->scratch_stream = stream;
+  ctx->scratch_in_use = true;
   if (bytes > ctx->scratch_bytes) {
     // grow-only; hipFree synchronises the device, so earlier users of the old arena are done
     if (ctx->scratch) BNPK_HIP(ctx, hipFree(ctx->scratch));

@@ -27,6 +27,10 @@ struct bnpk_ctx {
   int compute_units = 256;
   void* scratch = nullptr;       // grow-only device arena for scan partials and small temporaries
   size_t scratch_bytes = 0;
+  hipStream_t scratch_stream = nullptr;   // the stream of the last call that used the arena (see bnpk_scratch)
+  hipEvent_t scratch_event = nullptr;
+  bool scratch_in_use = false;
+  bool launch_attr_set[8] = {false, false, false, false, false, false, false, false};   // per-device kernel attributes (radix.hip)
   bool prof = false;
   std::vector<bnpk_prof_entry> entries;
   std::vector<bnpk_pending_event> pending;
@@ -54,8 +58,10 @@ struct bnpk_ctx {
   } while (0)
 
 // Scratch arena: returns a device pointer to at least `bytes` bytes (valid until the next call that
-// grows it; every entry point carves what it needs up front, so a single request per call).
-int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out);
+// grows it; every entry point carves what it needs up front, so a single request per call).  The arena is shared by
+// all entry points of the ctx: a call on another stream than the previous user's is ordered behind that user's work
+// with an event (two streams never overwrite each other's tables); a ctx is for one host thread at a time.
+int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out, hipStream_t stream);
 
 // RAII hipEvent timer around a launch (or a group of launches) when profiling is enabled.
 struct bnpk_timer {

@@ -205,7 +205,7 @@ int bnpk_sort_keys(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_alt, int64_t n, in
   BNPK_HIP(ctx, rocprim::radix_sort_keys(nullptr, temp_bytes, keys, (size_t)n, (unsigned)begin_bit,
                                          (unsigned)end_bit, s));
   void* temp = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp));
+  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp, (hipStream_t)stream));
   bnpk_timer t(ctx, begin_bit == 0 ? "sort_keys" : "partition_keys", s);
   BNPK_HIP(ctx, rocprim::radix_sort_keys(temp, temp_bytes, keys, (size_t)n, (unsigned)begin_bit,
                                          (unsigned)end_bit, s));
@@ -225,7 +225,7 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
   size_t temp_bytes = 0;
   BNPK_HIP(ctx, rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, vals, (size_t)n, 0u, (unsigned)key_bits, s));
   void* temp = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp));
+  BNPK_CHECK(bnpk_scratch(ctx, temp_bytes, &temp, (hipStream_t)stream));
   bnpk_timer t(ctx, "sort_pairs", s);
   BNPK_HIP(ctx, rocprim::radix_sort_pairs(temp, temp_bytes, keys, vals, (size_t)n, 0u, (unsigned)key_bits, s));
   *h_in_alt = (keys.current() == reinterpret_cast<uint64_t*>(d_keys_alt)) ? 1 : 0;
@@ -241,7 +241,7 @@ int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_sec
   int64_t tiles = bnpk_run_tiles(n);
   if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "run_census", s);
     if (tiles > 0)

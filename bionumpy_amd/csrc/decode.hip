@@ -156,7 +156,7 @@ int bnpk_byte_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t val
   int64_t tiles = bnpk_scan_tiles(n);
   if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch, (hipStream_t)stream));
   uint32_t rep = 0x01010101u * value;
   {
     bnpk_timer t(ctx, "byte_census", s);

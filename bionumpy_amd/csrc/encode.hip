@@ -325,7 +325,7 @@ int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d
   // tiles of 256 packed words (8192 bases); the launch has extra workgroup(s) for the pad word
   const int64_t n_tiles = ceil_div(n_words, BNPK_BLOCK);
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "gather_encode_dna", s);
   if (total > 0)
     BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 32, (int64_t*)table, s));
@@ -353,7 +353,7 @@ int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_start
   int64_t blocks = ceil_div(total, (int64_t)BNPK_BLOCK * 16);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "gather_rows", s);
   BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 16, (int64_t*)table, s));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_buf, d_starts, d_offsets,
@@ -409,7 +409,7 @@ int bnpk_lut_bytes(bnpk_ctx* ctx, const uint8_t* d_in, int64_t n, const uint8_t*
   if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return BNPK_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   void* lut = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, 256, &lut));
+  BNPK_CHECK(bnpk_scratch(ctx, 256, &lut, (hipStream_t)stream));
   BNPK_HIP(ctx, hipMemcpyAsync(lut, h_lut256, 256, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipStreamSynchronize(s));              // (the table is the caller's host memory)
   bnpk_timer t(ctx, "lut_bytes", s);

@@ -481,7 +481,7 @@ int bnpk_fastq_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_
   int64_t* line_base = recs + tiles * FQ_TREC;
   int64_t* seq_base = line_base + tiles + 1;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch, (hipStream_t)stream));
   int64_t* scan_scratch = (int64_t*)scratch;
   {
     bnpk_timer t(ctx, "fastq_census", s);

@@ -341,7 +341,7 @@ int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d
   const int64_t n_tiles = ceil_div(n_bases, WF_TILE), n_mask_words = ceil_div(n_bases, 64);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch, (hipStream_t)stream));
   int64_t* tile_off = (int64_t*)scratch;
   int64_t* scan_scratch = tile_off + n_tiles + 1;
   bnpk_timer t(ctx, kmers_per_window == 1 ? "kmers_flat" : "minimizers_flat", s);
@@ -364,7 +364,7 @@ static int match_windows(bnpk_ctx* ctx, bool packed, const void* d_src, const ui
   const int64_t n_tiles = ceil_div(n_items, WF_TILE), n_mask_words = ceil_div(n_items, 64);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch, (hipStream_t)stream));
   int64_t* tile_off = (int64_t*)scratch;
   int64_t* scan_scratch = tile_off + n_tiles + 1;
   wf_pattern pat;
@@ -397,7 +397,7 @@ int bnpk_pwm_scores(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d_s
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* scratch = nullptr;
   const size_t pwm_bytes = (sizeof(wf_pwm) + 63) & ~(size_t)63;
-  BNPK_CHECK(bnpk_scratch(ctx, pwm_bytes + (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, pwm_bytes + (size_t)(n_tiles + 1) * 8 + bnpk_scan_scratch_bytes(n_tiles), &scratch, (hipStream_t)stream));
   wf_pwm* d_pwm = (wf_pwm*)scratch;
   int64_t* tile_off = (int64_t*)((char*)scratch + pwm_bytes);
   int64_t* scan_scratch = tile_off + n_tiles + 1;
@@ -436,7 +436,7 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "kmers", s);
   BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL((kmer_kernel<false>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
@@ -454,7 +454,7 @@ int bnpk_kmers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_i
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "kmers_generic", s);
   BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL(kmer_generic_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, d_in_offsets,
@@ -473,7 +473,7 @@ int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "minimizers", s);
   BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL((kmer_kernel<true>), dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, d_in_offsets,
@@ -491,7 +491,7 @@ int bnpk_row_ids(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "row_ids", s);
   BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL(row_ids_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_offsets, n_rows, n,

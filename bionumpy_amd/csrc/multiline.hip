@@ -138,7 +138,7 @@ int bnpk_multiline_cut(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_new
   if (!d_buf || !d_newlines) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, 16, &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, 16, &scratch, (hipStream_t)stream));
   BNPK_HIP(ctx, hipMemsetAsync(scratch, 0, 16, s));
   {
     bnpk_timer t(ctx, "multiline_cut", s);
@@ -166,7 +166,7 @@ int bnpk_multiline_table(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t size, cons
   // scratch: three scan arrays of n_lines + 1, the per-record cumulative byte counts (<= n_lines + 1), scan partials
   const size_t arr = (size_t)(n_lines + 1) * 8;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, 4 * arr + bnpk_scan_scratch_bytes(n_lines) + 64, &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, 4 * arr + bnpk_scan_scratch_bytes(n_lines) + 64, &scratch, (hipStream_t)stream));
   int64_t* rec_of = (int64_t*)scratch;
   int64_t* seq_of = rec_of + (n_lines + 1);
   int64_t* bytes_before = seq_of + (n_lines + 1);
@@ -206,7 +206,7 @@ int bnpk_multiline_wrap(bnpk_ctx* ctx, const uint8_t* d_names, const int64_t* d_
   if (!d_name_offsets || !d_seq_offsets || !d_out_offsets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_records) + 64, &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_records) + 64, &scratch, (hipStream_t)stream));
   bnpk_timer t(ctx, "multiline_wrap", s);
   hipLaunchKernelGGL(ml_wrap_sizes_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_records, 256), 4096))), dim3(256), 0, s,
                      d_name_offsets, d_seq_offsets, n_records, width, d_out_offsets);

@@ -505,7 +505,7 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   int64_t* seg_slabs = reinterpret_cast<int64_t*>(scratch + align64(16));
   int64_t* H = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(seg_slabs) + align64((size_t)(n_seg + 1) * 8));
   int64_t* scan_scratch = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(H) + align64((size_t)(hn + 1) * 8));
-  static bool attr_set[3] = {false, false, false};
+  bool* attr_set = ctx->launch_attr_set;
   constexpr int which = std::is_same<Source, mem_source>::value ? 0 : (std::is_same<Source, kmer_source<false>>::value ? 1 : 2);
   if (!attr_set[which]) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 16>,
@@ -641,7 +641,7 @@ int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const 
   if (n_seg > 1 && !d_seg_offsets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n, n_seg, bits), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n, n_seg, bits), &scratch, (hipStream_t)stream));
   mem_source src{reinterpret_cast<const uint64_t*>(d_keys)};
   return rp_level(ctx, src, n, d_seg_offsets, n_seg, shift, bits, d_out, d_child_offsets, (char*)scratch,
                   "radix_hist", "radix_scatter", s);
@@ -655,7 +655,7 @@ int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t
   if (n_bases > 0 && (!d_packed || !d_kmer_starts || !d_out)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n_bases, 1, bits), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n_bases, 1, bits), &scratch, (hipStream_t)stream));
   if (canonical) {
     kmer_source<true> src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
     return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
@@ -677,12 +677,11 @@ int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, 
   if (n > 0 && (!d_keys || !d_out || d_keys == d_out)) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, 64, &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, 64, &scratch, (hipStream_t)stream));
   const size_t lds = (size_t)RS_CAP * 8 + (size_t)RS_MAXB * (RS_THREADS / 64) * 4 + RS_MAXB * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx->launch_attr_set[3]) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_split_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->launch_attr_set[3] = true;
   }
   BNPK_HIP(ctx, hipMemsetAsync(scratch, 0, 8, s));
   {

@@ -119,7 +119,7 @@ int bnpk_reverse_complement_packed(bnpk_ctx* ctx, const uint64_t* d_packed, cons
   const int64_t n_tiles = ceil_div(n_words, RC_TILE_WORDS);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "reverse_complement_packed", s);
   if (n_rows > 0 && total > 0) BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, RC_TILE_BASES, (int64_t*)table, s));
   hipLaunchKernelGGL(rc_packed_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, d_offsets, n_rows, total,
@@ -137,7 +137,7 @@ int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const i
   const int64_t n_tiles = ceil_div(total, RC_TILE_BYTES);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "reverse_complement_bytes", s);
   BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, RC_TILE_BYTES, (int64_t*)table, s));
   hipLaunchKernelGGL(rc_bytes_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_bytes, d_offsets, n_rows, total,

@@ -157,7 +157,7 @@ extern "C" int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const
   const int64_t n_tiles = ceil_div(total, JL_TILE);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "join_lines", s);
   BNPK_CHECK(build_tile_rows(ctx, d_entry_offsets, n_rows, JL_TILE, (int64_t*)table, s));
   hipLaunchKernelGGL(join_lines_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, lines, n_lines, header,
@@ -223,7 +223,7 @@ extern "C" int bnpk_col_sums_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int6
   const int64_t n_tiles = ceil_div(total, CS_TILE);
   if (n_tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table));
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "col_sums_u8", s);
   BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, CS_TILE, (int64_t*)table, s));
   hipLaunchKernelGGL(col_sums_u8_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_data, d_offsets, n_rows, total,

@@ -108,7 +108,7 @@ extern "C" {
 int bnpk_exclusive_scan_i64(bnpk_ctx* ctx, const int64_t* d_in, int64_t n, int64_t* d_out, void* stream) {
   if (!ctx || n < 0 || !d_out || (n > 0 && !d_in)) return BNPK_ERR_ARG;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n), &scratch, (hipStream_t)stream));
   bnpk_timer t(ctx, "exclusive_scan_i64", (hipStream_t)stream);
   return bnpk_scan_launch(ctx, d_in, n, 1, d_out, true, (int64_t*)scratch, (hipStream_t)stream);
 }
@@ -117,7 +117,7 @@ int bnpk_row_offsets(bnpk_ctx* ctx, const int64_t* d_lens, int64_t n, int window
                      void* stream) {
   if (!ctx || n < 0 || !d_offsets || (n > 0 && !d_lens) || window < 1) return BNPK_ERR_ARG;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n), &scratch));
+  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n), &scratch, (hipStream_t)stream));
   bnpk_timer t(ctx, "row_offsets", (hipStream_t)stream);
   return bnpk_scan_launch(ctx, d_lens, n, window, d_offsets, true, (int64_t*)scratch, (hipStream_t)stream);
 }

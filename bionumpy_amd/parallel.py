@@ -85,6 +85,29 @@ def exchange_by_key_range(hashes, key_bits, group=None, cuts=None):
     return _from_tensor(recv_t, ops), key_range
 
 
+def count_sparse_virtual(shards, key_bits):
+    """The N > 1 sparse path on ONE GPU: ``shards`` = [(hashes partitioned by their top FINE_BITS bits, cuts)] of N
+    virtual ranks (what kmers_partitioned(FINE_BITS) leaves on every rank before the exchange).  The all-to-all is
+    replaced by what it delivers — for destination r the slices of its fine buckets from source 0, 1, .. N-1, one
+    after the other — and every destination then counts its own key range exactly as count_sparse_distributed does.
+    Returns [(keys, counts)] per virtual rank (concatenated: the histogram of all shards) and the per-rank key counts."""
+    ops = get_ops()
+    world = len(shards)
+    owner = rank_of_bucket(world)
+    cuts = [np.asarray(c.host(), dtype=np.int64) for _, c in shards]
+    out, received = [], []
+    for r in range(world):
+        mine = np.flatnonzero(owner == r)
+        lo_b, hi_b = int(mine[0]), int(mine[-1]) + 1
+        key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
+        pieces = [HArray(dev=part.dev()[c[lo_b]:c[hi_b]]) if not getattr(ops, "host_only", False)
+                  else HArray(host=part.host()[c[lo_b]:c[hi_b]]) for (part, _), c in zip(shards, cuts)]
+        recv = ops.concat(pieces)                       # == the receive buffer of all_to_all_single on rank r
+        received.append(recv.size)
+        out.append(ops.count_sparse(recv, key_bits=key_bits, consume=True, key_range=key_range))
+    return out, received
+
+
 def count_sparse_distributed(hashes, key_bits, group=None, cuts=None):
     """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range"""
     ops = get_ops()

@@ -91,6 +91,26 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
 
 
+def fastq_kmer_histogram_virtual_ranks(texts, k, buffer_type=FastQBuffer, canonical=False):
+    """The sparse N-GPU path with the N ranks played one after the other by a single GPU: texts[r] is rank
+    r's shard of the reads.  Every virtual rank decodes its shard and generates its k-mer hashes grouped by the top
+    parallel.FINE_BITS bits (the send cuts); parallel.count_sparse_virtual stands in for the exchange and counts every
+    rank's key range.  Returns ([(keys, counts)] per rank, [BatchStats] per rank, keys received per rank)."""
+    assert k > DENSE_MAX_K
+    ops = get_ops()
+    lpe = buffer_type.n_lines_per_entry
+    shards, stats = [], []
+    for text in texts:
+        packed, ends, n, n_bases = ops.fastq_encode(text, text.size, lpe, 1, ord(buffer_type.HEADER), buffer_type._check_plus)
+        starts_mask, n_kmers = ops.kmer_starts_from_ends(ends, n_bases, k)
+        del ends
+        shards.append(ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, parallel.FINE_BITS, canonical=canonical))
+        stats.append(BatchStats(n, n_bases, n_kmers, text.size))
+        del packed, starts_mask
+    hists, received = parallel.count_sparse_virtual(shards, 2 * k)
+    return hists, stats, received
+
+
 def fastq_minimizers(text, k, window_size, buffer_type=FastQBuffer):
     """BASELINE config 3 as a pipeline: text (HArray uint8, complete FASTQ records) -> the minimizers of every window
     of ``window_size`` bases of every read, ragged-flat (get_minimizers, sequence/minimizers.py:8-54), through the

@@ -17,7 +17,10 @@
  *     every buffer (the Python side allocates HBM through torch, pinned host memory through
  *     bnpk_host_alloc); the library keeps only a small grow-only scratch arena inside the ctx
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
- *     asynchronous on that stream unless documented otherwise
+ *     asynchronous on that stream unless documented otherwise.  Calls of one ctx may use different
+ *     streams: the scratch arena is handed from stream to stream with an event (a call on another
+ *     stream than the previous call's waits, on the device, for that call's work), everything the
+ *     caller owns is the caller's to order
  *   - byte buffers handed to the scanners must be 16-byte aligned (any torch allocation is)
  *   - one ctx per GPU per host thread
  */

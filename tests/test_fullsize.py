@@ -62,6 +62,32 @@ def _oracle_fasta(path):
     return codes, res.seq_lens
 
 
+@pytest.mark.parametrize("world,mode", [(2, 0), (8, 0), (3, 1), (8, 1)])
+def test_virtual_ranks_equal_the_unsharded_histogram(ops, world, mode):
+    """the N-GPU sparse path played by one GPU (pipeline.fastq_kmer_histogram_virtual_ranks): N shards of 5 M reads in
+    total, k-mers partitioned by the send cuts on the device, the exchange replaced by its result, every rank's key
+    range counted with count_sparse(key_range=...) — the concatenation over the ranks must be the unsharded histogram"""
+    from bionumpy_amd.pipeline import fastq_kmer_histogram, fastq_kmer_histogram_virtual_ranks
+    n_reads, read_len, k, seed, genome_len = 5_000_000, 150, 31, 21, 3_000_000
+    per = -(-n_reads // world)
+    texts = [ops.synth_fastq(min(per, n_reads - r * per), read_len, seed, mode, genome_len, r * per) for r in range(world)]
+    hists, stats, received = fastq_kmer_histogram_virtual_ranks(texts, k)
+    assert sum(s.n_reads for s in stats) == n_reads and sum(received) == sum(s.n_kmers for s in stats)
+    if mode == 0:
+        assert max(received) < 1.3 * min(received)                          # uniform keys: balanced ranges
+    whole = ops.synth_fastq(n_reads, read_len, seed, mode, genome_len, 0)
+    (rk, rc), _ = fastq_kmer_histogram(whole, k)
+    import torch
+    keys = torch.cat([h[0].dev() for h in hists])
+    counts = torch.cat([h[1].dev() for h in hists])
+    assert keys.numel() == rk.size and bool((keys == rk.dev()).all()) and bool((counts == rc.dev()).all())
+    for a, b in zip(hists[:-1], hists[1:]):                                 # the ranks' key ranges do not overlap
+        assert a[0].size == 0 or b[0].size == 0 or int(a[0].dev()[-1]) < int(b[0].dev()[0])
+    done = fullsize.check_histogram(ops, whole, n_reads, read_len, k, seed, mode, genome_len, 0,
+                                    HArray(dev=keys), HArray(dev=counts))
+    assert done["kmers"] == sum(s.n_kmers for s in stats)
+
+
 def _pinned_copy(array):
     from bionumpy_amd.io.pinned import PinnedBuffer
     buf = PinnedBuffer(array.size + 64)

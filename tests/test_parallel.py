@@ -23,3 +23,29 @@ def test_bucket_ownership_is_contiguous_and_balanced():
         assert owner[0] == 0 and owner[-1] == world - 1 and np.all(np.diff(owner) >= 0)
         sizes = np.bincount(owner, minlength=world)
         assert sizes.max() - sizes.min() <= 1
+
+
+def test_virtual_ranks_on_the_host_logic():
+    """pipeline.fastq_kmer_histogram_virtual_ranks with the oracle-backed ops: shard -> partition by send cuts -> the
+    exchange's result -> per-range counts == np.unique over all reads"""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from oracle_ops import OracleOps
+    from bionumpy_amd import ops as ops_mod, synth
+    from bionumpy_amd.device import HArray
+    from bionumpy_amd.pipeline import fastq_kmer_histogram_virtual_ranks
+    ops_mod.set_ops(OracleOps())
+    try:
+        world, per, read_len, k = 3, 400, 90, 31
+        texts = [HArray(host=synth.fastq_bytes(per, read_len, 9, 1, 7000, r * per)) for r in range(world)]
+        hists, stats, received = fastq_kmer_histogram_virtual_ranks(texts, k)
+        codes = synth.read_codes(world * per, read_len, 9, 1, 7000, 0)
+        h, _ = oracle.get_kmers(codes.reshape(-1), np.full(world * per, read_len, dtype=np.int64), k)
+        ek, ec = oracle.count_sparse(h)
+        assert np.array_equal(np.concatenate([a.host() for a, _ in hists]), ek)
+        assert np.array_equal(np.concatenate([c.host() for _, c in hists]), ec)
+        assert sum(received) == h.size
+    finally:
+        ops_mod.set_ops(None)
