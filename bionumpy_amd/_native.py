@@ -75,6 +75,9 @@ SIGNATURES = {
     "bnpk_multiline_cut": (_int, [_p, _p, _p, _i64, _u8, C.POINTER(_i64), C.POINTER(_i64), _p]),
     "bnpk_multiline_table": (_int, [_p, _p, _i64, _p, _i64, _u8, _int, _p, _p, _p, _p, _p, _p, _p]),
     "bnpk_multiline_wrap": (_int, [_p, _p, _p, _p, _p, _i64, _int, _u8, _p, _p, _i64, C.POINTER(_i64), _p]),
+    "bnpk_merge_add": (_int, [_p, _p, _p, _i64, _p, _p, _i64, _p, _p, C.POINTER(_i64), _p]),
+    "bnpk_pair_compose": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "bnpk_pair_split": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p]),
     "bnpk_kmers_generic": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
     "bnpk_lut_bytes": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
     "bnpk_kmer_start_mask": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),

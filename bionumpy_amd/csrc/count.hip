@@ -150,6 +150,28 @@ __global__ void search_sorted_kernel(const int64_t* __restrict__ sorted, int64_t
   }
 }
 
+// A12 without a key-value sort: the distinct (kmer, row) pairs of KmerIndex.create_index (kmer_indexing.py:24-47) are the
+// distinct values of ONE integer per occurrence, id = rank(kmer) * n_rows + row with rank = index of the k-mer among the
+// sorted distinct k-mers — ascending ids are ascending (kmer, row) — so the index is built by the sparse counting path
+// twice (k-mers, then ids) and two element-wise kernels.
+__global__ void pair_compose_kernel(const int64_t* __restrict__ rank, const int64_t* __restrict__ rows, int64_t n, int64_t n_rows,
+                                    int64_t* __restrict__ ids) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) ids[i] = rank[i] * n_rows + rows[i];
+}
+
+__global__ void pair_split_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t n_rows, const int64_t* __restrict__ keys,
+                                  int64_t* __restrict__ keys_out, int64_t* __restrict__ rows_out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int64_t id = ids[i], r = id / n_rows;
+    keys_out[i] = keys[r];
+    rows_out[i] = id - r * n_rows;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -292,6 +314,32 @@ int bnpk_search_sorted(bnpk_ctx* ctx, const int64_t* d_sorted, int64_t n, const 
   bnpk_timer t(ctx, "search_sorted", s);
   hipLaunchKernelGGL(search_sorted_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_sorted, n, d_queries, m,
                      upper, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_pair_compose(bnpk_ctx* ctx, const int64_t* d_rank, const int64_t* d_rows, int64_t n, int64_t n_rows, int64_t* d_ids,
+                      void* stream) {
+  if (!ctx || n < 0 || n_rows < 1) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_rank || !d_rows || !d_ids) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "pair_compose", s);
+  hipLaunchKernelGGL(pair_compose_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->compute_units * 32))),
+                     dim3(256), 0, s, d_rank, d_rows, n, n_rows, d_ids);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_pair_split(bnpk_ctx* ctx, const int64_t* d_ids, int64_t n, int64_t n_rows, const int64_t* d_sorted_keys,
+                    int64_t* d_keys_out, int64_t* d_rows_out, void* stream) {
+  if (!ctx || n < 0 || n_rows < 1) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_ids || !d_sorted_keys || !d_keys_out || !d_rows_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "pair_split", s);
+  hipLaunchKernelGGL(pair_split_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->compute_units * 32))),
+                     dim3(256), 0, s, d_ids, n, n_rows, d_sorted_keys, d_keys_out, d_rows_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -606,19 +606,41 @@ class HipOps:
         return keys_out, counts
 
     def _precount_buckets(self, keys_t, offsets_t, bucket_ids_t, key_bits):
-        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets counted with the sort + run kernels"""
+        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets (ascending ids) counted in ONE batch — their
+        keys are gathered into one array (bnpk_gather_rows over the buckets' byte ranges), sorted and run-length-counted
+        once (buckets differ in their top bits, so the batch sorts bucket by bucket), and the distinct keys are cut
+        back into buckets by a binary search of every bucket's first possible key."""
         t = torch_mod()
-        ids = bucket_ids_t.cpu().numpy()
-        bounds = t.stack([offsets_t[bucket_ids_t], offsets_t[bucket_ids_t + 1]]).cpu().numpy()
-        table, all_keys, all_counts, at = [], [], [], 0
-        for j, b in enumerate(ids):
-            k, c = self._count_by_sorting(keys_t[int(bounds[0, j]):int(bounds[1, j])].clone(), key_bits)
-            table += [int(b), int(k.numel()), at]
-            at += int(k.numel())
-            all_keys.append(k.clone())
-            all_counts.append(c)
-        return (self.device.upload(np.array(table, dtype=np.int64)), t.cat(all_keys), t.cat(all_counts))
+        nb = int(bucket_ids_t.numel())
+        lo = offsets_t[bucket_ids_t]
+        sizes = offsets_t[bucket_ids_t + 1] - lo
+        byte_off = self._empty(nb + 1, np.int64)
+        byte_off[0] = 0
+        byte_off[1:] = t.cumsum(sizes * 8, 0)
+        total = int(byte_off[nb].item())
+        batch = self._empty(total, np.uint8)
+        self._chk(lib.bnpk_gather_rows(self.ctx, ptr(keys_t.view(t.uint8)), ptr(lo * 8), ptr(byte_off), nb, total, 0,
+                                       ptr(batch), self._s()))
+        k, c = self._count_by_sorting(batch.view(t.int64), key_bits)
+        # the distinct keys of listed bucket b start where the keys (with multiplicity) of the earlier listed buckets end
+        prefix = t.cumsum(sizes, 0) - sizes                  # keys (with multiplicity) of earlier buckets in the batch
+        cum = self._empty(k.numel() + 1, np.int64)
+        self._chk(lib.bnpk_exclusive_scan_i64(self.ctx, ptr(c), c.numel(), ptr(cum), self._s()))
+        starts = self._empty(nb, np.int64)
+        self._chk(lib.bnpk_search_sorted(self.ctx, ptr(cum), cum.numel(), ptr(prefix), nb, 0, ptr(starts), self._s()))
+        ends = t.cat([starts[1:], t.tensor([k.numel()], dtype=t.int64, device=starts.device)])
+        table = t.stack([bucket_ids_t.to(t.int64), ends - starts, starts], dim=1).reshape(-1).contiguous()
+        return table, k, c
 
+    def merge_add(self, a_keys, a_counts, b_keys, b_counts):
+        """(keys, counts) of the sum of two sparse histograms (sorted distinct keys each): bnpk_merge_add"""
+        na, nb = a_keys.size, b_keys.size
+        out_k, out_c = self._empty(na + nb, np.int64), self._empty(na + nb, np.int64)
+        n_out = C.c_int64(0)
+        self._chk(lib.bnpk_merge_add(self.ctx, ptr(a_keys.dev()) if na else None, ptr(a_counts.dev()) if na else None, na,
+                                     ptr(b_keys.dev()) if nb else None, ptr(b_counts.dev()) if nb else None, nb,
+                                     ptr(out_k), ptr(out_c), C.byref(n_out), self._s()))
+        return HArray(dev=out_k[:n_out.value]), HArray(dev=out_c[:n_out.value])
 
     def reduce_by_key(self, keys, weights, key_bits=62):
         """sum of weights per distinct key (merge of sparse histograms; EncodedCounts.__add__ analogue)."""
@@ -652,26 +674,29 @@ class HipOps:
         self._chk(lib.bnpk_row_ids(self.ctx, ptr(offsets.dev()), n_rows, n, ptr(rows), self._s()))
         return HArray(dev=rows)
 
-    def unique_pairs(self, keys, values, key_bits=62):
-        """sorted distinct (key, value) pairs; values must already ascend within equal keys' input order
-        (row ids do), since the radix sort is stable."""
-        t = keys.dev().clone()
-        v = values.dev().clone()
+    def unique_pairs(self, keys, values, key_bits=62, n_values=None):
+        """sorted distinct (key, value) pairs, values in [0, n_values) — KmerIndex.create_index.  No key-value sort: the
+        pairs are the distinct values of id = rank(key) * n_values + value, rank = position among the sorted distinct
+        keys, so the index is two runs of the sparse counting path (bnpk_pair_compose / bnpk_pair_split around them)."""
+        t, v = keys.dev(), values.dev()
         n = t.numel()
         if n == 0:
-            return HArray(dev=t), HArray(dev=v)
-        t_alt = self._empty(n, np.int64)
-        v_alt = self._empty(n, np.int64)
-        in_alt = C.c_int(0)
-        self._chk(lib.bnpk_sort_pairs(self.ctx, ptr(t), ptr(t_alt), ptr(v), ptr(v_alt), n, key_bits, C.byref(in_alt),
-                                      self._s()))
-        if in_alt.value:
-            t, t_alt, v, v_alt = t_alt, t, v_alt, v
-        n_runs, tile_off = self._runs(t, v)
-        keys_out, vals_out = t_alt[:n_runs], v_alt[:n_runs]
-        starts = self._empty(n_runs + 1, np.int64)
-        self._chk(lib.bnpk_run_heads(self.ctx, ptr(t), ptr(v), n, ptr(tile_off), n_runs, ptr(keys_out), ptr(vals_out),
-                                     ptr(starts), self._s()))
+            return HArray(dev=t.clone()), HArray(dev=v.clone())
+        if n_values is None:
+            n_values = int(v.max().item()) + 1
+        distinct, _ = self.count_sparse(HArray(dev=t), key_bits=key_bits)
+        rank = self.search_sorted(distinct, HArray(dev=t))
+        ids = self._empty(n, np.int64)
+        self._chk(lib.bnpk_pair_compose(self.ctx, ptr(rank.dev()), ptr(v), n, n_values, ptr(ids), self._s()))
+        del rank
+        id_bits = max(1, (distinct.size * n_values - 1).bit_length())
+        if id_bits > 62:
+            raise NotImplementedError("index too large: %d distinct k-mers x %d rows" % (distinct.size, n_values))
+        uids, _ = self.count_sparse(HArray(dev=ids), key_bits=id_bits, consume=True)
+        m = uids.size
+        keys_out, vals_out = self._empty(m, np.int64), self._empty(m, np.int64)
+        self._chk(lib.bnpk_pair_split(self.ctx, ptr(uids.dev()), m, n_values, ptr(distinct.dev()), ptr(keys_out),
+                                      ptr(vals_out), self._s()))
         return HArray(dev=keys_out), HArray(dev=vals_out)
 
     def search_sorted(self, sorted_keys, queries, upper=False):

@@ -121,8 +121,8 @@ class SparseKmerCounts:
             assert other == 0, "only 0 (the start value of sum) can be added to a sparse histogram"
             return self
         assert self.encoding == other.encoding
-        keys, counts = get_ops().reduce_by_key([self._keys, other._keys], [self._counts, other._counts],
-                                               key_bits=2 * self.encoding.k)
+        # both key lists are sorted and distinct: one merge along the merge path, no sort (bnpk_merge_add)
+        keys, counts = get_ops().merge_add(self._keys, self._counts, other._keys, other._counts)
         return SparseKmerCounts(self.encoding, keys, counts)
 
     __radd__ = __add__

@@ -1,8 +1,9 @@
 """KmerIndex / KmerLookup (bionumpy/sequence/indexing/kmer_indexing.py:7-76) on the MI355X path.
 
 The reference loops over every distinct k-mer with an O(U*N) numpy scan; here the index is the
-sorted, de-duplicated (kmer, row) pair list built by one radix sort on the device, and a lookup is a
-pair of binary searches (``bnpk_search_sorted``) — same answers: the ascending row ids that contain
+sorted, de-duplicated (kmer, row) pair list, built by the sparse counting kernels (the pairs are the distinct
+values of rank(kmer) * n_rows + row, ops.unique_pairs), and a lookup is a pair of binary searches
+(``bnpk_search_sorted``) — same answers: the ascending row ids that contain
 the k-mer, ``[]`` for an unseen k-mer.
 """
 import numpy as np
@@ -33,7 +34,7 @@ class KmerIndex:
         kmers = get_kmers(sequences, k)
         kmers._compact()
         rows = ops.row_ids(kmers.offsets(), len(kmers), kmers.total())
-        keys, rows = ops.unique_pairs(kmers._flat_data(), rows, key_bits=2 * k)
+        keys, rows = ops.unique_pairs(kmers._flat_data(), rows, key_bits=2 * k, n_values=max(len(kmers), 1))
         return cls(k, keys, rows, sequences.encoding)
 
     def _encode_query(self, kmer):

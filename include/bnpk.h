@@ -366,6 +366,21 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                        const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream);
+/* A10 for sparse histograms: the sum of two (sorted distinct keys, counts) lists — EncodedCounts.__add__
+ * (bionumpy/sequence/count_encoded.py:38-48) as `streamable(sum)` folds it over the chunks of a file — by a merge along
+ * the merge path: keys of either list are copied, counts of keys both lists hold are added.  d_out_* need na + nb
+ * entries; *h_n_out = number of distinct keys of the sum (synchronous). */
+int bnpk_merge_add(bnpk_ctx* ctx, const int64_t* d_a_keys, const int64_t* d_a_counts, int64_t na, const int64_t* d_b_keys,
+                   const int64_t* d_b_counts, int64_t nb, int64_t* d_out_keys, int64_t* d_out_counts, int64_t* h_n_out,
+                   void* stream);
+/* A12, KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47) without a key-value sort: with
+ * rank[i] = index of k-mer i among the sorted distinct k-mers (bnpk_search_sorted), id[i] = rank[i] * n_rows + row[i]
+ * orders like (kmer, row); the distinct ids (the sparse counting path again) are split back into
+ * d_keys_out[j] = d_sorted_keys[id / n_rows], d_rows_out[j] = id % n_rows. */
+int bnpk_pair_compose(bnpk_ctx* ctx, const int64_t* d_rank, const int64_t* d_rows, int64_t n, int64_t n_rows, int64_t* d_ids,
+                      void* stream);
+int bnpk_pair_split(bnpk_ctx* ctx, const int64_t* d_ids, int64_t n, int64_t n_rows, const int64_t* d_sorted_keys,
+                    int64_t* d_keys_out, int64_t* d_rows_out, void* stream);
 /* d_tile_offsets needs bnpk_run_tiles(n)+1 entries */
 int64_t bnpk_run_tiles(int64_t n);
 int bnpk_run_census(bnpk_ctx* ctx, const int64_t* d_sorted, const int64_t* d_second, int64_t n,

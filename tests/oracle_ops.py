@@ -304,10 +304,14 @@ class OracleOps:
     def row_ids(self, offsets, n_rows, n):
         return _h(np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(offsets.host())))
 
-    def unique_pairs(self, keys, values, key_bits=62):
+    def unique_pairs(self, keys, values, key_bits=62, n_values=None):
         pairs = np.unique(np.stack([keys.host(), values.host()], axis=1), axis=0) if keys.size else \
             np.zeros((0, 2), dtype=np.int64)
         return _h(pairs[:, 0]), _h(pairs[:, 1])
+
+    def merge_add(self, a_keys, a_counts, b_keys, b_counts):
+        k, c = oracle.merge_sparse([(a_keys.host(), a_counts.host()), (b_keys.host(), b_counts.host())])
+        return _h(k), _h(c)
 
     def search_sorted(self, sorted_keys, queries, upper=False):
         return _h(np.searchsorted(sorted_keys.host(), queries.host(), side="right" if upper else "left")

@@ -127,6 +127,27 @@ def test_sparse_counts_and_merge(ops):
     assert np.array_equal(lo, np.arange(0, ek.size, 1000))
 
 
+@pytest.mark.parametrize("na,nb,overlap", [(0, 0, 0), (0, 5, 0), (7, 0, 0), (1, 1, 1), (2047, 1, 1), (2048, 2048, 2048),
+                                           (2049, 4095, 100), (300_001, 700_003, 123_456), (3_000_000, 3_000_000, 0),
+                                           (2_000_000, 2_000_000, 2_000_000)])
+def test_merge_add_of_sparse_histograms(ops, na, nb, overlap):
+    """A10 sparse: EncodedCounts.__add__ for (sorted distinct keys, counts) along the merge path vs oracle.merge_sparse"""
+    rng = np.random.default_rng(na * 7 + nb * 3 + overlap)
+    pool = np.unique(rng.integers(0, 1 << 62, size=na + nb + 16, dtype=np.int64))[:na + nb - overlap]
+    rng.shuffle(pool)
+    shared, rest = pool[:overlap], pool[overlap:]
+    a = np.sort(np.concatenate([shared, rest[:na - overlap]]))
+    b = np.sort(np.concatenate([shared, rest[na - overlap:na - overlap + nb - overlap]]))
+    assert a.size == na and b.size == nb
+    ca = rng.integers(1, 1000, size=na).astype(np.int64)
+    cb = rng.integers(1, 1000, size=nb).astype(np.int64)
+    ek, ec = oracle.merge_sparse([(a, ca), (b, cb)])
+    gk, gc = ops.merge_add(_h(a), _h(ca), _h(b), _h(cb))
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+    gk, gc = ops.merge_add(_h(b), _h(cb), _h(a), _h(ca))                 # (commutes)
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+
+
 def test_full_path_properties_at_scale(ops):
     """1M synthetic reads (316 MB of FASTQ): size-independent properties of the whole path"""
     import bionumpy_amd as bnp
