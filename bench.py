@@ -60,6 +60,38 @@ def algorithmic_bytes(name, s, read_len, k, n_distinct=None):
     }.get(name)
 
 
+def _oracle_pass(args):
+    """one process of the nproc-sharded baseline: the whole oracle path over its shard of the sample"""
+    host_text, k = args
+    import oracle
+    t0 = time.perf_counter()
+    res = oracle.scan_one_line_buffer(host_text, oracle.FASTQ)
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    codes = oracle.encode_dna(oracle.gather_rows(host_text, starts, lens))
+    h, _ = oracle.get_kmers(codes, lens, k)
+    if k <= 8:
+        oracle.count_dense(h, k)
+    else:
+        oracle.count_sparse(h)
+    return codes.size, time.perf_counter() - t0
+
+
+def cpu_baseline_sharded(host_text, record_bytes, k):
+    """the same sample cut into one shard of whole records per host core, one process each (chunks shard
+    embarrassingly; the per-shard histograms are not merged, which only flatters the CPU)"""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    n_rec = host_text.size // record_bytes
+    per = max(1, n_rec // cores)
+    shards = [host_text[i * per * record_bytes:(i + 1) * per * record_bytes] for i in range(cores) if i * per < n_rec]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(shards)) as pool:
+        done = pool.map(_oracle_pass, [(s, k) for s in shards])
+    dt = time.perf_counter() - t0
+    return {"value": float(sum(d[0] for d in done) / dt / 1e9), "unit": "Gbases/s", "cores": len(shards), "kind": "port",
+            "sample": "%d processes x %d reads of the same sample, wall %.1f s" % (len(shards), per, dt)}
+
+
 def cpu_baseline(host_text, k, budget_s=20.0):
     """the oracle (numpy port of the reference path) on a bounded sample of the same reads, 1 thread"""
     import numpy as np
@@ -300,22 +332,46 @@ def main():
         b = algorithmic_bytes(name, stats, args.read_len, args.k, n_distinct)
         kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
                          "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
-    # HBM traffic of the dominant kernel from the committed PMC profile of this same workload (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in separate passes, scripts/profile_r01.sh; FETCH x2 as MI355X_MICROARCH.md prescribes)
-    traffic = None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the run, so they come from the committed
+    # rocprofv3 --pmc passes of this same command (scripts/profile_r02.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
+    # FETCH x2 as MI355X_MICROARCH.md prescribes) — and only if that profile was taken from THIS build (hash of the kernel
+    # sources) on this workload; otherwise null
+    traffic, traffic_source = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
-        cfg = pmc.get("_config", {})
-        if (cfg.get("reads_per_gpu"), cfg.get("read_len"), cfg.get("k"), cfg.get("mode"), bool(cfg.get("canonical", False))) == \
-                (args.reads, args.read_len, args.k, args.mode, bool(args.canonical)) and world == 1:
-            names = {"finish_sorted": "finish_sorted", "radix_scatter": "rp_scatter<mem_source>",
+        from bionumpy_amd.csrc.build import _source_hash
+        for cand in ("r02_pmc.json", "r01_pmc.json"):
+            path = os.path.join(ROOT, "profiles", cand)
+            if not os.path.exists(path):
+                continue
+            pmc = json.load(open(path))
+            cfg = pmc.get("_config", {})
+            same_work = (cfg.get("reads_per_gpu"), cfg.get("read_len"), cfg.get("k"), cfg.get("mode"), bool(cfg.get("canonical", False))) == \
+                (args.reads, args.read_len, args.k, args.mode, bool(args.canonical)) and world == 1
+            if not same_work or pmc.get("_source_hash") != _source_hash():
+                continue
+            names = {"finish_sorted": "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
                      "fastq_encode": "fq_encode", "fastq_census": "fq_census"}
-            rec = pmc.get(names.get(dom, dom))
+            rec = pmc.get(names.get(dom, dom)) or pmc.get(dom)
             if rec and "read_bytes_corrected" in rec and "write_bytes" in rec:
                 traffic = int(rec["read_bytes_corrected"] + rec["write_bytes"])
+                traffic_source = "profiles/%s (source hash %s)" % (cand, pmc["_source_hash"][:12])
+                break
     except Exception:
         traffic = None
+    measured_peak = None
+    try:                                                     # what this chip streams at (device copy, read + write bytes)
+        import ctypes as C
+        from bionumpy_amd._native import lib
+        src = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(src)
+        rate = C.c_double(0.0)
+        if lib.bnpk_copy_peak(dev.ctx, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), 5, C.byref(rate),
+                              None) == 0:
+            measured_peak = round(rate.value, 1)
+        del src, dst
+    except Exception:
+        measured_peak = None
     if dom is not None:
         p = prof[dom]
         avg_ms = p["total_ms"] / max(p["launches"], 1)
@@ -324,7 +380,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": None if achieved is None else round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 3),
+                    "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 3),
+                    "measured_copy_gb_per_s": measured_peak,
+                    "frac_of_measured_copy": None if (achieved is None or not measured_peak) else round(achieved / measured_peak, 4),
                     "algorithmic_bytes_per_launch": b}
     out = {
         "metric": "Gbases/s FASTQ->k-mer count (k=%d)" % args.k,
@@ -356,6 +414,10 @@ def main():
         m = min(args.reads, args.cpu_sample_reads)
         sample = text.dev()[:m * (2 * args.read_len + 16)].cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(sample, args.k)
+        try:                                                 # the same sample over all host cores, one process per core
+            out["cpu_baseline"]["all_cores"] = cpu_baseline_sharded(sample, 2 * args.read_len + 16, args.k)
+        except Exception as e:
+            out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))

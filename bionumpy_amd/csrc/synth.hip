@@ -1,5 +1,7 @@
 // Synthetic FASTQ generator (bench / test input) written straight into HBM.
 // Every byte is a pure function of (seed, read id, position); bionumpy_amd/synth.py holds the numpy twin.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -78,6 +80,17 @@ __global__ __launch_bounds__(BNPK_BLOCK) void synth_fastq_kernel(uint8_t* __rest
   }
 }
 
+// the rate this chip streams at: dst[i] = src[i], 16 bytes per lane, non-temporal — what bench.py prints next to the 8 TB/s
+// spec peak ("measure achievable with a device memcpy and state it")
+__global__ __launch_bounds__(256) void copy_peak_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  typedef unsigned v4 __attribute__((ext_vector_type(4)));
+  const v4* s4 = reinterpret_cast<const v4*>(src);
+  v4* d4 = reinterpret_cast<v4*>(dst);
+  for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&s4[i]), &d4[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -100,6 +113,29 @@ int bnpk_synth_fastq(bnpk_ctx* ctx, uint8_t* d_out, int64_t first_read, int64_t 
   hipLaunchKernelGGL(synth_fastq_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_out, first_read, n_reads,
                      read_len, seed, mode, genome_len);
   BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s, void* stream) {
+  if (!ctx || !d_src || !d_dst || bytes < 16 || reps < 1 || !h_gb_per_s) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) return BNPK_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n16 = bytes / 16;
+  const unsigned grid = (unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)ctx->compute_units * 64);
+  hipEvent_t e0, e1;
+  BNPK_HIP(ctx, hipEventCreate(&e0));
+  BNPK_HIP(ctx, hipEventCreate(&e1));
+  hipLaunchKernelGGL(copy_peak_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)d_src, (uint4*)d_dst, n16);   // warm-up
+  BNPK_HIP(ctx, hipEventRecord(e0, s));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(copy_peak_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)d_src, (uint4*)d_dst, n16);
+  BNPK_HIP(ctx, hipEventRecord(e1, s));
+  BNPK_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  BNPK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *h_gb_per_s = ms > 0 ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
   return BNPK_OK;
 }
 

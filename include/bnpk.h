@@ -64,6 +64,11 @@ int bnpk_prof_reset(bnpk_ctx* ctx);
 int bnpk_prof_count(bnpk_ctx* ctx);                 /* resolves pending events (synchronises) */
 int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t* launches);
 
+/* the rate the device streams at (measurement aid of bench.py): `reps` copies of `bytes` bytes from d_src to
+ * d_dst with 16-byte non-temporal accesses, timed with hipEvents; *h_gb_per_s = (bytes read + bytes written) / time.
+ * Synchronous. */
+int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s, void* stream);
+
 /* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
  * "finish_mode": which finishing kernel bnpk_finish_sorted launches — 0 = chosen per call from a probe of
  *                the first buckets (default), 1 = the general kernel only, 2 = the fast kernel + redo list only.

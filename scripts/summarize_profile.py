@@ -27,7 +27,7 @@ def _short(name):
         src = "kmer_source" if "kmer_source" in name else "mem_source"
         return "%s<%s>" % (kind, src)
     for key in ("fq_census", "fq_encode", "fq_select", "fq_starts", "fq_detect_cr", "wf_generate", "wf_count",
-                "finish_sorted", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
+                "finish_fast", "finish_sorted", "finish_check", "finish_collect", "finish_fit", "copy_peak", "mg_tile", "mg_split", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
                 "gather_encode", "kmer_kernel", "run_census", "run_heads", "run_sums", "synth_fastq", "fill_kernel",
                 "hist_lds", "hist_global", "finish_runs", "partition_scatter", "partition_hist"):
         if key in name:
@@ -107,6 +107,12 @@ def main():
                 table["_config"] = json.loads(open(bench).read().strip().splitlines()[-1])["config"]
             except Exception:
                 pass
+        try:                                           # the build the counters belong to (bench.py only trusts a matching one)
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from bionumpy_amd.csrc.build import _source_hash
+            table["_source_hash"] = _source_hash()
+        except Exception:
+            pass
         json.dump(table, open(out + "_pmc.json", "w"), indent=1, sort_keys=True)
         print(json.dumps(table, indent=1, sort_keys=True))
 
