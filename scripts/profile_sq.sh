@@ -15,7 +15,7 @@ for pm in ("pmc1", "pmc2"):
     for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, pm), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
-            for key in ("finish_sorted", "rp_scatter", "rp_hist", "fq_encode", "fq_census"):
+            for key in ("finish_fast", "finish_sorted", "rp_scatter", "rp_hist", "fq_encode", "fq_census"):
                 if key in name:
                     short = key + ("<kmer>" if "kmer_source" in name else "<mem>" if "mem_source" in name else "")
                     agg[short][row["Counter_Name"]] += float(row["Counter_Value"])
@@ -31,6 +31,6 @@ for k, c in agg.items():
     d["_valu_active_frac_of_wave_cycles"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3)
     d["_lds_bank_conflict_frac_of_lds_active"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0) / (d.get("SQ_LDS_IDX_ACTIVE", 0) or 1), 3)
     res[k] = d
-json.dump(res, open(out + "/r01_sq_counters.json", "w"), indent=1, sort_keys=True)
+json.dump(res, open(out + "/r02_sq_counters.json", "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {x: y for x, y in v.items() if x.startswith("_")} for k, v in res.items()}, indent=1))
 PY
