@@ -29,24 +29,34 @@ def _hipcc():
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH and /opt/rocm/bin/hipcc)")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _unit_hash(src):
+    """hash of what one object file is built from: its source, every header, the flags"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(HERE, src)] + HEADERS:
+        h.update(open(path, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
 
 
 def _compile(hipcc, src):
+    """(object path, whether it was rebuilt); an object is current iff the stamp next to it carries the hash of its inputs
+    (content, not mtimes: a snapshot copied without mtimes must never leave a stale object in the library)"""
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
     path = os.path.join(HERE, src)
-    if _stale(obj, [path] + HEADERS):
-        cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-        if r.stderr.strip():
-            sys.stderr.write(r.stderr)
-    return obj
+    want = _unit_hash(src)
+    stamp = obj + ".sha256"
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return obj, False
+    cmd = [hipcc] + FLAGS + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return obj, True
 
 
 def _source_hash():
@@ -72,8 +82,9 @@ def build(force=False, verbose=True):
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(hipcc, s), SOURCES))
-    if force or _stale(LIB, objs):
+        built = list(ex.map(lambda s: _compile(hipcc, s), SOURCES))
+    objs = [o for o, _ in built]
+    if True:                                              # the digest differs from the library's stamp: always relink
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -19,10 +19,15 @@ class MemMapEncodedRaggedArray:
     @classmethod
     def load(cls, basename):
         """read-only memory maps -> EncodedRaggedArray (memory_mapping.py:12-31)"""
-        data = np.memmap("%s_data.dat" % basename, dtype=np.uint8, mode="r")
-        lengths = np.memmap("%s_lengths.dat" % basename, dtype=np.int32, mode="r")
+        import os
         with open("%s_encoding.pkl" % basename, "rb") as f:
             encoding = pickle.load(f)
+
+        def mapped(path, dtype):                       # (np.memmap cannot map an empty file)
+            return np.memmap(path, dtype=dtype, mode="r") if os.path.getsize(path) else np.zeros(0, dtype=dtype)
+        data = mapped("%s_data.dat" % basename, np.uint8)
+        lengths = mapped("%s_lengths.dat" % basename, np.int32)
+        assert int(np.sum(lengths, dtype=np.int64)) == data.size, "lengths do not add up to the data file"
         return EncodedRaggedArray(EncodedArray(HArray(host=np.ascontiguousarray(data)), encoding),
                                   np.asarray(lengths, dtype=np.int64))
 
@@ -41,15 +46,23 @@ class MemMapEncodedRaggedArray:
                 assert encoding == sequences.encoding, "Expected %s but got %s" % (encoding, sequences.encoding)
         with open("%s_encoding.pkl" % basename, "wb") as f:
             pickle.dump(encoding, f)
-        data = np.memmap("%s_data.dat" % basename, dtype=np.uint8, mode="w+", shape=max(total, 1))[:total]
-        lengths = np.memmap("%s_lengths.dat" % basename, dtype=np.int32, mode="w+", shape=max(n_rows, 1))[:n_rows]
+        def created(path, dtype, n):                   # an empty data set is an empty file, not a phantom element
+            if n:
+                return np.memmap(path, dtype=dtype, mode="w+", shape=n)
+            open(path, "wb").close()
+            return np.zeros(0, dtype=dtype)
+        data = created("%s_data.dat" % basename, np.uint8, total)
+        lengths = created("%s_lengths.dat" % basename, np.int32, n_rows)
         d0 = r0 = 0
         for sequences in loader_creator():
             flat = np.asarray(sequences.raw().ravel())          # compacted on the device, one download per chunk
             data[d0:d0 + flat.size] = flat
             d0 += flat.size
+            assert int(np.max(sequences.lengths, initial=0)) < 2 ** 31, "row longer than the int32 lengths file can say"
             lengths[r0:r0 + len(sequences)] = sequences.lengths
             r0 += len(sequences)
-        data.flush()
-        lengths.flush()
+        if total:
+            data.flush()
+        if n_rows:
+            lengths.flush()
         return cls.load(basename)
