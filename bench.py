@@ -82,7 +82,7 @@ def cpu_baseline_sharded(host_text, record_bytes, k):
     import multiprocessing as mp
     cores = os.cpu_count() or 1
     n_rec = host_text.size // record_bytes
-    per = min(n_rec, 100_000)                              # ~0.4 s of numpy per process: start-up does not dominate
+    per = min(n_rec, 50_000)                               # ~0.2 s of numpy per process: start-up does not dominate
     # every process gets `per` reads of the sample (rotated; the data are i.i.d., the work per shard is the same)
     shards = [host_text[(i * per) % max(n_rec - per + 1, 1) * record_bytes:][:per * record_bytes] for i in range(cores)]
     t0 = time.perf_counter()

@@ -120,7 +120,11 @@ int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value) {
 // ---- host staging -----------------------------------------------------------------------------
 int bnpk_host_alloc(size_t bytes, void** h_out) {
   if (!h_out) return BNPK_ERR_ARG;
-  if (hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return BNPK_ERR_NOMEM;
+  if (hipHostMalloc(h_out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();                             // the failure is reported as a status; it must not stick to the runtime
+    *h_out = nullptr;
+    return BNPK_ERR_NOMEM;
+  }
   return BNPK_OK;
 }
 
@@ -169,7 +173,11 @@ int bnpk_scratch(bnpk_ctx* ctx, size_t bytes, void** out, hipStream_t stream) {
     ctx->scratch = nullptr;
     ctx->scratch_bytes = 0;
     size_t want = bytes + (bytes >> 2) + (1 << 20);
-    if (hipMalloc(&ctx->scratch, want) != hipSuccess) return BNPK_ERR_NOMEM;
+    if (hipMalloc(&ctx->scratch, want) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->scratch = nullptr;
+      return BNPK_ERR_NOMEM;
+    }
     ctx->scratch_bytes = want;
   }
   *out = ctx->scratch;

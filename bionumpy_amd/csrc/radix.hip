@@ -20,9 +20,15 @@
 
 namespace {
 
+#ifndef RP_EXP_HALF
 constexpr int RP_THREADS = 1024;
 constexpr int RP_MAXBITS = 11;
 constexpr int RP_TILE = 8192;                         // new keys per round (at most)
+#else                                                 // (experiment: half-size workgroups, two per CU, digits <= 9 bits)
+constexpr int RP_THREADS = 512;
+constexpr int RP_MAXBITS = 9;
+constexpr int RP_TILE = 4096;
+#endif
 constexpr int RP_MAXITEMS = RP_TILE / RP_THREADS;     // 8
 constexpr uint64_t RP_PHANTOM = 1ull << 63;           // placeholder for the slots before a bucket's first key
 constexpr size_t RP_CACHE_BYTES = 0;                  // LDS scratch handed to the key sources (none needs it now)
@@ -33,10 +39,18 @@ template <int LINE_>
 struct rp_cfg {
   static constexpr int LINE = LINE_;
   static constexpr int LOG_LINE = LINE_ == 16 ? 4 : 3;
+#ifndef RP_EXP_HALF
   static constexpr int MAXB = LINE_ == 16 ? 1024 : 2048;
+#else
+  static constexpr int MAXB = LINE_ == 16 ? 512 : 1024;
+#endif
   static constexpr int NBT = MAXB / RP_THREADS;              // buckets owned by one lane
   static constexpr int CARRY = LINE_ - 1;                    // most keys a bucket carries into the next round
+#ifndef RP_EXP_HALF
   static constexpr int STAGE = LINE_ == 16 ? 16384 : 15360;  // keys staged in LDS
+#else
+  static constexpr int STAGE = LINE_ == 16 ? 8192 : 7680;
+#endif
   // LDS carve-up (dynamic, 16-byte aligned pieces)
   static constexpr size_t OFF_META = (size_t)STAGE * 8;
   static constexpr size_t OFF_CNT = OFF_META + (size_t)MAXB * 8;

@@ -25,9 +25,21 @@ for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
         kernels.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 copies.sort()
 kernels.sort()
+chunk_bytes = 1 << 30
+try:                                                       # (this rocprofv3 prints no size column: the chunks are 1 GiB, bench.py says)
+    import json
+    hf = json.loads(open(os.path.join(os.path.dirname(src.rstrip("/")), "bench_hostfed.json")).read().strip().splitlines()[-1])["host_fed"]
+    chunk_bytes = hf["chunk_bytes"]
+except Exception:
+    hf = None
+if copies and max(c[3] for c in copies) == 0:              # no byte counts in the trace: long host-to-device copies are the chunks
+    copies = [(s, e, d, chunk_bytes if (e - s) > 5_000_000 and "HOST_TO_DEVICE" in d.upper().replace(" ", "_") else 0)
+              for s, e, d, _ in copies]
 big = [c for c in copies if c[3] >= (1 << 28)]
 lines = ["# rocprofv3 --kernel-trace --memory-copy-trace -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-         "# memory copies of at least 256 MiB (the host-fed leg's chunks): %d rows" % len(big),
+         "# memory copies of at least 256 MiB (the host-fed leg's chunks; sizes taken as bench.py's chunk size where the trace "
+         "has no size column, the last chunk of a batch is shorter): %d rows" % len(big),
+         "# bench.py host_fed of the traced run: %s" % (json.dumps(hf) if hf else "?"),
          "%-18s %14s %12s %10s" % ("direction", "bytes", "duration_us", "GB/s")]
 for s, e, d, b in big[:12] + ([("...",) * 4] if len(big) > 24 else []) + big[-12:]:
     if s == "...":
