@@ -114,6 +114,11 @@ int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value) {
     ctx->finish_mode = (int)value;
     return BNPK_OK;
   }
+  if (!strcmp(name, "fastq_encoder")) {
+    if (value < 0 || value > 1) return BNPK_ERR_ARG;
+    ctx->fastq_encoder = (int)value;
+    return BNPK_OK;
+  }
   return BNPK_ERR_ARG;
 }
 

@@ -40,6 +40,7 @@ struct bnpk_ctx {
   bool finish_ready = false;
   int finish_fast_grid = 0;
   int finish_mode = 0;           // 0 = choose per call, 1 = general kernel only, 2 = fast kernel + redo list only
+  int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
 };
 
 #define BNPK_HIP(ctx, call)                          \

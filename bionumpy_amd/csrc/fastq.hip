@@ -16,6 +16,8 @@
 // io/fastq_buffer.py:39-45), _get_buffer_extractor + get_field_by_number(1) (io/one_line_buffer.py:140-152,
 // io/file_buffers.py:315-338), EncodedRaggedArray.ravel() + AlphabetEncoding._encode (encodings/alphabet_encoding.py:19-46),
 // BitArray.pack (sequence/kmers.py:121) and the ragged trim [..., :-(k-1)] (sequence/kmers.py:100).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -32,21 +34,25 @@ constexpr int FQ_MAXLPE = 4;
 constexpr int FQ_TREC = 1 + FQ_MAXLPE;                       // per-tile census record: first line, payload bytes per phase
 constexpr uint8_t FQ_NL = 10, FQ_CR = 13;
 
-__device__ __forceinline__ uint32_t fq_match4(uint32_t w, uint32_t rep) {       // high bit of every matching byte
-  uint32_t x = w ^ rep;
-  uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
-  return ~(t | x | 0x7f7f7f7fu);
-}
-__device__ __forceinline__ uint32_t fq_mask16(uint64_t lo, uint64_t hi, uint32_t rep) {   // bit j = byte j matches
+// bit j of the result = byte j of the sixteen bytes is NOT `rep`'s byte.  Per 32-bit word the classic exact zero-byte
+// test leaves 0x7f in a matching byte and 0xff in any other; V_DOT4_U32_U8 against the weights 1,2,4,...,128 then
+// gathers eight flags at a time: sum(w_i * g_i) = 0x7f * 255 + 0x80 * (mask of the non-matching bytes), and the
+// constant goes into the accumulator.
+__device__ __forceinline__ uint32_t fq_nomatch16(uint64_t lo, uint64_t hi, uint32_t rep) {
   const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-  uint32_t m = 0;
+  uint32_t g[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    uint32_t h = fq_match4(w[q], rep);
-    uint32_t b = ((h >> 7) & 1u) | ((h >> 14) & 2u) | ((h >> 21) & 4u) | ((h >> 28) & 8u);
-    m |= b << (4 * q);
+    const uint32_t x = w[q] ^ rep;
+    g[q] = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
   }
-  return m;
+  const uint32_t bias = 0u - 0x7fu * 255u;
+  const uint32_t a = __builtin_amdgcn_udot4(g[1], 0x80402010u, __builtin_amdgcn_udot4(g[0], 0x08040201u, bias, false), false);
+  const uint32_t b = __builtin_amdgcn_udot4(g[3], 0x80402010u, __builtin_amdgcn_udot4(g[2], 0x08040201u, bias, false), false);
+  return (a >> 7) | (b << 1);                                // a, b = 128 * (eight flags)
+}
+__device__ __forceinline__ uint32_t fq_mask16(uint64_t lo, uint64_t hi, uint32_t rep) {   // bit j = byte j matches
+  return ~fq_nomatch16(lo, hi, rep) & 0xffffu;
 }
 
 // one 16-byte chunk of the tile: raw bytes, newline mask, mask of the bytes that are not payload (newlines and,
@@ -109,6 +115,32 @@ __device__ __forceinline__ void fq_tile_prefix(const int v[FQ_ITERS], int ex[FQ_
   }
   __syncthreads();                                           // smem may still be read from a previous call
   if (lane_id() == 0) smem[wave_id()] = run;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < FQ_WAVES; ++w) {
+    const int x = smem[w];
+    if (w < wave_id()) base += x;
+    tot += x;
+  }
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) ex[it] += base;
+  *total = tot;
+}
+
+// The same prefix for counts of at most 16 per chunk (newlines): two chunks share a 32-bit scan, 16 bits each.
+__device__ __forceinline__ void fq_tile_prefix16(const int v[FQ_ITERS], int ex[FQ_ITERS], int* smem, int* total) {
+  static_assert(FQ_ITERS == 4, "two packed scans");
+  const unsigned a = (unsigned)v[0] | ((unsigned)v[1] << 16), b = (unsigned)v[2] | ((unsigned)v[3] << 16);
+  const unsigned ia = wave_inclusive_scan(a), ib = wave_inclusive_scan(b);
+  const unsigned ta = (unsigned)__builtin_amdgcn_readlane((int)ia, 63), tb = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
+  const int t0 = (int)(ta & 0xffffu), t1 = (int)(ta >> 16), t2 = (int)(tb & 0xffffu), t3 = (int)(tb >> 16);
+  ex[0] = (int)(ia & 0xffffu) - v[0];
+  ex[1] = t0 + (int)(ia >> 16) - v[1];
+  ex[2] = t0 + t1 + (int)(ib & 0xffffu) - v[2];
+  ex[3] = t0 + t1 + t2 + (int)(ib >> 16) - v[3];
+  __syncthreads();                                           // smem may still be read from a previous call
+  if (lane_id() == 0) smem[wave_id()] = t0 + t1 + t2 + t3;
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
@@ -273,6 +305,9 @@ __device__ __forceinline__ uint32_t fq_codes8(uint64_t x, uint32_t* invalid) {
   return (uint32_t)((c | (c >> 24)) & 0xFFFFull);
 }
 
+// The general tile encoder: every lane classifies its own sixteen bytes whatever the line structure is.  LIST = false:
+// tile = blockIdx.x.  LIST = true: the tiles the fast kernel below handed back (redo[0] = how many, redo[1..] = which).
+template <bool LIST>
 __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
                                                                int seq_line, uint8_t header, int check_plus,
                                                                const int64_t* __restrict__ flags,
@@ -280,16 +315,21 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
                                                                const int64_t* __restrict__ seq_base, int64_t used,
                                                                unsigned long long* __restrict__ packed,
                                                                unsigned long long* __restrict__ ends,
-                                                               unsigned long long* __restrict__ err) {
+                                                               unsigned long long* __restrict__ err,
+                                                               const unsigned* __restrict__ redo) {
   __shared__ __attribute__((aligned(16))) unsigned stage[FQ_SWORDS];
   __shared__ unsigned ebits[FQ_EWORDS];
   __shared__ int smem[FQ_WAVES];
+  const unsigned n_list = LIST ? redo[0] : 1u;
+  for (unsigned item = LIST ? blockIdx.x : 0u; item < n_list; item += LIST ? gridDim.x : 1u) {
+  const int64_t tile = LIST ? (int64_t)redo[1 + item] : (int64_t)blockIdx.x;
+  if (LIST) __syncthreads();                                 // the staging areas of the previous tile have been read
   const int strip_cr = (int)flags[0];
   const int tid = threadIdx.x;
-  const int64_t tile_base = (int64_t)blockIdx.x * FQ_TILE;
-  const int64_t g0 = recs[(int64_t)blockIdx.x * FQ_TREC];              // absolute line of the tile's first byte
-  const int64_t fbase = seq_base[blockIdx.x];                          // flat base index of the tile's first sequence byte
-  const int S = (int)(seq_base[blockIdx.x + 1] - fbase);               // sequence bytes of the tile
+  const int64_t tile_base = tile * FQ_TILE;
+  const int64_t g0 = recs[tile * FQ_TREC];              // absolute line of the tile's first byte
+  const int64_t fbase = seq_base[tile];                          // flat base index of the tile's first sequence byte
+  const int S = (int)(seq_base[tile + 1] - fbase);               // sequence bytes of the tile
   const int off32 = (int)(fbase & 31), off64 = (int)(fbase & 63);
   // line numbers relative to the tile's first line: 32-bit compares and a cheap phase instead of 64-bit % per chunk
   const int g0_phase = (int)(g0 % lpe);
@@ -297,7 +337,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
   const float inv_lpe = 1.0f / (float)lpe;
   for (int i = tid; i < FQ_SWORDS; i += BNPK_BLOCK) stage[i] = 0;
   for (int i = tid; i < FQ_EWORDS; i += BNPK_BLOCK) ebits[i] = 0;
-  if (blockIdx.x == 0 && tid == 0 && n > 0 && used > 0 && buf[0] != header) atomicMin(&err[0], 0ull);
+  if (tile == 0 && tid == 0 && n > 0 && used > 0 && buf[0] != header) atomicMin(&err[0], 0ull);
 
   fq_chunk c[FQ_ITERS];
   int nls[FQ_ITERS], line[FQ_ITERS], total;
@@ -424,6 +464,276 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
     if (edge) { if (word) atomicOr(&ends[eword0 + w], word); }
     else ends[eword0 + w] = word;
   }
+  }
+}
+
+// ---- encode, the fast kernel --------------------------------------------------------------------------------------------
+// The general kernel above spends ~390 vector instructions per sixteen bytes of text, on every byte of the file, and
+// that — not memory — is its limit (SQ_INSTS_VALU * 4 cycles = its run time).  Half of a FASTQ file is quality and
+// header text that only has to be searched for newlines, and what is left is, to all but one lane in ten, a plain run
+// of sixteen bases.  So this kernel splits the work by what it is done on:
+//   per byte of text   the newline mask (two dot products gather the flags), a copy of the tile in LDS, the tile-wide
+//                      line number of every chunk, the start of every line
+//   per line           start, phase, number of bases and (one scan over the lines) the rank of its first base in the
+//                      tile and the number of sixteen-byte chunks it touches; the read-end bit (an atomic OR into the
+//                      zeroed mask); the check of the byte that starts a header / '+' line; one 32-bit record per
+//                      (line, chunk): chunk, first byte, length, rank
+//   per record         dense lanes again: sixteen bytes from LDS -> codes (V_PERM_B32 looks the letter of every code
+//                      up again and the XOR with the text is the validity test) -> OR-ed into the staging words.
+//                      Lines of more than 256 bytes skip the queue: the whole workgroup walks their chunks.
+// Tiles with more than FQ2_NLMAX newlines or more records than the queue holds (lines shorter than ~20 bytes) and the
+// last tile of the text are handed to the general kernel through a list; the results are the same bits either way
+// (tests/test_gpu_parity.py runs both).
+constexpr int FQ2_NLMAX = 640;                               // lines 0 .. FQ2_NLMAX of a tile have a table entry
+constexpr int FQ2_QCAP = 640;                                // records of lines of at most FQ2_SHORT chunks
+constexpr int FQ2_SHORT = 16;
+constexpr int FQ2_LONGMAX = FQ_TILE / (FQ2_SHORT * FQ_VEC - FQ_VEC) + 2;      // lines touching more than FQ2_SHORT chunks
+constexpr int FQ2_CHUNKS = FQ_TILE / FQ_VEC;                 // 1024
+constexpr int FQ2_WG_PER_CU = 6;                             // resident workgroups per CU the fast kernel is built for (LDS and registers)
+
+// four text bytes -> four codes (low two bits of every byte); *z != 0 in every byte that is not one of ACGTacgt
+__device__ __forceinline__ uint32_t fq_codes4(uint32_t w, uint32_t* z) {
+  const uint32_t u = w & 0xDFDFDFDFu;
+  const uint32_t c = ((u >> 1) & 0x03030303u) ^ ((u >> 2) & 0x01010101u);
+  *z = u ^ __builtin_amdgcn_perm(0u, 0x54474341u, c);        // 'A' 'C' 'G' 'T' selected by the code
+  return c;
+}
+// x mod m for 0 <= x < 4096 + m, 1 <= m <= 4, with inv = ceil(65536 / m): two 24-bit multiplies
+__device__ __forceinline__ int fq_mod_tiny(int x, int m, int inv) { return x - (int)__umul24(__umul24((unsigned)x, (unsigned)inv) >> 16, (unsigned)m); }
+
+// Persistent workgroups (the grid is what fits on the chip; workgroup g takes the tiles g, g + grid, ...): the text of
+// the next tile is requested into registers as soon as this tile's copy is in LDS, so that a workgroup never sits out
+// a memory latency between its tiles — without that the loads are in flight for a third of a tile's life only and the
+// kernel runs at the rate of the latency, not of the instructions.
+__global__ __launch_bounds__(BNPK_BLOCK, FQ2_WG_PER_CU) void fq_encode_fast_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
+                                                                       int seq_line, uint8_t header, int check_plus,
+                                                                       const int64_t* __restrict__ flags,
+                                                                       const int64_t* __restrict__ recs,
+                                                                       const int64_t* __restrict__ seq_base, int64_t used,
+                                                                       int64_t tiles,
+                                                                       unsigned long long* __restrict__ packed,
+                                                                       unsigned long long* __restrict__ ends,
+                                                                       unsigned long long* __restrict__ err,
+                                                                       unsigned* __restrict__ redo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  // one block of LDS carved by hand: six workgroups per CU is a budget of 27306 bytes
+  constexpr int OFF_STAGE = FQ2_CHUNKS * 16, OFF_LTAB = OFF_STAGE + FQ_SWORDS * 4, OFF_RUNS = OFF_LTAB + (FQ2_NLMAX + 2) * 4;
+  constexpr int OFF_LONG = OFF_RUNS + FQ2_QCAP * 4, OFF_SMEM = OFF_LONG + FQ2_LONGMAX * 8, LDS_BYTES = OFF_SMEM + 48;
+  static_assert(OFF_STAGE % 16 == 0 && OFF_LTAB % 4 == 0 && OFF_LONG % 8 == 0 && LDS_BYTES * 6 <= 160 * 1024, "LDS layout");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+  u32x4* text = reinterpret_cast<u32x4*>(lds);               // the tile, chunk c = bytes [16c, 16c + 16)
+  unsigned* stage = reinterpret_cast<unsigned*>(lds + OFF_STAGE);
+  unsigned* ltab = reinterpret_cast<unsigned*>(lds + OFF_LTAB);                     // line l: its start in the tile (low 16 bits)
+  unsigned* runs = reinterpret_cast<unsigned*>(lds + OFF_RUNS);
+  uint2* longs = reinterpret_cast<uint2*>(lds + OFF_LONG);
+  int* smem = reinterpret_cast<int*>(lds + OFF_SMEM);        // 8 ints of scan scratch, then the long-line counter
+  int* n_long = smem + 8;
+  const int tid = threadIdx.x;
+  const int strip_cr = (int)flags[0];
+  const int inv_lpe = (65536 + lpe - 1) / lpe;
+  const unsigned chunk0 = (unsigned)wave_id() * (FQ_ITERS * BNPK_WAVE) + lane_id();
+  const int64_t full_tiles = n >= FQ_TILE + 16 ? (n - 16) / FQ_TILE : 0;     // tiles [0, full_tiles) have their 16 KiB and two more bytes
+  if (blockIdx.x == 0 && tid == 0) {
+    for (int64_t t = full_tiles; t < tiles; ++t) redo[1 + atomicAdd(&redo[0], 1u)] = (unsigned)t;   // the end of the text: bounds checks live in the general kernel
+    if (full_tiles > 0 && used > 0 && buf[0] != header) atomicMin(&err[0], 0ull);
+  }
+  // the text of the tile about to be worked on and what the tables say of it.  The table words and the two bytes
+  // behind the tile are loaded per lane (lane 0: first line, 1: first base, 2: end of the bases; even lanes: the byte
+  // behind the tile, odd lanes: the one after) and read with readlane a tile later: a scalar load, or a vector load the
+  // compiler knows to be uniform, is waited for where it is issued.
+  u32x4 pre[FQ_ITERS];
+  int64_t pre_tab = 0;
+  uint32_t pre_after = 0;
+  auto request = [&](int64_t t) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(buf + t * FQ_TILE) + chunk0;
+#pragma unroll
+    for (int it = 0; it < FQ_ITERS; ++it) pre[it] = __builtin_nontemporal_load(src + it * BNPK_WAVE);
+    const int64_t* tab = lane_id() == 0 ? recs + t * FQ_TREC : seq_base + t + (lane_id() == 1 ? 0 : 1);
+    pre_tab = *tab;
+    pre_after = buf[(t + 1) * FQ_TILE + (lane_id() & 1)];
+  };
+  auto lane64 = [](int64_t v, int lane) {
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, lane));
+  };
+  if ((int64_t)blockIdx.x < full_tiles) request(blockIdx.x);
+  // The per-entry phase keeps one wavefront busy and the record loop gives the first wavefronts one round more.  The
+  // wavefronts of a workgroup sit on different SIMDs, and always the same ones: so the roles rotate from tile to tile
+  // (logical wavefront rw = physical + turn), or one SIMD of every CU carries a third more than the others.
+  int turn = 0;
+  for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x, ++turn) {
+  const int rw = (wave_id() + turn) & (FQ_WAVES - 1), rtid = rw * BNPK_WAVE + lane_id();
+  const int64_t g0 = lane64(pre_tab, 0), fbase = lane64(pre_tab, 1);
+  const int S = (int)(lane64(pre_tab, 2) - fbase);
+  const uint32_t after0 = (uint32_t)__builtin_amdgcn_readlane((int)pre_after, 0), after1 = (uint32_t)__builtin_amdgcn_readlane((int)pre_after, 1);
+  const int off32 = (int)(fbase & 31);
+  const int g0_phase = lpe == 4 ? (int)(g0 & 3) : lpe == 2 ? (int)(g0 & 1) : lpe == 1 ? 0 : (int)(((uint32_t)(g0 >> 32) % 3u + (uint32_t)g0 % 3u) % 3u);
+  const int used_rel = (int)max((int64_t)-1, min(used - g0, (int64_t)1 << 30));
+  __syncthreads();                                           // the previous tile has been written out
+  for (int i = tid; i < FQ_SWORDS; i += BNPK_BLOCK) stage[i] = 0;
+  if (tid == 0) {
+    reinterpret_cast<unsigned short*>(ltab)[0] = 0;
+    *n_long = 0;
+  }
+  // ---- per byte: newline masks, the copy in LDS, line numbers, line starts ----
+  uint32_t nlm[FQ_ITERS];
+  int nls[FQ_ITERS], line[FQ_ITERS], L;
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    const u32x4 v = pre[it];
+    text[chunk0 + it * BNPK_WAVE] = v;
+    nlm[it] = ~fq_nomatch16((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), 0x01010101u * FQ_NL) & 0xffffu;
+    nls[it] = __popc(nlm[it]);
+  }
+  if (tile + gridDim.x < full_tiles) request(tile + gridDim.x);      // (uniform) on its way while this tile is worked on
+  fq_tile_prefix16(nls, line, smem, &L);                     // L = newlines of the tile = index of its last (open) line
+  if (L > FQ2_NLMAX) {                                       // (uniform) too many lines for the table
+    if (tid == 0) redo[1 + atomicAdd(&redo[0], 1u)] = (unsigned)tile;
+    continue;
+  }
+#pragma unroll
+  for (int it = 0; it < FQ_ITERS; ++it) {
+    uint32_t nl = nlm[it];
+    int ln = line[it];
+    const unsigned at = (chunk0 + it * BNPK_WAVE) * FQ_VEC;
+    while (__ballot(nl != 0) != 0ull) {
+      if (nl) {
+        ++ln;
+        reinterpret_cast<unsigned short*>(ltab)[2 * ln] = (unsigned short)(at + __ffs(nl));
+        nl &= nl - 1;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- per record: sixteen bytes of chunk c, of which [a, a + len) are bases; r = rank of the first of them in the tile ----
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+  auto encode = [&](unsigned cidx, int a, int len, int r) {
+    const u32x4 v = text[cidx];
+    uint32_t z0, z1, z2, z3;
+    const uint32_t c0 = fq_codes4(v.x, &z0), c1 = fq_codes4(v.y, &z1), c2 = fq_codes4(v.z, &z2), c3 = fq_codes4(v.w, &z3);
+    const uint32_t codes = __builtin_amdgcn_udot4(c0, 0x40100401u, 0u, false) | (__builtin_amdgcn_udot4(c1, 0x40100401u, 0u, false) << 8) |
+                           (__builtin_amdgcn_udot4(c2, 0x40100401u, 0u, false) << 16) | (__builtin_amdgcn_udot4(c3, 0x40100401u, 0u, false) << 24);
+    const uint32_t val = (codes >> (2 * a)) & (~0u >> (32 - 2 * len));
+    // bytes of the run that are no base: the flags of the non-zero bytes of z, gathered like the newline flags
+    const uint32_t g0z = ((z0 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z0 | 0x7f7f7f7fu, g1z = ((z1 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z1 | 0x7f7f7f7fu;
+    const uint32_t g2z = ((z2 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z2 | 0x7f7f7f7fu, g3z = ((z3 & 0x7f7f7f7fu) + 0x7f7f7f7fu) | z3 | 0x7f7f7f7fu;
+    const uint32_t bias = 0u - 0x7fu * 255u;
+    const uint32_t lo8 = __builtin_amdgcn_udot4(g1z, 0x80402010u, __builtin_amdgcn_udot4(g0z, 0x08040201u, bias, false), false);
+    const uint32_t hi8 = __builtin_amdgcn_udot4(g3z, 0x80402010u, __builtin_amdgcn_udot4(g2z, 0x08040201u, bias, false), false);
+    const uint32_t nz = (((lo8 >> 7) | (hi8 << 1)) >> a) & (0xffffu >> (16 - len));
+    if (nz) {
+      const unsigned long long where = (unsigned long long)(fbase + r + (__ffs(nz) - 1));
+      if (where < bad) bad = where;
+    }
+    const int bitpos = 2 * (off32 + r);
+    const int sh = bitpos & 31;
+    atomicOr(&stage[bitpos >> 5], val << sh);
+    if (sh + 2 * len > 32) atomicOr(&stage[(bitpos >> 5) + 1], val >> (32 - sh));
+  };
+  // ---- per entry: thread k has the lines k * lpe - p0 + {0 .. lpe - 1} of the tile (p0 = phase of the tile's first line),
+  // so the lanes that meet a sequence line sit side by side in the first wavefront(s) and the others pass through ----
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(text);
+  const bool open_line_ends = after0 == FQ_NL || (strip_cr && after0 == FQ_CR && after1 == FQ_NL);
+  int R = 0;                                                 // records queued so far (uniform)
+  {
+    int rank0 = 0;
+    const int n_entries = (int)__umul24(__umul24((unsigned)(L + g0_phase), (unsigned)inv_lpe) >> 16, 1u) + 1;     // (L + p0) / lpe + 1
+    for (int base = 0; base < n_entries; base += BNPK_BLOCK) {
+      const int k = base + rtid;
+      int s = 0, e = 0, len = 0, nch = 0;
+      bool ends_read = false;
+      if (k < n_entries) {
+        const int l0 = (int)__umul24((unsigned)k, (unsigned)lpe) - g0_phase;
+        // the byte that starts a header / '+' line is checked by the tile that holds the newline before it
+#pragma unroll
+        for (int j = 0; j <= 2; j += 2) {
+          const int l = l0 + j;
+          if ((j == 0 || (check_plus && lpe > 2)) && l >= 1 && l <= L && l < used_rel) {
+            const int at = (int)(ltab[l] & 0xffffu);
+            const uint32_t b = at < FQ_TILE ? bytes[at] : after0;
+            if (b != (j == 0 ? (uint32_t)header : (uint32_t)'+')) atomicMin(&err[j == 0 ? 0 : 1], (unsigned long long)((g0 + l) / lpe));
+          }
+        }
+        const int l = l0 + seq_line;
+        if (l >= 0 && l <= L && l < used_rel) {
+          s = (int)(ltab[l] & 0xffffu);
+          e = l < L ? (int)(ltab[l + 1] & 0xffffu) - 1 : FQ_TILE;
+          if (strip_cr && e > s && bytes[e - 1] == FQ_CR && (l < L || after0 == FQ_NL)) --e;
+          len = e - s;
+          if (len > 0) nch = ((e - 1) >> 4) - (s >> 4) + 1;
+          ends_read = l < L || open_line_ends;
+        }
+      }
+      const bool is_long = nch > FQ2_SHORT;
+      int total, x;
+      {                                                      // exclusive scan in the order of the logical wavefronts
+        const int v = len | (is_long ? 0 : nch << 16);
+        const int inc = wave_inclusive_scan(v);
+        if (lane_id() == 63) smem[rw] = inc;
+        __syncthreads();                                     // (every read of ltab above precedes whatever follows)
+        int before = 0;
+        total = 0;
+#pragma unroll
+        for (int w = 0; w < FQ_WAVES; ++w) {
+          const int t = smem[w];
+          before += w < rw ? t : 0;
+          total += t;
+        }
+        x = before + inc - v;
+        __syncthreads();
+      }
+      const int rank = rank0 + (x & 0xffff), qat = R + (x >> 16);
+      rank0 += total & 0xffff;
+      R += total >> 16;
+      if (len > 0) {
+        if (ends_read) {                                     // its last base ends a read
+          const int64_t eb = fbase + rank + len - 1;
+          atomicOr(&ends[eb >> 6], 1ull << (eb & 63));
+        }
+        if (is_long) {
+          longs[atomicAdd(n_long, 1)] = make_uint2((unsigned)s | ((unsigned)e << 16), (unsigned)rank);
+        } else {
+          const int c0 = s >> 4;
+          for (int q = 0; q < nch; ++q) {
+            const int lo = q == 0 ? s & 15 : 0, hi = min(e - ((c0 + q) << 4), FQ_VEC);
+            const int r = rank + (q == 0 ? 0 : ((c0 + q) << 4) - s);
+            if (qat + q < FQ2_QCAP) runs[qat + q] = (unsigned)(c0 + q) | ((unsigned)lo << 10) | ((unsigned)(hi - lo - 1) << 14) | ((unsigned)r << 18);
+          }
+        }
+      }
+    }
+  }
+  if (R > FQ2_QCAP) {                                        // (uniform; the read ends set above are set again, harmlessly)
+    if (tid == 0) redo[1 + atomicAdd(&redo[0], 1u)] = (unsigned)tile;
+    continue;
+  }
+  __syncthreads();
+  for (int t = rtid; t < R; t += BNPK_BLOCK) {
+    const unsigned rec = runs[t];
+    encode(rec & 1023u, (int)((rec >> 10) & 15u), (int)((rec >> 14) & 15u) + 1, (int)(rec >> 18));
+  }
+  {
+    const int nl_long = *n_long;
+    for (int i = 0; i < nl_long; ++i) {                      // (uniform) the workgroup walks the chunks of a long line
+      const uint2 ll = longs[i];
+      const int s = (int)(ll.x & 0xffffu), e = (int)(ll.x >> 16), rank = (int)ll.y;
+      const int c0 = s >> 4, nch = ((e - 1) >> 4) - c0 + 1;
+      for (int q = rtid; q < nch; q += BNPK_BLOCK) {
+        const int lo = q == 0 ? s & 15 : 0, hi = min(e - ((c0 + q) << 4), FQ_VEC);
+        encode((unsigned)(c0 + q), lo, hi - lo, rank + (q == 0 ? 0 : ((c0 + q) << 4) - s));
+      }
+    }
+  }
+  if (bad != (unsigned long long)BNPK_NONE) atomicMin(&err[2], bad);
+  __syncthreads();
+  const int n_words = (off32 + S + 31) / 32;
+  const int64_t word0 = fbase >> 5;
+  for (int w = tid; w < n_words; w += BNPK_BLOCK) {
+    const unsigned long long word = (unsigned long long)stage[2 * w] | ((unsigned long long)stage[2 * w + 1] << 32);
+    const bool edge = (w == 0 && off32 != 0) || (w == n_words - 1 && ((off32 + S) & 31) != 0);
+    if (edge) { if (word) atomicOr(&packed[word0 + w], word); }
+    else packed[word0 + w] = word;
+  }
+  }
 }
 
 // ---- k-mer start mask from the read-end mask --------------------------------------------------------------------------
@@ -531,10 +841,27 @@ int bnpk_fastq_encode(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_
   const int64_t* flags = d_tile_table;
   const int64_t* recs = d_tile_table + 8;
   const int64_t* seq_base = recs + tiles * FQ_TREC + tiles + 1;
-  hipLaunchKernelGGL(fq_encode_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry, seq_line,
-                     header, check_plus, flags, recs, seq_base, n_lines_used,
-                     reinterpret_cast<unsigned long long*>(d_packed), reinterpret_cast<unsigned long long*>(d_row_ends),
-                     reinterpret_cast<unsigned long long*>(d_err3));
+  unsigned long long* packed = reinterpret_cast<unsigned long long*>(d_packed);
+  unsigned long long* ends = reinterpret_cast<unsigned long long*>(d_row_ends);
+  unsigned long long* err = reinterpret_cast<unsigned long long*>(d_err3);
+  if (ctx->fastq_encoder == 0) {
+    hipLaunchKernelGGL((fq_encode_kernel<false>), dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                       seq_line, header, check_plus, flags, recs, seq_base, n_lines_used, packed, ends, err,
+                       (const unsigned*)nullptr);
+  } else {
+    // the fast kernel, then the general one over the tiles it handed back (usually none: the grid finds an empty list)
+    void* scratch = nullptr;
+    BNPK_CHECK(bnpk_scratch(ctx, (size_t)(tiles + 1) * 4 + 64, &scratch, s));
+    unsigned* redo = (unsigned*)scratch;
+    BNPK_HIP(ctx, hipMemsetAsync(redo, 0, 4, s));
+    static const int wg_per_cu = getenv("BNPK_FQ_WG") ? atoi(getenv("BNPK_FQ_WG")) : FQ2_WG_PER_CU;      // (experiments)
+    const unsigned fast_grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * wg_per_cu);
+    hipLaunchKernelGGL(fq_encode_fast_kernel, dim3(fast_grid), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                       seq_line, header, check_plus, flags, recs, seq_base, n_lines_used, tiles, packed, ends, err, redo);
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * 8);
+    hipLaunchKernelGGL((fq_encode_kernel<true>), dim3(grid), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry, seq_line,
+                       header, check_plus, flags, recs, seq_base, n_lines_used, packed, ends, err, (const unsigned*)redo);
+  }
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -429,7 +429,18 @@ def test_join_lines(ops, seed, n_rows, max_len):
     assert np.array_equal(got, expect)
 
 
-def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
+@pytest.fixture(params=[1, 0], ids=["fast-encoder", "general-encoder"])
+def encoder(request):
+    """both tile encoders of bnpk_fastq_encode (fastq.hip): the fast one (default; hands tiles with very short lines
+    to the general one) and the general one alone"""
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import Device
+    assert lib.bnpk_set_option(Device.get().ctx, b"fastq_encoder", request.param) == 0
+    yield request.param
+    assert lib.bnpk_set_option(Device.get().ctx, b"fastq_encoder", 1) == 0
+
+
+def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True, min_len=0, name=b"@r%d some text"):
     """FASTQ text with ragged read lengths (including empty reads), optional CRLF line ends and a trailing
     incomplete entry"""
     rng = np.random.default_rng(seed)
@@ -437,9 +448,9 @@ def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     eol = b"\r\n" if crlf else b"\n"
     parts = []
     for i in range(n_reads):
-        ln = int(rng.integers(0, max_len))
+        ln = int(rng.integers(min_len, max_len))
         seq = rng.choice(alphabet, size=ln).tobytes()
-        parts.append(b"@r%d some text" % i + eol + seq + eol + b"+" + eol + b"I" * ln + eol)
+        parts.append((name % i if b"%" in name else name) + eol + seq + eol + b"+" + eol + b"I" * ln + eol)
     return np.frombuffer(b"".join(parts) + tail, dtype=np.uint8).copy()
 
 
@@ -447,7 +458,7 @@ def _ragged_fastq(seed, n_reads, max_len, crlf=False, tail=b"", lower=True):
     (1, 1, 10, False, b""), (2, 7, 40, False, b"@partial\nACG"), (3, 3000, 300, False, b""),
     (4, 3000, 300, True, b""), (5, 40, 60_000, False, b"@x\nAC\n+\n"), (6, 50_000, 120, False, b""),
     (7, 2000, 3, False, b""), (8, 5000, 200, True, b"@t\r\nACGT\r\n")])
-def test_fused_fastq_encode_matches_the_unfused_path(ops, seed, n_reads, max_len, crlf, tail):
+def test_fused_fastq_encode_matches_the_unfused_path(ops, encoder, seed, n_reads, max_len, crlf, tail):
     """bnpk_fastq_census + bnpk_fastq_encode + bnpk_kmer_starts_from_ends == scan + validate + field table +
     gather/encode + start mask of the unfused kernels == the oracle (tile-straddling reads, empty reads, CRLF,
     trailing incomplete entry)"""
@@ -472,7 +483,29 @@ def test_fused_fastq_encode_matches_the_unfused_path(ops, seed, n_reads, max_len
         assert n_kmers == int(np.maximum(lens - k + 1, 0).sum())
 
 
-def test_fused_fastq_encode_raises_like_the_reference(ops):
+@pytest.mark.parametrize("seed,n_reads,min_len,max_len,crlf,name", [
+    (21, 20_000, 12, 20, False, b"@a"), (22, 20_000, 14, 18, True, b"@a"), (23, 30_000, 0, 9, False, b"@"),
+    (24, 8000, 30, 40, False, b"@read%d"), (25, 4000, 149, 152, True, b"@SRR0000000.%d length=150"),
+    (26, 60_000, 15, 17, False, b"@q"), (27, 3000, 0, 2, True, b"@")])
+def test_fused_fastq_encode_line_lengths_around_a_chunk(ops, encoder, seed, n_reads, min_len, max_len, crlf, name):
+    """lines about as long as the sixteen bytes a lane owns: the fast encoder's queues and line table fill up and
+    tiles move to the general encoder mid-file; the packed bases and read ends stay the oracle's"""
+    text = _ragged_fastq(seed, n_reads, max_len, crlf, b"", min_len=min_len, name=name)
+    res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    codes = oracle.encode_dna(oracle.gather_rows(text, starts, lens))
+    packed, ends, n_records, n_bases = ops.fastq_encode(_h(text), text.size, 4, 1, ord("@"), True)
+    assert n_records == res.n_records and n_bases == codes.size
+    words = oracle.pack_2bit(codes)
+    got = packed.host().view(np.uint64)
+    assert np.array_equal(got[:words.size], words) and not got[words.size:].any()
+    flags = np.unpackbits(ends.host().view(np.uint8), bitorder="little")
+    expect = np.zeros(flags.size, dtype=np.uint8)
+    expect[np.cumsum(lens)[lens > 0] - 1] = 1
+    assert np.array_equal(flags, expect)
+
+
+def test_fused_fastq_encode_raises_like_the_reference(ops, encoder):
     from bionumpy_amd.exceptions import FormatException, EncodingError, IncompleteEntryException
     good = _ragged_fastq(11, 500, 100)
     with pytest.raises(IncompleteEntryException):
