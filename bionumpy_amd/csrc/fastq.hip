@@ -16,8 +16,6 @@
 // io/fastq_buffer.py:39-45), _get_buffer_extractor + get_field_by_number(1) (io/one_line_buffer.py:140-152,
 // io/file_buffers.py:315-338), EncodedRaggedArray.ravel() + AlphabetEncoding._encode (encodings/alphabet_encoding.py:19-46),
 // BitArray.pack (sequence/kmers.py:121) and the ragged trim [..., :-(k-1)] (sequence/kmers.py:100).
-#include <stdlib.h>
-
 #include <algorithm>
 
 #include "common.h"
@@ -27,7 +25,7 @@ namespace {
 
 constexpr int FQ_VEC = 16;                                   // bytes per lane per load
 constexpr int FQ_WAVE_BYTES = BNPK_WAVE * FQ_VEC;            // 1 KiB per wavefront-instruction
-constexpr int FQ_ITERS = 4;
+constexpr int FQ_ITERS = 4;                                  // (2 = 8 KiB tiles was measured: 1.6x slower, the per-tile costs double)
 constexpr int FQ_WAVES = BNPK_BLOCK / BNPK_WAVE;
 constexpr int FQ_TILE = FQ_WAVES * FQ_ITERS * FQ_WAVE_BYTES; // 16 KiB per workgroup
 constexpr int FQ_MAXLPE = 4;
@@ -130,15 +128,23 @@ __device__ __forceinline__ void fq_tile_prefix(const int v[FQ_ITERS], int ex[FQ_
 
 // The same prefix for counts of at most 16 per chunk (newlines): two chunks share a 32-bit scan, 16 bits each.
 __device__ __forceinline__ void fq_tile_prefix16(const int v[FQ_ITERS], int ex[FQ_ITERS], int* smem, int* total) {
-  static_assert(FQ_ITERS == 4, "two packed scans");
-  const unsigned a = (unsigned)v[0] | ((unsigned)v[1] << 16), b = (unsigned)v[2] | ((unsigned)v[3] << 16);
-  const unsigned ia = wave_inclusive_scan(a), ib = wave_inclusive_scan(b);
-  const unsigned ta = (unsigned)__builtin_amdgcn_readlane((int)ia, 63), tb = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
-  const int t0 = (int)(ta & 0xffffu), t1 = (int)(ta >> 16), t2 = (int)(tb & 0xffffu), t3 = (int)(tb >> 16);
+  static_assert(FQ_ITERS == 4 || FQ_ITERS == 2, "packed scans");
+  const unsigned a = (unsigned)v[0] | ((unsigned)v[1] << 16);
+  const unsigned ia = wave_inclusive_scan(a);
+  const unsigned ta = (unsigned)__builtin_amdgcn_readlane((int)ia, 63);
+  const int t0 = (int)(ta & 0xffffu), t1 = (int)(ta >> 16);
+  int t2 = 0, t3 = 0;
   ex[0] = (int)(ia & 0xffffu) - v[0];
   ex[1] = t0 + (int)(ia >> 16) - v[1];
-  ex[2] = t0 + t1 + (int)(ib & 0xffffu) - v[2];
-  ex[3] = t0 + t1 + t2 + (int)(ib >> 16) - v[3];
+  if (FQ_ITERS == 4) {
+    const unsigned b = (unsigned)v[FQ_ITERS - 2] | ((unsigned)v[FQ_ITERS - 1] << 16);
+    const unsigned ib = wave_inclusive_scan(b);
+    const unsigned tb = (unsigned)__builtin_amdgcn_readlane((int)ib, 63);
+    t2 = (int)(tb & 0xffffu);
+    t3 = (int)(tb >> 16);
+    ex[FQ_ITERS - 2] = t0 + t1 + (int)(ib & 0xffffu) - v[FQ_ITERS - 2];
+    ex[FQ_ITERS - 1] = t0 + t1 + t2 + (int)(ib >> 16) - v[FQ_ITERS - 1];
+  }
   __syncthreads();                                           // smem may still be read from a previous call
   if (lane_id() == 0) smem[wave_id()] = t0 + t1 + t2 + t3;
   __syncthreads();
@@ -180,37 +186,45 @@ __device__ __forceinline__ void fq_count_phases(const fq_chunk& c, int line, int
 }
 
 // ---- census --------------------------------------------------------------------------------------------------------
+// The general census: LIST = false: tile = blockIdx.x; LIST = true: the tiles the fast census below handed back.
+template <bool LIST>
 __global__ __launch_bounds__(BNPK_BLOCK) void fq_census_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
                                                                const int64_t* __restrict__ flags,
                                                                int64_t* __restrict__ recs,
-                                                               int64_t* __restrict__ newlines) {
+                                                               int64_t* __restrict__ newlines,
+                                                               const unsigned* __restrict__ redo) {
   __shared__ int smem[FQ_WAVES];
   __shared__ int acc[FQ_MAXLPE];
   const int strip_cr = (int)flags[0];
-  const int64_t tile_base = (int64_t)blockIdx.x * FQ_TILE;
-  if (threadIdx.x < FQ_MAXLPE) acc[threadIdx.x] = 0;
-  fq_chunk c[FQ_ITERS];
-  int nls[FQ_ITERS], line[FQ_ITERS], total;
+  const unsigned n_list = LIST ? redo[0] : 1u;
+  for (unsigned item = LIST ? blockIdx.x : 0u; item < n_list; item += LIST ? gridDim.x : 1u) {
+    const int64_t tile = LIST ? (int64_t)redo[1 + item] : (int64_t)blockIdx.x;
+    const int64_t tile_base = tile * FQ_TILE;
+    if (LIST) __syncthreads();
+    if (threadIdx.x < FQ_MAXLPE) acc[threadIdx.x] = 0;
+    fq_chunk c[FQ_ITERS];
+    int nls[FQ_ITERS], line[FQ_ITERS], total;
 #pragma unroll
-  for (int it = 0; it < FQ_ITERS; ++it) {
-    c[it] = fq_load(buf, fq_chunk_pos(tile_base, it), n, strip_cr);
-    nls[it] = __popc(c[it].nl);
-  }
-  fq_tile_prefix(nls, line, smem, &total);
-  int cnt[FQ_MAXLPE] = {0, 0, 0, 0};
+    for (int it = 0; it < FQ_ITERS; ++it) {
+      c[it] = fq_load(buf, fq_chunk_pos(tile_base, it), n, strip_cr);
+      nls[it] = __popc(c[it].nl);
+    }
+    fq_tile_prefix(nls, line, smem, &total);
+    int cnt[FQ_MAXLPE] = {0, 0, 0, 0};
 #pragma unroll
-  for (int it = 0; it < FQ_ITERS; ++it) fq_count_phases(c[it], line[it], lpe, cnt);
+    for (int it = 0; it < FQ_ITERS; ++it) fq_count_phases(c[it], line[it], lpe, cnt);
 #pragma unroll
-  for (int p = 0; p < FQ_MAXLPE; ++p) {
-    const int s = (int)wave_sum((unsigned)cnt[p]);
-    if (lane_id() == 0 && s) atomicAdd(&acc[p], s);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int64_t* r = recs + (int64_t)blockIdx.x * FQ_TREC;
-    newlines[blockIdx.x] = total;
+    for (int p = 0; p < FQ_MAXLPE; ++p) {
+      const int s = (int)wave_sum((unsigned)cnt[p]);
+      if (lane_id() == 0 && s) atomicAdd(&acc[p], s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int64_t* r = recs + tile * FQ_TREC;
+      newlines[tile] = total;
 #pragma unroll
-    for (int p = 0; p < FQ_MAXLPE; ++p) r[1 + p] = acc[p];
+      for (int p = 0; p < FQ_MAXLPE; ++p) r[1 + p] = acc[p];
+    }
   }
 }
 
@@ -484,12 +498,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void fq_encode_kernel(const uint8_t* __
 // Tiles with more than FQ2_NLMAX newlines or more records than the queue holds (lines shorter than ~20 bytes) and the
 // last tile of the text are handed to the general kernel through a list; the results are the same bits either way
 // (tests/test_gpu_parity.py runs both).
-constexpr int FQ2_NLMAX = 640;                               // lines 0 .. FQ2_NLMAX of a tile have a table entry
-constexpr int FQ2_QCAP = 640;                                // records of lines of at most FQ2_SHORT chunks
+constexpr int FQ2_NLMAX = 160 * FQ_ITERS;                               // lines 0 .. FQ2_NLMAX of a tile have a table entry
+constexpr int FQ2_QCAP = 160 * FQ_ITERS;                                // records of lines of at most FQ2_SHORT chunks
 constexpr int FQ2_SHORT = 16;
 constexpr int FQ2_LONGMAX = FQ_TILE / (FQ2_SHORT * FQ_VEC - FQ_VEC) + 2;      // lines touching more than FQ2_SHORT chunks
 constexpr int FQ2_CHUNKS = FQ_TILE / FQ_VEC;                 // 1024
-constexpr int FQ2_WG_PER_CU = 6;                             // resident workgroups per CU the fast kernel is built for (LDS and registers)
+constexpr int FQ2_WG_PER_CU = FQ_ITERS == 4 ? 6 : 8;                             // resident workgroups per CU the fast kernel is built for (LDS and registers)
 
 // four text bytes -> four codes (low two bits of every byte); *z != 0 in every byte that is not one of ACGTacgt
 __device__ __forceinline__ uint32_t fq_codes4(uint32_t w, uint32_t* z) {
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(BNPK_BLOCK, FQ2_WG_PER_CU) void fq_encode_fast_kern
   // one block of LDS carved by hand: six workgroups per CU is a budget of 27306 bytes
   constexpr int OFF_STAGE = FQ2_CHUNKS * 16, OFF_LTAB = OFF_STAGE + FQ_SWORDS * 4, OFF_RUNS = OFF_LTAB + (FQ2_NLMAX + 2) * 4;
   constexpr int OFF_LONG = OFF_RUNS + FQ2_QCAP * 4, OFF_SMEM = OFF_LONG + FQ2_LONGMAX * 8, LDS_BYTES = OFF_SMEM + 48;
-  static_assert(OFF_STAGE % 16 == 0 && OFF_LTAB % 4 == 0 && OFF_LONG % 8 == 0 && LDS_BYTES * 6 <= 160 * 1024, "LDS layout");
+  static_assert(OFF_STAGE % 16 == 0 && OFF_LTAB % 4 == 0 && OFF_LONG % 8 == 0 && LDS_BYTES * FQ2_WG_PER_CU <= 160 * 1024, "LDS layout");
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
   u32x4* text = reinterpret_cast<u32x4*>(lds);               // the tile, chunk c = bytes [16c, 16c + 16)
   unsigned* stage = reinterpret_cast<unsigned*>(lds + OFF_STAGE);
@@ -736,6 +750,98 @@ __global__ __launch_bounds__(BNPK_BLOCK, FQ2_WG_PER_CU) void fq_encode_fast_kern
   }
 }
 
+// ---- census, the fast kernel ---------------------------------------------------------------------------------------------
+// The same split for the census: newline masks and line starts per byte of text, the payload of every line (and so of
+// every line phase, relative to the tile's first line) per line.  Nothing but the newline masks is computed per byte, the
+// text stays in registers, and the workgroups are persistent with the next tile in flight.
+constexpr int FQC_WG_PER_CU = 8;
+
+__global__ __launch_bounds__(BNPK_BLOCK, FQC_WG_PER_CU) void fq_census_fast_kernel(const uint8_t* __restrict__ buf, int64_t n, int lpe,
+                                                                                    const int64_t* __restrict__ flags,
+                                                                                    int64_t* __restrict__ recs,
+                                                                                    int64_t* __restrict__ newlines, int64_t tiles,
+                                                                                    unsigned* __restrict__ redo) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ unsigned short lstart[FQ2_NLMAX + 2];           // line l of the tile starts at byte lstart[l]
+  __shared__ int smem[FQ_WAVES + 4];
+  __shared__ int acc[FQ_MAXLPE];
+  const int tid = threadIdx.x;
+  const int strip_cr = (int)flags[0];
+  const int inv_lpe = (65536 + lpe - 1) / lpe;
+  const unsigned chunk0 = (unsigned)wave_id() * (FQ_ITERS * BNPK_WAVE) + lane_id();
+  const int64_t full_tiles = n >= FQ_TILE + 16 ? (n - 16) / FQ_TILE : 0;
+  if (blockIdx.x == 0 && tid == 0)
+    for (int64_t t = full_tiles; t < tiles; ++t) redo[1 + atomicAdd(&redo[0], 1u)] = (unsigned)t;
+  u32x4 pre[FQ_ITERS];
+  uint32_t pre_after = 0;
+  auto request = [&](int64_t t) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(buf + t * FQ_TILE) + chunk0;
+#pragma unroll
+    for (int it = 0; it < FQ_ITERS; ++it) pre[it] = __builtin_nontemporal_load(src + it * BNPK_WAVE);
+    if (strip_cr) pre_after = buf[(t + 1) * FQ_TILE + (lane_id() & 1)];
+  };
+  if ((int64_t)blockIdx.x < full_tiles) request(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < full_tiles; tile += gridDim.x) {
+    const int64_t tile_base = tile * FQ_TILE;
+    const uint32_t after0 = (uint32_t)__builtin_amdgcn_readlane((int)pre_after, 0);
+    __syncthreads();                                         // the previous tile's table and sums have been read
+    if (tid < FQ_MAXLPE) acc[tid] = 0;
+    if (tid == 0) lstart[0] = 0;
+    uint32_t nlm[FQ_ITERS];
+    int nls[FQ_ITERS], line[FQ_ITERS], L;
+#pragma unroll
+    for (int it = 0; it < FQ_ITERS; ++it) {
+      const u32x4 v = pre[it];
+      nlm[it] = ~fq_nomatch16((uint64_t)v.x | ((uint64_t)v.y << 32), (uint64_t)v.z | ((uint64_t)v.w << 32), 0x01010101u * FQ_NL) & 0xffffu;
+      nls[it] = __popc(nlm[it]);
+    }
+    if (tile + gridDim.x < full_tiles) request(tile + gridDim.x);
+    fq_tile_prefix16(nls, line, smem, &L);
+    if (L > FQ2_NLMAX) {                                     // (uniform)
+      if (tid == 0) redo[1 + atomicAdd(&redo[0], 1u)] = (unsigned)tile;
+      continue;
+    }
+#pragma unroll
+    for (int it = 0; it < FQ_ITERS; ++it) {
+      uint32_t nl = nlm[it];
+      int ln = line[it];
+      const unsigned at = (chunk0 + it * BNPK_WAVE) * FQ_VEC;
+      while (__ballot(nl != 0) != 0ull) {
+        if (nl) {
+          ++ln;
+          lstart[ln] = (unsigned short)(at + __ffs(nl));
+          nl &= nl - 1;
+        }
+      }
+    }
+    __syncthreads();
+    int cnt[FQ_MAXLPE] = {0, 0, 0, 0};
+    for (int base = 0; base <= L; base += BNPK_BLOCK) {
+      const int l = base + tid;
+      if (l <= L) {
+        const int s = lstart[l];
+        int e = l < L ? (int)lstart[l + 1] - 1 : FQ_TILE;
+        if (strip_cr && e > s && buf[tile_base + e - 1] == FQ_CR && (l < L || after0 == FQ_NL)) --e;
+        const int ph = fq_mod_tiny(l, lpe, inv_lpe);
+#pragma unroll
+        for (int p = 0; p < FQ_MAXLPE; ++p) cnt[p] += p == ph ? e - s : 0;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < FQ_MAXLPE; ++p) {
+      const int sum = (int)wave_sum((unsigned)cnt[p]);
+      if (lane_id() == 0 && sum) atomicAdd(&acc[p], sum);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int64_t* r = recs + tile * FQ_TREC;
+      newlines[tile] = L;
+#pragma unroll
+      for (int p = 0; p < FQ_MAXLPE; ++p) r[1 + p] = acc[p];
+    }
+  }
+}
+
 // ---- k-mer start mask from the read-end mask --------------------------------------------------------------------------
 __global__ __launch_bounds__(BNPK_BLOCK) void fq_starts_kernel(const unsigned long long* __restrict__ ends,
                                                                int64_t n_bases, int k,
@@ -791,13 +897,25 @@ int bnpk_fastq_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_
   int64_t* line_base = recs + tiles * FQ_TREC;
   int64_t* seq_base = line_base + tiles + 1;
   void* scratch = nullptr;
-  BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(tiles), &scratch, (hipStream_t)stream));
+  const size_t scan_bytes = (bnpk_scan_scratch_bytes(tiles) + 63) & ~(size_t)63;
+  BNPK_CHECK(bnpk_scratch(ctx, scan_bytes + (size_t)(tiles + 1) * 4 + 64, &scratch, (hipStream_t)stream));
   int64_t* scan_scratch = (int64_t*)scratch;
+  unsigned* redo = (unsigned*)((char*)scratch + scan_bytes);
   {
     bnpk_timer t(ctx, "fastq_census", s);
     hipLaunchKernelGGL(fq_detect_cr_kernel, dim3(1), dim3(64), 0, s, d_buf, n, lines_per_entry, flags);
-    hipLaunchKernelGGL(fq_census_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
-                       (const int64_t*)flags, recs, line_base);
+    if (ctx->fastq_encoder == 0) {
+      hipLaunchKernelGGL((fq_census_kernel<false>), dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                         (const int64_t*)flags, recs, line_base, (const unsigned*)nullptr);
+    } else {                                                 // the fast census, then the general one over the tiles it handed back
+      BNPK_HIP(ctx, hipMemsetAsync(redo, 0, 4, s));
+      const unsigned fast_grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * FQC_WG_PER_CU);
+      hipLaunchKernelGGL(fq_census_fast_kernel, dim3(fast_grid), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                         (const int64_t*)flags, recs, line_base, tiles, redo);
+      const unsigned grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * 8);
+      hipLaunchKernelGGL((fq_census_kernel<true>), dim3(grid), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
+                         (const int64_t*)flags, recs, line_base, (const unsigned*)redo);
+    }
     BNPK_HIP(ctx, hipGetLastError());
     BNPK_CHECK(bnpk_scan_launch(ctx, line_base, tiles, 1, line_base, true, scan_scratch, s));      // newline counts -> first lines
     hipLaunchKernelGGL(fq_select_kernel, dim3(grid_for(ceil_div(tiles, 256))), dim3(256), 0, s, d_buf, n, lines_per_entry,
@@ -854,8 +972,7 @@ int bnpk_fastq_encode(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, int lines_
     BNPK_CHECK(bnpk_scratch(ctx, (size_t)(tiles + 1) * 4 + 64, &scratch, s));
     unsigned* redo = (unsigned*)scratch;
     BNPK_HIP(ctx, hipMemsetAsync(redo, 0, 4, s));
-    static const int wg_per_cu = getenv("BNPK_FQ_WG") ? atoi(getenv("BNPK_FQ_WG")) : FQ2_WG_PER_CU;      // (experiments)
-    const unsigned fast_grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * wg_per_cu);
+    const unsigned fast_grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * FQ2_WG_PER_CU);
     hipLaunchKernelGGL(fq_encode_fast_kernel, dim3(fast_grid), dim3(BNPK_BLOCK), 0, s, d_buf, n, lines_per_entry,
                        seq_line, header, check_plus, flags, recs, seq_base, n_lines_used, tiles, packed, ends, err, redo);
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, (int64_t)ctx->compute_units * 8);
