@@ -199,13 +199,17 @@ struct kmer_source {
     }
     const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
     const int64_t end = min(t0 + (int64_t)RP_TILE, hi);
-    if (o >= end) return 0;
+    if (o >= end) {                                          // (the caller adds zeros: spread them over the bins, not all on bin 0)
+#pragma unroll
+      for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (threadIdx.x + q) & dmask;
+      return 0;
+    }
     unsigned valid = raw.v;
     if (end - o < RP_MAXITEMS) valid &= (1u << (int)(end - o)) - 1u;
-    if (valid == 0) return 0;
-    const uint64_t win = window(raw, 2 * (int)(o & 31) + shift);       // (< 128: shift <= 2k - bits <= 61)
+    // the eight digits lie in the low 2 * 7 + 11 = 25 bits of the window: 32-bit field extracts, no 64-bit shifts
+    const unsigned win = (unsigned)window(raw, 2 * (int)(o & 31) + shift);       // (< 128: shift <= 2k - bits <= 61)
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(win >> (2 * q)) & dmask;
+    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (win >> (2 * q)) & dmask;
     return valid;
   }
 };
@@ -228,12 +232,119 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
   src.issue(sl.lo, sl.hi, raw);
   for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += RP_TILE) {
     if (t0 + RP_TILE < sl.hi) src.issue(t0 + RP_TILE, sl.hi, raw_next);      // one tile ahead
-    unsigned d[RP_MAXITEMS];
+    unsigned d[RP_MAXITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned vm = src.digits(t0, sl.hi, raw, shift, (unsigned)(B - 1), d);
+    // branch-free: a position where no k-mer starts adds zero (one field extract instead of an exec-mask round trip per key)
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q)
-      if ((vm >> q) & 1u) atomicAdd(&h[d[q]], 1u);
+    for (int q = 0; q < RP_MAXITEMS; ++q) atomicAdd(&h[d[q]], (vm >> q) & 1u);
     raw = raw_next;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) H[sl.hbase + (int64_t)c * sl.nsl + sl.local] = h[c];
+}
+
+// The level-1 counts of plain (not canonical) k-mer hashes.  Bits [shift, shift + bits) of the k-mer at base p are bits
+// [2p + shift, ..) of the packed stream, so a lane's eight digits lie in the 25 bits behind bit 2 * o + shift of it: two
+// 32-bit words, one V_ALIGNBIT, one field extract per digit.  The bit offset inside the word is the same in every round (a
+// round advances all lanes by 16384 bits), the addresses are a scalar base plus a per-lane offset, and positions where no
+// k-mer starts add zero instead of being branched around: ~4 vector instructions per k-mer, where the generic kernel
+// above (64-bit indices, three words, a 64-bit funnel shift) spent 15 and was bound by them.
+__global__ __launch_bounds__(RP_THREADS) void rp_hist_kmer_kernel(const uint32_t* __restrict__ W32, const uint8_t* __restrict__ V,
+                                                                  const int64_t* __restrict__ seg_off, const int64_t* __restrict__ seg_slabs,
+                                                                  int64_t n_seg, int64_t slab_keys, int shift, int bits,
+                                                                  int64_t* __restrict__ H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* h = reinterpret_cast<unsigned*>(smem);
+  int64_t* sh = reinterpret_cast<int64_t*>(smem + (size_t)RP_HIST_BINS * 4);
+  const int B = 1 << bits;
+  const unsigned dmask = (unsigned)(B - 1);
+  slab_t sl;
+  if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) h[c] = 0;
+  __syncthreads();
+  // slab-relative 32-bit arithmetic: position r = round * RP_TILE + 8 * tid of [0, len)
+  const unsigned len = (unsigned)(sl.hi - sl.lo);
+  const int64_t bit0 = 2 * (sl.lo + (int64_t)threadIdx.x * RP_MAXITEMS) + shift;        // of this lane's round-0 window
+  const uint32_t* wp = W32 + (bit0 >> 5);
+  const uint8_t* vp = V + ((sl.lo >> 3) + threadIdx.x);
+  const unsigned sh5 = (unsigned)(bit0 & 31);
+  constexpr unsigned W_STEP = RP_TILE * 2 / 32, V_STEP = RP_TILE / 8;                       // per round: words of the stream, bytes of the mask
+  unsigned r = threadIdx.x * RP_MAXITEMS;
+  uint2 w = make_uint2(0, 0);
+  unsigned v = 0;
+  if (r < len) {
+    w = *reinterpret_cast<const uint2*>(wp);
+    v = *vp;
+  }
+  while (r < len) {                                          // (per lane; a lane that ran out just waits at the barrier below)
+    const uint2 w_cur = w;
+    unsigned valid = v;
+    const unsigned r_next = r + RP_TILE;
+    wp += W_STEP;
+    vp += V_STEP;
+    if (r_next < len) {                                      // one round ahead
+      w = *reinterpret_cast<const uint2*>(wp);
+      v = *vp;
+    }
+    if (len - r < RP_MAXITEMS) valid &= (1u << (len - r)) - 1u;
+    const unsigned win = __builtin_amdgcn_alignbit(w_cur.y, w_cur.x, sh5);
+#pragma unroll
+    for (int q = 0; q < RP_MAXITEMS; ++q) atomicAdd(&h[(win >> (2 * q)) & dmask], (valid >> q) & 1u);
+    r = r_next;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) H[sl.hbase + (int64_t)c * sl.nsl + sl.local] = h[c];
+}
+
+// The same counts for keys that lie in memory, with 16-byte loads (two keys per lane and request: the 8-byte version reads
+// at 5.5 TB/s, this one nearer the rate a pure read stream reaches) and the next tile's requests in flight while the
+// current tile is counted.  A slab that starts or ends on an odd key has that key counted by lane 0.
+__global__ __launch_bounds__(RP_THREADS) void rp_hist_mem_kernel(const uint64_t* __restrict__ keys, const int64_t* __restrict__ seg_off,
+                                                                 const int64_t* __restrict__ seg_slabs, int64_t n_seg,
+                                                                 int64_t slab_keys, int shift, int bits, int64_t* __restrict__ H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* h = reinterpret_cast<unsigned*>(smem);
+  int64_t* sh = reinterpret_cast<int64_t*>(smem + (size_t)RP_HIST_BINS * 4);
+  const int B = 1 << bits;
+  const unsigned dmask = (unsigned)(B - 1);
+  slab_t sl;
+  if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
+  for (int c = threadIdx.x; c < B; c += RP_THREADS) h[c] = 0;
+  __syncthreads();
+  int64_t lo = sl.lo, hi = sl.hi;
+  if (lo < hi && (lo & 1)) {
+    if (threadIdx.x == 0) atomicAdd(&h[(unsigned)(keys[lo] >> shift) & dmask], 1u);
+    ++lo;
+  }
+  if (lo < hi && ((hi - lo) & 1)) {
+    --hi;
+    if (threadIdx.x == 0) atomicAdd(&h[(unsigned)(keys[hi] >> shift) & dmask], 1u);
+  }
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* pairs = reinterpret_cast<const u64x2*>(keys + lo);
+  const int64_t n_pairs = (hi - lo) >> 1;
+  constexpr int PER = RP_MAXITEMS / 2;                       // pairs per lane and tile
+  u64x2 cur[PER], nxt[PER];
+  auto issue = [&](int64_t base, u64x2 v[PER]) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int64_t i = base + threadIdx.x + (int64_t)q * RP_THREADS;
+      if (i < n_pairs) v[q] = __builtin_nontemporal_load(pairs + i);
+    }
+  };
+  issue(0, cur);
+  for (int64_t base = 0; base < n_pairs; base += (int64_t)PER * RP_THREADS) {
+    if (base + (int64_t)PER * RP_THREADS < n_pairs) issue(base + (int64_t)PER * RP_THREADS, nxt);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int64_t i = base + threadIdx.x + (int64_t)q * RP_THREADS;
+      if (i < n_pairs) {
+        atomicAdd(&h[(unsigned)(cur[q].x >> shift) & dmask], 1u);
+        atomicAdd(&h[(unsigned)(cur[q].y >> shift) & dmask], 1u);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) cur[q] = nxt[q];
   }
   __syncthreads();
   for (int c = threadIdx.x; c < B; c += RP_THREADS) H[sl.hbase + (int64_t)c * sl.nsl + sl.local] = h[c];
@@ -536,8 +647,16 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
     bnpk_timer t(ctx, hist_name, s);
     hipLaunchKernelGGL(rp_slab_table_kernel, dim3(1), dim3(RP_THREADS), 0, s, d_seg_off, n_seg, slab_keys, seg_slabs);
     BNPK_HIP(ctx, hipMemsetAsync(H, 0, (size_t)(hn + 1) * 8, s));
-    hipLaunchKernelGGL((rp_hist_kernel<Source>), dim3((unsigned)bound), dim3(RP_THREADS), RP_HIST_LDS, s, src, d_seg_off,
-                       (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, H);
+    if constexpr (std::is_same<Source, kmer_source<false>>::value)
+      hipLaunchKernelGGL(rp_hist_kmer_kernel, dim3((unsigned)bound), dim3(RP_THREADS), RP_HIST_LDS, s,
+                         reinterpret_cast<const uint32_t*>(src.W), src.V, d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys,
+                         shift, bits, H);
+    else if constexpr (std::is_same<Source, mem_source>::value)
+      hipLaunchKernelGGL(rp_hist_mem_kernel, dim3((unsigned)bound), dim3(RP_THREADS), RP_HIST_LDS, s, src.keys, d_seg_off,
+                         (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, H);
+    else
+      hipLaunchKernelGGL((rp_hist_kernel<Source>), dim3((unsigned)bound), dim3(RP_THREADS), RP_HIST_LDS, s, src, d_seg_off,
+                         (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, H);
     BNPK_HIP(ctx, hipGetLastError());
     BNPK_CHECK(bnpk_scan_launch(ctx, H, hn, 1, H, true, scan_scratch, s));
     if (d_child_off)

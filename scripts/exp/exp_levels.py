@@ -25,3 +25,13 @@ for bits in (9, 10, 11):
     torch.cuda.synchronize()
     rep = dev.prof_report(); dev.prof_enable(False)
     print("level-2 style (1024 segments), %2d bits: " % bits + "  ".join("%s %.2f ms" % (k, v["total_ms"] / 2) for k, v in rep.items()), flush=True)
+# a 9-bit first level followed by an 11-bit second level (the other way to reach 20 bits)
+del a, off1
+a, off1 = ops.radix_partition(keys, None, 1, 53, 9)
+for bits in (10, 11):
+    dev.prof_enable(True); dev.prof_reset()
+    for _ in range(2):
+        o, child = ops.radix_partition(a, off1, 1 << 9, 53 - bits, bits, out)
+    torch.cuda.synchronize()
+    rep = dev.prof_report(); dev.prof_enable(False)
+    print("level-2 style (512 segments), %2d bits: " % bits + "  ".join("%s %.2f ms" % (k, v["total_ms"] / 2) for k, v in rep.items()), flush=True)
