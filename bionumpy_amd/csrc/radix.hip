@@ -20,37 +20,28 @@
 
 namespace {
 
-#ifndef RP_EXP_HALF
 constexpr int RP_THREADS = 1024;
 constexpr int RP_MAXBITS = 11;
 constexpr int RP_TILE = 8192;                         // new keys per round (at most)
-#else                                                 // (experiment: half-size workgroups, two per CU, digits <= 9 bits)
-constexpr int RP_THREADS = 512;
-constexpr int RP_MAXBITS = 9;
-constexpr int RP_TILE = 4096;
-#endif
 constexpr int RP_MAXITEMS = RP_TILE / RP_THREADS;     // 8
 constexpr uint64_t RP_PHANTOM = 1ull << 63;           // placeholder for the slots before a bucket's first key
 constexpr size_t RP_CACHE_BYTES = 0;                  // LDS scratch handed to the key sources (none needs it now)
 
-// Two shapes of the scatter kernel: digits up to 10 bits flush whole 128-byte lines (16 keys); 11-bit digits
-// (2048 buckets) flush 64-byte half lines, because the carried keys (< LINE per bucket) have to fit LDS.
-template <int LINE_>
+// Shapes of the scatter kernel: the flush granule LINE (keys) and the number of buckets MAXB the tables are sized for.
+//   <16, 1024>  whole 128-byte lines: what HBM rewards, for a level that is bound by its bytes (level 2: 96 GB)
+//   < 8, 1024>  64-byte granules: the fused level 1 writes half the bytes of level 2 in the same time — it is bound by
+//               its LDS rounds, not by HBM — and with 8-key granules a bucket carries 3.5 keys instead of 7.5 from
+//               round to round, which is a third of the round's LDS traffic (21.3 -> 19.5 ms per 6e9 k-mers; 32-byte
+//               granules: 47 ms, HBM does not take them; level 2 with 64-byte granules: 9.7 -> 12.7 ms per 3e9 keys)
+//   < 8, 2048>  11-bit digits: the carried keys (< LINE per bucket) of 2048 buckets have to fit LDS
+template <int LINE_, int MAXB_>
 struct rp_cfg {
   static constexpr int LINE = LINE_;
-  static constexpr int LOG_LINE = LINE_ == 16 ? 4 : 3;
-#ifndef RP_EXP_HALF
-  static constexpr int MAXB = LINE_ == 16 ? 1024 : 2048;
-#else
-  static constexpr int MAXB = LINE_ == 16 ? 512 : 1024;
-#endif
+  static constexpr int LOG_LINE = LINE_ == 16 ? 4 : LINE_ == 8 ? 3 : 2;
+  static constexpr int MAXB = MAXB_;
   static constexpr int NBT = MAXB / RP_THREADS;              // buckets owned by one lane
   static constexpr int CARRY = LINE_ - 1;                    // most keys a bucket carries into the next round
-#ifndef RP_EXP_HALF
-  static constexpr int STAGE = LINE_ == 16 ? 16384 : 15360;  // keys staged in LDS
-#else
-  static constexpr int STAGE = LINE_ == 16 ? 8192 : 7680;
-#endif
+  static constexpr int STAGE = MAXB_ == 1024 ? 16384 : 15360;  // keys staged in LDS
   // LDS carve-up (dynamic, 16-byte aligned pieces)
   static constexpr size_t OFF_META = (size_t)STAGE * 8;
   static constexpr size_t OFF_CNT = OFF_META + (size_t)MAXB * 8;
@@ -361,13 +352,13 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_mem_kernel(const uint64_t*
 //          offset, otherwise all slices start on LDS bank 0 and equal ranks collide 16-way
 //   flush  the FLUSH region leaves the CU as aligned 16-byte-per-lane stores (whole lines only); the CARRY region is
 //          read back into the owning lanes' registers
-template <typename Source, int LINE>
+template <typename Source, int LINE, int MAXB>
 __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, const int64_t* __restrict__ seg_off,
                                                                 const int64_t* __restrict__ seg_slabs, int64_t n_seg,
                                                                 int64_t slab_keys, int shift, int bits,
                                                                 const int64_t* __restrict__ offs,
                                                                 uint64_t* __restrict__ out) {
-  using C = rp_cfg<LINE>;
+  using C = rp_cfg<LINE, MAXB>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   uint64_t* meta = reinterpret_cast<uint64_t*>(smem + C::OFF_META);   // {flush start:16 | nfl:16 | carry start:16 | rem:16}
@@ -633,10 +624,15 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   bool* attr_set = ctx->launch_attr_set;
   constexpr int which = std::is_same<Source, mem_source>::value ? 0 : (std::is_same<Source, kmer_source<false>>::value ? 1 : 2);
   if (!attr_set[which]) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 16>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<16>::LDS));
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)rp_scatter_kernel<Source, 8>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<8>::LDS));
+    auto allow = [&](auto line_c, auto maxb_c) {
+      constexpr int L_ = decltype(line_c)::value, M_ = decltype(maxb_c)::value;
+      auto kernel = rp_scatter_kernel<Source, L_, M_>;
+      return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rp_cfg<L_, M_>::LDS);
+    };
+    using std::integral_constant;
+    BNPK_HIP(ctx, allow(integral_constant<int, 16>{}, integral_constant<int, 1024>{}));
+    BNPK_HIP(ctx, allow(integral_constant<int, 8>{}, integral_constant<int, 1024>{}));
+    BNPK_HIP(ctx, allow(integral_constant<int, 8>{}, integral_constant<int, 2048>{}));
     attr_set[which] = true;
   }
   if (!d_seg_off) {
@@ -664,14 +660,19 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
                          (const int64_t*)H, (const int64_t*)seg_slabs, n_seg, B, hn, d_child_off);
   }
   bnpk_timer t(ctx, scatter_name, s);
-  if (bits <= 10)
-    hipLaunchKernelGGL((rp_scatter_kernel<Source, 16>), dim3((unsigned)bound), dim3(RP_THREADS), rp_cfg<16>::LDS, s, src,
-                       d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, (const int64_t*)H,
-                       reinterpret_cast<uint64_t*>(d_out));
-  else
-    hipLaunchKernelGGL((rp_scatter_kernel<Source, 8>), dim3((unsigned)bound), dim3(RP_THREADS), rp_cfg<8>::LDS, s, src,
-                       d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys, shift, bits, (const int64_t*)H,
-                       reinterpret_cast<uint64_t*>(d_out));
+  // (the granule: 16 keys for levels that read their keys from memory, 8 for the fused first level — see rp_cfg)
+  constexpr int line = std::is_same<Source, mem_source>::value ? 16 : 8;
+  auto launch = [&](auto line_c, auto maxb_c) {
+    constexpr int L_ = decltype(line_c)::value, M_ = decltype(maxb_c)::value;
+    constexpr size_t lds = rp_cfg<L_, M_>::LDS;
+    auto kernel = rp_scatter_kernel<Source, L_, M_>;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)bound), dim3(RP_THREADS), lds, s, src, d_seg_off, (const int64_t*)seg_slabs, n_seg,
+                       slab_keys, shift, bits, (const int64_t*)H, reinterpret_cast<uint64_t*>(d_out));
+  };
+  using std::integral_constant;
+  if (bits > 10) launch(integral_constant<int, 8>{}, integral_constant<int, 2048>{});
+  else if (line == 16) launch(integral_constant<int, 16>{}, integral_constant<int, 1024>{});
+  else launch(integral_constant<int, 8>{}, integral_constant<int, 1024>{});
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
