@@ -22,8 +22,8 @@ namespace {
 
 constexpr int RP_THREADS = 1024;
 constexpr int RP_MAXBITS = 11;
-constexpr int RP_TILE = 8192;                         // new keys per round (at most)
-constexpr int RP_MAXITEMS = RP_TILE / RP_THREADS;     // 8
+constexpr int RP_SLAB_UNIT = 24576;                   // slabs are multiples of every source's tile (8 or 12 items per lane)
+constexpr int HK_ITEMS = 8, HK_TILE = HK_ITEMS * RP_THREADS;      // rp_hist_kmer_kernel: positions per lane and round
 constexpr uint64_t RP_PHANTOM = 1ull << 63;           // placeholder for the slots before a bucket's first key
 constexpr size_t RP_CACHE_BYTES = 0;                  // LDS scratch handed to the key sources (none needs it now)
 
@@ -92,25 +92,26 @@ __device__ __forceinline__ bool find_slab(const int64_t* __restrict__ seg_off, c
 }
 
 // ---- key sources ---------------------------------------------------------------------------------------------
-// A tile is the item range [t0, t0 + T) ∩ [.., hi), T = items * RP_THREADS <= RP_TILE.  issue() starts the global
-// loads of a whole RP_TILE-sized tile into registers (no use of the values, so nothing waits), finish() turns the
+// A tile is the item range [t0, t0 + T) ∩ [.., hi), T = items * RP_THREADS <= ITEMS * RP_THREADS.  issue() starts the global
+// loads of a whole full tile into registers (no use of the values, so nothing waits), finish() turns the
 // first T items' worth of them into keys: k[q] for every bit q of the returned mask.  The partition kernels issue two tiles ahead of the one they
 // finish, so a full round of LDS work hides the HBM latency.
 struct mem_source {
+  static constexpr int ITEMS = 8;                      // keys per lane and round
   const uint64_t* __restrict__ keys;
-  struct raw_t { uint64_t v[RP_MAXITEMS]; };
+  struct raw_t { uint64_t v[ITEMS]; };
   template <bool STREAM = false>
   __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) {
+    for (int q = 0; q < ITEMS; ++q) {
       const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
       if (i < hi) raw.v[q] = STREAM ? __builtin_nontemporal_load(&keys[i]) : keys[i];   // STREAM: last use of the keys
     }
   }
-  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[RP_MAXITEMS]) const {
+  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[ITEMS]) const {
     unsigned vm = 0;
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) {
+    for (int q = 0; q < ITEMS; ++q) {
       const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
       if (q < items && i < hi) { k[q] = raw.v[q]; vm |= 1u << q; }
     }
@@ -118,11 +119,11 @@ struct mem_source {
   }
   // only the digit (key >> shift) & mask of every item: what the histogram pass needs
   __device__ __forceinline__ unsigned digits(int64_t t0, int64_t hi, const raw_t& raw, int shift, unsigned mask,
-                                             unsigned d[RP_MAXITEMS]) const {
-    uint64_t k[RP_MAXITEMS];
-    const unsigned vm = finish(t0, hi, RP_MAXITEMS, raw, k);
+                                             unsigned d[ITEMS]) const {
+    uint64_t k[ITEMS];
+    const unsigned vm = finish(t0, hi, ITEMS, raw, k);
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(k[q] >> shift) & mask;
+    for (int q = 0; q < ITEMS; ++q) d[q] = (unsigned)(k[q] >> shift) & mask;
     return vm;
   }
 };
@@ -135,20 +136,29 @@ struct mem_source {
 // CANON: every hash is replaced by min(h, hash of the reverse complement k-mer) — strand-independent k-mers.
 template <bool CANON>
 struct kmer_source {
+  // base positions per lane and round.  (Twelve fit the staging area too — a fifth of the positions start no k-mer and
+  // 64-byte granules halve what a bucket carries — and were measured: 20.1 instead of 19.5 ms, the rounds get longer
+  // faster than they get fewer.)
+  static constexpr int ITEMS = 8;
   const uint64_t* __restrict__ W;          // 2 bits per base
-  const uint8_t* __restrict__ V;           // 1 bit per base: a k-mer starts here (positions are multiples of 8 per lane)
+  const uint8_t* __restrict__ V;           // 1 bit per base: a k-mer starts here
   int64_t n_words;                         // words of W
   int k;
   struct raw_t { uint64_t w0, w1, w2; unsigned v; };
   template <bool STREAM = false>
   __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
-    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
+    const int64_t o = t0 + (int64_t)threadIdx.x * ITEMS;
     if (o < hi) {
       const int64_t wi = o >> 5;
       raw.w0 = W[wi];
       raw.w1 = W[wi + 1];
       raw.w2 = wi + 2 < n_words ? W[wi + 2] : 0;
-      raw.v = V[o >> 3];
+      if (ITEMS == 8) {
+        raw.v = V[o >> 3];
+      } else {                                               // ITEMS mask bits from bit o of the mask (o a multiple of 4): two bytes
+        const unsigned two = (unsigned)V[o >> 3] | ((unsigned)V[(o >> 3) + 1] << 8);
+        raw.v = (two >> (int)(o & 7)) & ((1u << ITEMS) - 1u);
+      }
     }
   }
   // the 64 bits at bit offset sh (< 128) of the 192-bit window
@@ -157,20 +167,20 @@ struct kmer_source {
     const int s6 = sh & 63;
     return s6 ? (lo >> s6) | (hi << (64 - s6)) : lo;
   }
-  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t kk[RP_MAXITEMS]) const {
-    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
+  __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t kk[ITEMS]) const {
+    const int64_t o = t0 + (int64_t)threadIdx.x * ITEMS;
     const int64_t end = min(t0 + (int64_t)items * RP_THREADS, hi);
     if (o >= end) return 0;
     unsigned valid = raw.v;
-    if (end - o < RP_MAXITEMS) valid &= (1u << (int)(end - o)) - 1u;
+    if (end - o < ITEMS) valid &= (1u << (int)(end - o)) - 1u;
     if (valid == 0) return 0;
     const int sh0 = 2 * (int)(o & 31);
     const uint64_t mask = (1ull << (2 * k)) - 1ull;
     uint64_t h = window(raw, sh0) & mask;                      // k-mer at position o
-    const uint64_t next = window(raw, sh0 + 2 * k);            // the bases that enter at positions o+1 .. o+7 (14 bits)
+    const uint64_t next = window(raw, sh0 + 2 * k);            // the bases that enter at positions o+1 .. o+11 (2 * (ITEMS - 1) bits)
     const int top = 2 * k - 2;
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) {
+    for (int q = 0; q < ITEMS; ++q) {
       if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
       kk[q] = CANON ? min(h, ~(reverse_2bit_groups(h) >> (64 - 2 * k)) & mask) : h;   // slots of invalid positions are never read
     }
@@ -180,27 +190,26 @@ struct kmer_source {
   // are bits [2p + shift, ..) of the packed stream itself: one 64-bit window serves the lane's eight positions and
   // nothing is rolled.  (Canonical hashes have to be built.)
   __device__ __forceinline__ unsigned digits(int64_t t0, int64_t hi, const raw_t& raw, int shift, unsigned dmask,
-                                             unsigned d[RP_MAXITEMS]) const {
+                                             unsigned d[ITEMS]) const {
     if (CANON) {
-      uint64_t kk[RP_MAXITEMS];
-      const unsigned vm = finish(t0, hi, RP_MAXITEMS, raw, kk);
+      uint64_t kk[ITEMS];
+      const unsigned vm = finish(t0, hi, ITEMS, raw, kk);
 #pragma unroll
-      for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (unsigned)(kk[q] >> shift) & dmask;
+      for (int q = 0; q < ITEMS; ++q) d[q] = (unsigned)(kk[q] >> shift) & dmask;
       return vm;
     }
-    const int64_t o = t0 + (int64_t)threadIdx.x * RP_MAXITEMS;
-    const int64_t end = min(t0 + (int64_t)RP_TILE, hi);
+    const int64_t o = t0 + (int64_t)threadIdx.x * ITEMS;
+    const int64_t end = min(t0 + (int64_t)(ITEMS * RP_THREADS), hi);
     if (o >= end) {                                          // (the caller adds zeros: spread them over the bins, not all on bin 0)
 #pragma unroll
-      for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (threadIdx.x + q) & dmask;
+      for (int q = 0; q < ITEMS; ++q) d[q] = (threadIdx.x + q) & dmask;
       return 0;
     }
     unsigned valid = raw.v;
-    if (end - o < RP_MAXITEMS) valid &= (1u << (int)(end - o)) - 1u;
-    // the eight digits lie in the low 2 * 7 + 11 = 25 bits of the window: 32-bit field extracts, no 64-bit shifts
-    const unsigned win = (unsigned)window(raw, 2 * (int)(o & 31) + shift);       // (< 128: shift <= 2k - bits <= 61)
+    if (end - o < ITEMS) valid &= (1u << (int)(end - o)) - 1u;
+    const uint64_t win = window(raw, 2 * (int)(o & 31) + shift);       // (< 128: shift <= 2k - bits <= 61)
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) d[q] = (win >> (2 * q)) & dmask;
+    for (int q = 0; q < ITEMS; ++q) d[q] = (unsigned)(win >> (2 * q)) & dmask;
     return valid;
   }
 };
@@ -221,13 +230,13 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const i
   __syncthreads();
   typename Source::raw_t raw, raw_next;
   src.issue(sl.lo, sl.hi, raw);
-  for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += RP_TILE) {
-    if (t0 + RP_TILE < sl.hi) src.issue(t0 + RP_TILE, sl.hi, raw_next);      // one tile ahead
-    unsigned d[RP_MAXITEMS] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t t0 = sl.lo; t0 < sl.hi; t0 += (Source::ITEMS * RP_THREADS)) {
+    if (t0 + (Source::ITEMS * RP_THREADS) < sl.hi) src.issue(t0 + (Source::ITEMS * RP_THREADS), sl.hi, raw_next);      // one tile ahead
+    unsigned d[Source::ITEMS] = {};
     const unsigned vm = src.digits(t0, sl.hi, raw, shift, (unsigned)(B - 1), d);
     // branch-free: a position where no k-mer starts adds zero (one field extract instead of an exec-mask round trip per key)
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) atomicAdd(&h[d[q]], (vm >> q) & 1u);
+    for (int q = 0; q < Source::ITEMS; ++q) atomicAdd(&h[d[q]], (vm >> q) & 1u);
     raw = raw_next;
   }
   __syncthreads();
@@ -253,14 +262,14 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kmer_kernel(const uint32_t
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   for (int c = threadIdx.x; c < B; c += RP_THREADS) h[c] = 0;
   __syncthreads();
-  // slab-relative 32-bit arithmetic: position r = round * RP_TILE + 8 * tid of [0, len)
+  // slab-relative 32-bit arithmetic: position r = round * HK_TILE + 8 * tid of [0, len)
   const unsigned len = (unsigned)(sl.hi - sl.lo);
-  const int64_t bit0 = 2 * (sl.lo + (int64_t)threadIdx.x * RP_MAXITEMS) + shift;        // of this lane's round-0 window
+  const int64_t bit0 = 2 * (sl.lo + (int64_t)threadIdx.x * HK_ITEMS) + shift;        // of this lane's round-0 window
   const uint32_t* wp = W32 + (bit0 >> 5);
   const uint8_t* vp = V + ((sl.lo >> 3) + threadIdx.x);
   const unsigned sh5 = (unsigned)(bit0 & 31);
-  constexpr unsigned W_STEP = RP_TILE * 2 / 32, V_STEP = RP_TILE / 8;                       // per round: words of the stream, bytes of the mask
-  unsigned r = threadIdx.x * RP_MAXITEMS;
+  constexpr unsigned W_STEP = HK_TILE * 2 / 32, V_STEP = HK_TILE / 8;                       // per round: words of the stream, bytes of the mask
+  unsigned r = threadIdx.x * HK_ITEMS;
   uint2 w = make_uint2(0, 0);
   unsigned v = 0;
   if (r < len) {
@@ -270,17 +279,17 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_kmer_kernel(const uint32_t
   while (r < len) {                                          // (per lane; a lane that ran out just waits at the barrier below)
     const uint2 w_cur = w;
     unsigned valid = v;
-    const unsigned r_next = r + RP_TILE;
+    const unsigned r_next = r + HK_TILE;
     wp += W_STEP;
     vp += V_STEP;
     if (r_next < len) {                                      // one round ahead
       w = *reinterpret_cast<const uint2*>(wp);
       v = *vp;
     }
-    if (len - r < RP_MAXITEMS) valid &= (1u << (len - r)) - 1u;
+    if (len - r < HK_ITEMS) valid &= (1u << (len - r)) - 1u;
     const unsigned win = __builtin_amdgcn_alignbit(w_cur.y, w_cur.x, sh5);
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) atomicAdd(&h[(win >> (2 * q)) & dmask], (valid >> q) & 1u);
+    for (int q = 0; q < HK_ITEMS; ++q) atomicAdd(&h[(win >> (2 * q)) & dmask], (valid >> q) & 1u);
     r = r_next;
   }
   __syncthreads();
@@ -314,7 +323,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_mem_kernel(const uint64_t*
   typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
   const u64x2* pairs = reinterpret_cast<const u64x2*>(keys + lo);
   const int64_t n_pairs = (hi - lo) >> 1;
-  constexpr int PER = RP_MAXITEMS / 2;                       // pairs per lane and tile
+  constexpr int PER = mem_source::ITEMS / 2;                       // pairs per lane and tile
   u64x2 cur[PER], nxt[PER];
   auto issue = [&](int64_t base, u64x2 v[PER]) {
 #pragma unroll
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   if (sl.lo >= sl.hi) return;
   auto tile_size = [](unsigned carried) {
-    return min((unsigned)RP_TILE, ((unsigned)C::STAGE - carried) & ~(unsigned)(RP_THREADS - 1));   // >= RP_THREADS
+    return min((unsigned)(Source::ITEMS * RP_THREADS), ((unsigned)C::STAGE - carried) & ~(unsigned)(RP_THREADS - 1));   // >= RP_THREADS
   };
 
   // A lane owns buckets tid, tid + 1024, ..: their write cursors (kept LINE-aligned; the slots between the aligned
@@ -409,11 +418,11 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   unsigned T = tile_size(carried);
   typename Source::raw_t raw;                     // loads of the next tile, in flight while this one is staged + flushed
   src.template issue<true>(t0, sl.hi, raw);
-  uint64_t k[RP_MAXITEMS];
-  unsigned r[RP_MAXITEMS];
+  uint64_t k[Source::ITEMS];
+  unsigned r[Source::ITEMS];
   unsigned vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
 #pragma unroll
-  for (int q = 0; q < RP_MAXITEMS; ++q)
+  for (int q = 0; q < Source::ITEMS; ++q)
     if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
   __syncthreads();
 
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     if (!last) src.template issue<true>(t0 + T, sl.hi, raw);
     // stage the new keys behind the carried ones
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q) {
+    for (int q = 0; q < Source::ITEMS; ++q) {
       if ((vm >> q) & 1u) {
         const unsigned d = (unsigned)(k[q] >> shift) & (B - 1);
         const uint64_t m = meta[d];
@@ -545,7 +554,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     T = T_next;
     vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
 #pragma unroll
-    for (int q = 0; q < RP_MAXITEMS; ++q)
+    for (int q = 0; q < Source::ITEMS; ++q)
       if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
     __syncthreads();
   }
@@ -594,8 +603,8 @@ __global__ void rp_child_offsets_kernel(const int64_t* __restrict__ scanned, con
 }
 
 int64_t rp_slab_keys(int64_t n) {
-  int64_t k = ceil_div(ceil_div(n, 4096), RP_TILE) * RP_TILE;
-  return std::max<int64_t>(k, (int64_t)RP_TILE * 4);
+  int64_t k = ceil_div(ceil_div(n, 4096), RP_SLAB_UNIT) * RP_SLAB_UNIT;
+  return std::max<int64_t>(k, (int64_t)RP_SLAB_UNIT * 4);
 }
 
 size_t align64(size_t x) { return (x + 63) & ~(size_t)63; }
