@@ -353,7 +353,7 @@ def main():
                 continue
             names = {"finish_sorted": "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
-                     "fastq_encode": "fq_encode", "fastq_census": "fq_census"}
+                     "fastq_encode": "fq_encode_fast", "fastq_census": "fq_census_fast"}
             rec = pmc.get(names.get(dom, dom)) or pmc.get(dom)
             if rec and "read_bytes_corrected" in rec and "write_bytes" in rec:
                 traffic = int(rec["read_bytes_corrected"] + rec["write_bytes"])

@@ -22,6 +22,15 @@ def _short(name):
         return "rocprim::" + name[-50:]
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = name.split("(")[0]
+    if "rp_hist_kmer_kernel" in name:
+        return "rp_hist<kmer_source>"
+    if "rp_hist_mem_kernel" in name:
+        return "rp_hist<mem_source>"
+    for key in ("fq_encode_fast", "fq_census_fast", "fq_zero_edges"):
+        if key in name:
+            return key
+    if "fq_encode_kernel<true>" in name or "fq_census_kernel<true>" in name:
+        return name.split("_kernel")[0] + "<handed back>"
     if "rp_scatter_kernel" in name or "rp_hist_kernel" in name:
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
