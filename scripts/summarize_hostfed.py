@@ -19,7 +19,7 @@ for f in glob.glob(os.path.join(src, "**", "*memory_copy_trace.csv"), recursive=
     for r in rows:
         s, e = int(pick(r, "start")), int(pick(r, "end"))
         size = pick(r, "bytes", "size") or "0"
-        copies.append((s, e, pick(r, "direction", "kind"), int(float(size))))
+        copies.append((s, e, pick(r, "direction") or pick(r, "kind"), int(float(size))))
 for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         kernels.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
@@ -41,7 +41,7 @@ lines = ["# rocprofv3 --kernel-trace --memory-copy-trace -- python bench.py --st
          "has no size column, the last chunk of a batch is shorter): %d rows" % len(big),
          "# bench.py host_fed of the traced run: %s" % (json.dumps(hf) if hf else "?"),
          "%-18s %14s %12s %10s" % ("direction", "bytes", "duration_us", "GB/s")]
-for s, e, d, b in big[:12] + ([("...",) * 4] if len(big) > 24 else []) + big[-12:]:
+for s, e, d, b in (big if len(big) <= 24 else big[:12] + [("...",) * 4] + big[-12:]):
     if s == "...":
         lines.append("...")
         continue

@@ -73,10 +73,11 @@ def pmc(db):
     rows = con.execute("select %s, counter_name, value from counters_collection" % name_col).fetchall()
     agg = {}
     for name, counter, value in rows:
-        a = agg.setdefault((_short(name), counter), [0, 0.0])
+        a = agg.setdefault((_short(name), counter), [0, 0.0, 0.0])
         a[0] += 1
         a[1] += float(value)
-    return {"%s|%s" % k: {"launches": v[0], "sum": v[1], "per_launch": v[1] / v[0]} for k, v in agg.items()}
+        a[2] = max(a[2], float(value))
+    return {"%s|%s" % k: {"launches": v[0], "sum": v[1], "per_launch": v[1] / v[0], "largest": v[2]} for k, v in agg.items()}
 
 
 def main():
@@ -102,6 +103,7 @@ def main():
             kern, counter = key.split("|")
             t = table.setdefault(kern, {})
             t[counter + "_KB_per_launch"] = round(v["per_launch"], 1)
+            t[counter + "_KB_largest_launch"] = round(v["largest"], 1)     # (the decode kernels also run on the small parity inputs)
             t["launches"] = v["launches"]
         for kern, t in table.items():
             f = t.get("FETCH_SIZE_KB_per_launch")
@@ -110,6 +112,10 @@ def main():
                 t["read_bytes_corrected"] = int(f * 1024 * 2)        # gfx950: FETCH_SIZE reports 1/2 of wide reads
             if w is not None:
                 t["write_bytes"] = int(w * 1024)
+            if t.get("FETCH_SIZE_KB_largest_launch") is not None:
+                t["read_bytes_corrected_largest_launch"] = int(t["FETCH_SIZE_KB_largest_launch"] * 1024 * 2)
+            if t.get("WRITE_SIZE_KB_largest_launch") is not None:
+                t["write_bytes_largest_launch"] = int(t["WRITE_SIZE_KB_largest_launch"] * 1024)
         bench = os.path.join(src, "bench_fetch.json")
         if os.path.exists(bench):                      # the workload the counters were collected on
             try:
