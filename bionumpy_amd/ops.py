@@ -674,14 +674,15 @@ class HipOps:
         self._chk(lib.bnpk_row_ids(self.ctx, ptr(offsets.dev()), n_rows, n, ptr(rows), self._s()))
         return HArray(dev=rows)
 
-    def unique_pairs(self, keys, values, key_bits=62, n_values=None):
+    def unique_pairs(self, keys, values, key_bits=62, n_values=None, with_counts=False):
         """sorted distinct (key, value) pairs, values in [0, n_values) — KmerIndex.create_index.  No key-value sort: the
         pairs are the distinct values of id = rank(key) * n_values + value, rank = position among the sorted distinct
         keys, so the index is two runs of the sparse counting path (bnpk_pair_compose / bnpk_pair_split around them)."""
         t, v = keys.dev(), values.dev()
         n = t.numel()
         if n == 0:
-            return HArray(dev=t.clone()), HArray(dev=v.clone())
+            empty = (HArray(dev=t.clone()), HArray(dev=v.clone()))
+            return empty + (HArray(dev=t.clone()),) if with_counts else empty
         if n_values is None:
             n_values = int(v.max().item()) + 1
         distinct, _ = self.count_sparse(HArray(dev=t), key_bits=key_bits)
@@ -692,11 +693,13 @@ class HipOps:
         id_bits = max(1, (distinct.size * n_values - 1).bit_length())
         if id_bits > 62:
             raise NotImplementedError("index too large: %d distinct k-mers x %d rows" % (distinct.size, n_values))
-        uids, _ = self.count_sparse(HArray(dev=ids), key_bits=id_bits, consume=True)
+        uids, pair_counts = self.count_sparse(HArray(dev=ids), key_bits=id_bits, consume=True)
         m = uids.size
         keys_out, vals_out = self._empty(m, np.int64), self._empty(m, np.int64)
         self._chk(lib.bnpk_pair_split(self.ctx, ptr(uids.dev()), m, n_values, ptr(distinct.dev()), ptr(keys_out),
                                       ptr(vals_out), self._s()))
+        if with_counts:                                        # how often every pair occurred
+            return HArray(dev=keys_out), HArray(dev=vals_out), pair_counts
         return HArray(dev=keys_out), HArray(dev=vals_out)
 
     def search_sorted(self, sorted_keys, queries, upper=False):

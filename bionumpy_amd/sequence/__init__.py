@@ -9,6 +9,8 @@ from .position_weight_matrix import PWM, get_motif_scores
 from .count_encoded import count_encoded, EncodedCounts, SparseKmerCounts
 from . import indexing
 from .indexing import KmerIndex, KmerLookup
+from . import debruin
+from .debruin import DeBruijnGraph, ColoredDeBruijnGraph
 
 __all__ = ["get_kmers", "count_kmers", "get_minimizers", "get_reverse_complement", "match_string", "string_matcher", "PWM", "get_motif_scores", "position_weight_matrix", "count_encoded", "EncodedCounts", "SparseKmerCounts",
-           "KmerIndex", "KmerLookup", "indexing"]
+           "KmerIndex", "KmerLookup", "indexing", "debruin", "DeBruijnGraph", "ColoredDeBruijnGraph"]

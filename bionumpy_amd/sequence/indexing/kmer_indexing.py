@@ -15,10 +15,11 @@ from ..kmers import get_kmers
 
 
 class KmerIndex:
-    def __init__(self, k, pair_keys, pair_rows, sequences_encoding):
+    def __init__(self, k, pair_keys, pair_rows, sequences_encoding, pair_counts=None):
         self._k = k
         self._keys = pair_keys          # HArray int64, sorted (kmer of every distinct (kmer,row) pair)
         self._rows = pair_rows          # HArray int64, row ids, ascending within a kmer
+        self._counts = pair_counts      # HArray int64 or None: occurrences of the k-mer in the row
         self._sequences_encoding = sequences_encoding
 
     def __repr__(self):
@@ -29,13 +30,15 @@ class KmerIndex:
         return self._k
 
     @classmethod
-    def create_index(cls, sequences, k):
+    def create_index(cls, sequences, k, multiplicities=False):
+        """``multiplicities``: also keep how often every k-mer occurs in every row (the colored de Bruijn graph's lists)"""
         ops = get_ops()
         kmers = get_kmers(sequences, k)
         kmers._compact()
         rows = ops.row_ids(kmers.offsets(), len(kmers), kmers.total())
-        keys, rows = ops.unique_pairs(kmers._flat_data(), rows, key_bits=2 * k, n_values=max(len(kmers), 1))
-        return cls(k, keys, rows, sequences.encoding)
+        res = ops.unique_pairs(kmers._flat_data(), rows, key_bits=2 * k, n_values=max(len(kmers), 1),
+                               with_counts=multiplicities)
+        return cls(k, res[0], res[1], sequences.encoding, res[2] if multiplicities else None)
 
     def _encode_query(self, kmer):
         if isinstance(kmer, str):
@@ -57,6 +60,13 @@ class KmerIndex:
         if hi == lo:
             return []
         return self._rows.host()[lo:hi]
+
+    def get_indices_with_repeats(self, kmer):
+        """the row of every occurrence of the k-mer, in row order (needs ``multiplicities=True``)"""
+        assert self._counts is not None, "create_index(..., multiplicities=True)"
+        lo, hi = self.get_indices_batch(np.array([self._encode_query(kmer)], dtype=np.int64))
+        lo, hi = int(lo.host()[0]), int(hi.host()[0])
+        return np.repeat(self._rows.host()[lo:hi], self._counts.host()[lo:hi])
 
 
 class KmerLookup:

@@ -18,6 +18,7 @@ against the reference's own golden vectors instead (tests/test_oracle_goldens.py
 * tests/test_kmer.py:85-102              label order (first base = LSB), 3-mer counts
 * tests/test_minimizers.py:44-80         numeric + string minimizers
 * tests/test_kmer_index.py:12-28         KmerIndex / KmerLookup
+* tests/test_debruijn.py:16-35           DeBruijnGraph.forward / backward, ColoredDeBruijnGraph lookups
 * tests/buffers.py:17-40,104-112         FASTQ / FASTA text fixtures
 * tests/test_io_exceptions.py:11-33      FormatException.line_number
 * README.rst:38-42                       G count 53686 of big.fq.gz
@@ -34,6 +35,6 @@ from .encode import (dna_lut, gather_rows, encode_dna, decode_dna,
 from .kmers import (pack_2bit, sliding_window_2bit, kmer_hashes_flat,
                     get_kmers, get_kmers_generic, get_minimizers,
                     kmer_to_string, kmer_labels, count_dense, count_sparse,
-                    merge_sparse, build_kmer_index, kmer_index_pairs, kmer_from_string,
+                    merge_sparse, build_kmer_index, kmer_index_pairs, debruijn_neighbours, colored_debruijn, kmer_from_string,
                     reverse_complement, reverse_complement_hash, canonical_kmers,
                     match_string, pwm_scores)

@@ -186,6 +186,29 @@ def build_kmer_index(codes, lengths, k):
     return {int(key): r[bounds[i]:bounds[i + 1]] for i, key in enumerate(ukeys)}
 
 
+def debruijn_neighbours(kmer_set, kmer, k, forward=True):
+    """DeBruijnGraph.forward / backward (bionumpy/sequence/debruin.py:20-37): the int k-mers of ``kmer_set`` that
+    follow (precede) ``kmer``, in the order the reference tries them (new base A, C, G, T)."""
+    if forward:
+        base = kmer >> 2
+        candidates = [base + (i << (2 * (k - 1))) for i in range(4)]
+    else:
+        base = (kmer << 2) & (4 ** k - 1)
+        candidates = [base + i for i in range(4)]
+    members = set(int(x) for x in kmer_set)
+    return [c for c in candidates if c in members]
+
+
+def colored_debruijn(codes, lengths, k):
+    """ColoredDeBruijnGraph.from_sequences (debruin.py:51-58): {int kmer: [row of every occurrence, in row order]}"""
+    hashes, new_lengths = get_kmers(codes, lengths, k)
+    rows = np.repeat(np.arange(len(new_lengths), dtype=np.int64), new_lengths)
+    out = {}
+    for h, r in zip(hashes.tolist(), rows.tolist()):
+        out.setdefault(h, []).append(r)
+    return out
+
+
 # ---- reverse complement / canonical k-mers (SURVEY 8f-1) -------------------------------------------------------------
 _ASCII_COMPLEMENT = np.zeros(128, dtype=np.uint8)                 # bionumpy/sequence/dna.py:10,29-33
 for _a, _b in {"A": "T", "G": "C", "C": "G", "T": "A", "N": "N"}.items():

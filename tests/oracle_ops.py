@@ -304,9 +304,13 @@ class OracleOps:
     def row_ids(self, offsets, n_rows, n):
         return _h(np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(offsets.host())))
 
-    def unique_pairs(self, keys, values, key_bits=62, n_values=None):
-        pairs = np.unique(np.stack([keys.host(), values.host()], axis=1), axis=0) if keys.size else \
-            np.zeros((0, 2), dtype=np.int64)
+    def unique_pairs(self, keys, values, key_bits=62, n_values=None, with_counts=False):
+        if keys.size:
+            pairs, counts = np.unique(np.stack([keys.host(), values.host()], axis=1), axis=0, return_counts=True)
+        else:
+            pairs, counts = np.zeros((0, 2), dtype=np.int64), np.zeros(0, dtype=np.int64)
+        if with_counts:
+            return _h(pairs[:, 0]), _h(pairs[:, 1]), _h(counts.astype(np.int64))
         return _h(pairs[:, 0]), _h(pairs[:, 1])
 
     def merge_add(self, a_keys, a_counts, b_keys, b_counts):

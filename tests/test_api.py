@@ -213,6 +213,41 @@ def test_kmer_index(bnp):
     assert lookup.get_sequences(kmer="CGT").tolist() == ["ACGTAA"]
 
 
+def test_debruijn_graphs(bnp):
+    # tests/test_debruijn.py:10-35
+    from bionumpy_amd.sequence.debruin import DeBruijnGraph, ColoredDeBruijnGraph
+    sequences = ["acg", "cgtc"]
+    graph = DeBruijnGraph.from_sequences(sequences, 2)
+    assert isinstance(graph, DeBruijnGraph) and len(graph) == 4          # AC CG GT TC
+    assert graph.forward("ac") == ["CG"]
+    assert graph.backward("tc") == ["GT"]
+    assert graph.forward("tc") == ["CG"] and graph.backward("ac") == []      # C? after TC: CG is there; ?A before AC: nothing
+    colored = ColoredDeBruijnGraph.from_sequences(sequences, 2)
+    assert colored["ac"] == [0]
+    assert colored["tc"] == [1]
+    assert colored["cg"] == [0, 1]
+    assert colored["aa"] == []
+    # larger, against the oracle: every neighbour list, and rows with a k-mer more than once
+    rng = np.random.default_rng(5)
+    reads = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(0, 60, size=40)] + ["ACACACAC"]
+    k = 4
+    codes = np.concatenate([oracle.encode_dna(np.frombuffer(r.encode(), dtype=np.uint8)) for r in reads]).astype(np.uint8)
+    lens = np.array([len(r) for r in reads])
+    kmers, _ = oracle.get_kmers(codes, lens, k)
+    kmer_set = np.unique(kmers)
+    graph = DeBruijnGraph.from_sequences(reads, k)
+    assert len(graph) == kmer_set.size
+    for q in list(kmer_set[:25]) + [0, 4 ** k - 1]:
+        s = oracle.kmer_to_string(int(q), k)
+        assert graph.forward(s) == [oracle.kmer_to_string(x, k) for x in oracle.debruijn_neighbours(kmer_set, int(q), k, True)]
+        assert graph.backward(s) == [oracle.kmer_to_string(x, k) for x in oracle.debruijn_neighbours(kmer_set, int(q), k, False)]
+    colors = oracle.colored_debruijn(codes, lens, k)
+    colored = ColoredDeBruijnGraph.from_sequences(reads, k)
+    for q in list(colors)[:40] + [oracle.kmer_from_string("ACAC")]:
+        assert colored[oracle.kmer_to_string(q, k)] == colors.get(q, [])
+    assert colored["ACAC"].count(len(reads) - 1) == 3
+
+
 # ------------------------------------------------------------------------------------ encodings
 def test_encodings(bnp):
     # docs_source/source/encoding.rst:15-19,40-42; tests/test_encodings.py:30-41,118-122

@@ -177,6 +177,21 @@ def test_kmer_index_goldens():
     assert idx[oracle.kmer_from_string("CGT")].tolist() == [0]       # -> get_sequences == ["ACGTAA"]
 
 
+def test_debruijn_goldens():
+    # tests/test_debruijn.py:16-35 (sequences 'acg', 'cgtc', k = 2)
+    codes, lens = _encode(["ACG", "CGTC"])
+    kmers, _ = oracle.get_kmers(codes, lens, 2)
+    kmer_set = np.unique(kmers)
+    fw = oracle.debruijn_neighbours(kmer_set, oracle.kmer_from_string("AC"), 2, forward=True)
+    assert [oracle.kmer_to_string(x, 2) for x in fw] == ["CG"]
+    bw = oracle.debruijn_neighbours(kmer_set, oracle.kmer_from_string("TC"), 2, forward=False)
+    assert [oracle.kmer_to_string(x, 2) for x in bw] == ["GT"]
+    colors = oracle.colored_debruijn(codes, lens, 2)
+    assert colors[oracle.kmer_from_string("AC")] == [0]
+    assert colors[oracle.kmer_from_string("TC")] == [1]
+    assert colors[oracle.kmer_from_string("CG")] == [0, 1]
+
+
 # ---------------------------------------------------------------- text decode
 FASTQ_TEXT = "@headerishere\nCTTGTTGA\n+\n!!!!!!!!\n@anotherheader\nCGG\n+\n~~~\n"   # tests/buffers.py:17-25
 FASTA_TEXT = ">header\nCTTGTTGA\n>header2\nCGG\n"                                       # tests/buffers.py:26-31
