@@ -72,7 +72,9 @@ int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes,
 /* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
  * "finish_mode": which finishing kernel bnpk_finish_sorted launches — 0 = chosen per call from a probe of
  *                the first buckets (default), 1 = the general kernel only, 2 = the fast kernel + redo list only.
- * Unknown names return BNPK_ERR_ARG. */
+ * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
+ *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
+ * Unknown names and values out of range return BNPK_ERR_ARG. */
 int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value);
 
 /* ---- host staging: pinned buffers and async copies ----------------------------------- */

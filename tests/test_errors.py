@@ -45,6 +45,7 @@ def test_bad_arguments(env):
     assert lib.bnpk_kmers_generic(dev.ctx, ptr(keys), ptr(keys), ptr(keys), 1, 1, 32, 4, ptr(out), None) == ERR_ARG   # k > 31
     assert lib.bnpk_set_option(dev.ctx, b"no such knob", 1) == ERR_ARG
     assert lib.bnpk_set_option(dev.ctx, b"finish_mode", 7) == ERR_ARG
+    assert lib.bnpk_set_option(dev.ctx, b"fastq_encoder", 2) == ERR_ARG
     text = torch.zeros(64, dtype=torch.uint8, device="cuda")
     cell = torch.zeros(1, dtype=torch.int64, device="cuda")
     lut = np.zeros(256, dtype=np.uint8)
