@@ -68,6 +68,102 @@ int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_of
 
 }  // extern "C"
 
+// ---- element-wise helpers of the read filters ------------------------------------------------------------------------
+// np.mean(chunk.quality, axis=1) > 30, mask[::3] = False, mask1 & mask2 (scripts/small_example.py:36-46): the per-row
+// values of a 50 M-read chunk are 400 MB — they stay in HBM behind bionumpy_amd/device_vector.py and these kernels
+// compute on them; only what the caller looks at crosses PCIe.
+namespace {
+
+__global__ void vec_ratio_rows_kernel(const int64_t* __restrict__ sums, const int64_t* __restrict__ off, int64_t n,
+                                      double* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = (double)sums[i] / (double)(off[i + 1] - off[i]);     // 0 / 0 = nan, as numpy
+}
+
+template <typename T>
+__device__ __forceinline__ bool vec_cmp(T x, T y, int op) {
+  return op == 0 ? x < y : op == 1 ? x <= y : op == 2 ? x > y : op == 3 ? x >= y : op == 4 ? x == y : x != y;
+}
+
+template <typename T>
+__global__ void vec_compare_kernel(const T* __restrict__ x, int64_t n, int op, T y, uint8_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = vec_cmp(x[i], y, op) ? 1 : 0;
+}
+
+__global__ void mask_logic_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int64_t n, int op,
+                                  uint8_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const bool x = a[i] != 0, y = b ? b[i] != 0 : false;
+    out[i] = (op == 0 ? (x && y) : op == 1 ? (x || y) : op == 2 ? (x != y) : !x) ? 1 : 0;
+  }
+}
+
+__global__ void mask_fill_kernel(uint8_t* __restrict__ mask, int64_t start, int64_t step, int64_t count, uint8_t value) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < count; i += stride) mask[start + i * step] = value;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bnpk_vec_ratio_rows(bnpk_ctx* ctx, const int64_t* d_sums, const int64_t* d_offsets, int64_t n, double* d_out, void* stream) {
+  if (!ctx || n < 0 || (n > 0 && (!d_sums || !d_offsets || !d_out))) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "vec_ratio_rows", s);
+  hipLaunchKernelGGL(vec_ratio_rows_kernel, dim3(grid_for(ceil_div(n, 256))), dim3(256), 0, s, d_sums, d_offsets, n, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_vec_compare(bnpk_ctx* ctx, const void* d_x, int64_t n, int dtype, int op, double scalar_f64, int64_t scalar_i64,
+                     uint8_t* d_out, void* stream) {
+  if (!ctx || n < 0 || dtype < 0 || dtype > 2 || op < 0 || op > 5 || (n > 0 && (!d_x || !d_out))) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "vec_compare", s);
+  const dim3 grid(grid_for(ceil_div(n, 256))), block(256);
+  if (dtype == 0) hipLaunchKernelGGL((vec_compare_kernel<double>), grid, block, 0, s, (const double*)d_x, n, op, scalar_f64, d_out);
+  else if (dtype == 1) hipLaunchKernelGGL((vec_compare_kernel<int64_t>), grid, block, 0, s, (const int64_t*)d_x, n, op, scalar_i64, d_out);
+  else {
+    if (scalar_i64 < 0 || scalar_i64 > 255) return BNPK_ERR_ARG;     // (the caller folds comparisons that no uint8 can decide)
+    hipLaunchKernelGGL((vec_compare_kernel<uint8_t>), grid, block, 0, s, (const uint8_t*)d_x, n, op, (uint8_t)scalar_i64, d_out);
+  }
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t n, int op, uint8_t* d_out, void* stream) {
+  if (!ctx || n < 0 || op < 0 || op > 3 || (n > 0 && (!d_a || !d_out || (op != 3 && !d_b)))) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "mask_logic", s);
+  hipLaunchKernelGGL(mask_logic_kernel, dim3(grid_for(ceil_div(n, 256))), dim3(256), 0, s, d_a, op == 3 ? nullptr : d_b, n, op, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int64_t step, int64_t count, int value, void* stream) {
+  if (!ctx || n < 0 || start < 0 || step < 1 || count < 0 || (count > 0 && (!d_mask || start + (count - 1) * step >= n)))
+    return BNPK_ERR_ARG;
+  if (count == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "mask_fill", s);
+  hipLaunchKernelGGL(mask_fill_kernel, dim3(grid_for(ceil_div(count, 256))), dim3(256), 0, s, d_mask, start, step, count,
+                     (uint8_t)(value ? 1 : 0));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+}  // extern "C"
+
 // ---- join_fields: text of records from their fields (bionumpy/io/one_line_buffer.py:119-134) ----------------------
 // Entry r = its lines one after the other; line i = `prefix` header bytes, the field's row r (plus `add`: quality
 // scores are written as score + 33), a newline.  A line without a field is the constant byte `fill` ('+').

@@ -45,7 +45,10 @@ class SequenceEntry:
         if isinstance(idx, (int, np.integer)):
             idx = [int(idx)]
         if self._buffer is not None:      # stays lazy: the selection is a view of the chunk's text buffer, so
-            if isinstance(idx, np.ndarray) and idx.dtype == bool:     # that it can be written back (get_buffer)
+            from .device_vector import DeviceVector                   # that it can be written back (get_buffer)
+            if isinstance(idx, DeviceVector) and idx.dtype == np.bool_:
+                idx = idx.nonzero_rows()                              # the row list of a device mask never leaves HBM
+            elif isinstance(idx, np.ndarray) and idx.dtype == bool:
                 idx = np.flatnonzero(idx)
             return self.__class__._lazy(self._buffer[idx], self._line_offset)
         return self.__class__(**{f: getattr(self, f)[idx] for f in self._fields})

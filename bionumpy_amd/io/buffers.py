@@ -83,7 +83,7 @@ class OneLineBuffer(FileBuffer):
         self._data = data               # HArray: the chunk cut after the last complete entry
         self._scan = scan               # ops.LineScan
         self._size = scan.size
-        self._rows = rows               # optional row selection (host int64 indices)
+        self._rows = rows               # optional row selection: host int64 indices, or an HArray of them (device mask)
 
     @property
     def n_lines(self):
@@ -119,7 +119,9 @@ class OneLineBuffer(FileBuffer):
                                              self._scan.has_cr)
         view = EncodedRaggedArray._from_parts(self._data, starts, lens, None, self._scan.n_records, None,
                                               BaseEncoding)
-        return view if self._rows is None else view[self._rows]
+        if self._rows is None:
+            return view
+        return view[self._rows.host() if isinstance(self._rows, HArray) else self._rows]
 
     def get_text_field_by_number(self, i):
         return self._field_view(i)
@@ -134,7 +136,12 @@ class OneLineBuffer(FileBuffer):
         return SequenceEntry(self.get_field_by_number(0), self.get_field_by_number(1))
 
     def __getitem__(self, idx):
-        rows = np.arange(self._scan.n_records, dtype=np.int64) if self._rows is None else self._rows
+        if isinstance(idx, HArray):                      # the ascending row list of a device mask (DeviceVector.nonzero_rows)
+            if self._rows is None:
+                return self.__class__(self._data, self._scan, idx)
+            idx = idx.host()
+        rows = np.arange(self._scan.n_records, dtype=np.int64) if self._rows is None else \
+            (self._rows.host() if isinstance(self._rows, HArray) else self._rows)
         return self.__class__(self._data, self._scan, np.atleast_1d(rows[idx]))
 
     @classmethod
@@ -174,10 +181,10 @@ class OneLineBuffer(FileBuffer):
         if self._rows is None:
             return self._data if self._data.size == self._size else HArray(dev=self._data.dev()[:self._size])
         ops = get_ops()
-        rows = np.asarray(self._rows, dtype=np.int64)
+        rows = self._rows if isinstance(self._rows, HArray) else HArray(host=np.asarray(self._rows, dtype=np.int64))
         if rows.size == 0:
             return HArray(host=np.zeros(0, dtype=np.uint8))
-        starts, lens = ops.entry_table(self._scan.newlines, self.n_lines_per_entry, HArray(host=rows))
+        starts, lens = ops.entry_table(self._scan.newlines, self.n_lines_per_entry, rows)
         offsets, total = ops.row_offsets(lens, 1)
         return ops.gather_rows(self._data, starts, offsets, rows.size, total, 0)
 

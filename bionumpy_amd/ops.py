@@ -396,6 +396,50 @@ class HipOps:
                                          ptr(outs["min"]), ptr(outs["max"]), self._s()))
         return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
 
+    # -- per-row values that stay in HBM (device_vector.py) ---------------------------------------------------------
+    def vec_ratio_rows(self, sums, offsets, n):
+        """sums[i] / (offsets[i+1] - offsets[i]) as float64 — np.mean(ragged, axis=-1)"""
+        out = self._empty(n, np.float64)
+        self._chk(lib.bnpk_vec_ratio_rows(self.ctx, ptr(sums.dev()), ptr(offsets.dev()), n, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def vec_compare(self, x, op, scalar):
+        """x OP scalar as a 0/1 uint8 mask; x float64 / int64 / uint8, op one of < <= > >= == !="""
+        code = {"<": 0, "<=": 1, ">": 2, ">=": 3, "==": 4, "!=": 5}[op]
+        dtype = {np.dtype(np.float64): 0, np.dtype(np.int64): 1, np.dtype(np.uint8): 2}[np.dtype(x.dtype)]
+        out = self._empty(x.size, np.uint8)
+        self._chk(lib.bnpk_vec_compare(self.ctx, ptr(x.dev()), x.size, dtype, code, float(scalar) if dtype == 0 else 0.0,
+                                       int(scalar) if dtype != 0 else 0, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def mask_logic(self, a, b, op):
+        """a AND / OR / XOR b, or NOT a (b None): 0/1 uint8 masks"""
+        code = {"and": 0, "or": 1, "xor": 2, "not": 3}[op]
+        out = self._empty(a.size, np.uint8)
+        self._chk(lib.bnpk_mask_logic(self.ctx, ptr(a.dev()), ptr(b.dev()) if b is not None else None, a.size, code,
+                                      ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def mask_fill(self, mask, start, step, count, value):
+        """mask[start + i * step] = value for i < count, in place"""
+        self._chk(lib.bnpk_mask_fill(self.ctx, ptr(mask.dev()), mask.size, start, step, count, 1 if value else 0, self._s()))
+
+    def mask_rows(self, mask):
+        """(indices of the set bytes of a 0/1 mask as int64, ascending; their number) — np.flatnonzero(mask)"""
+        d = mask.dev()
+        n = mask.size
+        tiles = lib.bnpk_scan_tiles(n)
+        tile_off = self._empty(tiles + 1, np.int64)
+        self._chk(lib.bnpk_byte_census(self.ctx, ptr(d), n, 1, ptr(tile_off), self._s()))
+        total = int(tile_off[tiles].item())
+        pos = self._empty(total, np.int64)
+        self._chk(lib.bnpk_byte_positions(self.ctx, ptr(d), n, 1, ptr(tile_off), total, ptr(pos), self._s()))
+        return HArray(dev=pos), total
+
+    def slice_copy(self, x, start, stop):
+        """x[start:stop] as its own buffer"""
+        return HArray(dev=x.dev()[start:stop].clone())
+
     # -- reverse complement / canonical k-mers (SURVEY 8f-1) ---------------------------------------------------
     def reverse_complement_packed(self, packed, offsets, n_rows, total):
         out = self._empty(total // 32 + 2, np.int64)

@@ -204,8 +204,11 @@ class RaggedArray:
                                       "match flags)")
         self._compact()
         data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
-        out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what].host()
-        return out.astype(bool) if (self.dtype == np.bool_ and what != "sum") else out
+        out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what]
+        if self.dtype == np.bool_ and what != "sum":
+            return out.host().astype(bool)
+        from .device_vector import DeviceVector             # one value per row, left in HBM (device_vector.py)
+        return DeviceVector(out)
 
     @staticmethod
     def _row_axis(axis):
@@ -234,7 +237,9 @@ class RaggedArray:
             return sums / counts                                            # every column < max length has a row
         self._row_axis(axis)
         with np.errstate(invalid="ignore", divide="ignore"):
-            return self._row_reduce("sum") / self.lengths                   # an empty row gives nan, as in numpy
+            from .device_vector import DeviceVector
+            sums = self._row_reduce("sum").harray()
+            return DeviceVector(get_ops().vec_ratio_rows(sums, self.offsets(), self._n_rows))     # an empty row gives nan, as in numpy
 
     def _extreme(self, what, axis):
         self._row_axis(axis)

@@ -206,6 +206,20 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
                        int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
 
+/* Element-wise helpers of the read filters (scripts/small_example.py:36-46: `np.mean(chunk.quality, axis=1) > 30`,
+ * `mask[::3] = False`, `mask1 & mask2`, `chunk[mask]`) on per-row values that stay in HBM (bionumpy_amd/device_vector.py):
+ *   bnpk_vec_ratio_rows  d_out[i] = (double)d_sums[i] / (double)(d_offsets[i+1] - d_offsets[i])   — np.mean(ragged, axis=-1)
+ *   bnpk_vec_compare     d_out[i] = d_x[i] OP scalar as 0/1; dtype 0 = float64 (scalar_f64), 1 = int64, 2 = uint8
+ *                        (scalar_i64); op 0 <, 1 <=, 2 >, 3 >=, 4 ==, 5 != (IEEE: comparisons with nan are false, != true)
+ *   bnpk_mask_logic      d_out = d_a AND / OR / XOR d_b (op 0 / 1 / 2) or NOT d_a (op 3, d_b unused); masks are 0/1 bytes
+ *   bnpk_mask_fill       d_mask[start + i * step] = value for i < count   — mask[start:stop:step] = value
+ * (the set bits of a mask are counted and listed by bnpk_byte_census / bnpk_byte_positions with value 1) */
+int bnpk_vec_ratio_rows(bnpk_ctx* ctx, const int64_t* d_sums, const int64_t* d_offsets, int64_t n, double* d_out, void* stream);
+int bnpk_vec_compare(bnpk_ctx* ctx, const void* d_x, int64_t n, int dtype, int op, double scalar_f64, int64_t scalar_i64,
+                     uint8_t* d_out, void* stream);
+int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t n, int op, uint8_t* d_out, void* stream);
+int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int64_t step, int64_t count, int value, void* stream);
+
 /* Per-column sums of ragged uint8 data: np.sum / np.mean(ragged, axis=0) (scripts/small_example.py:20-22,49-52).
  * d_sums[c] = sum over the rows with more than c elements of their element c, d_counts[c] = number of such rows,
  * c < n_cols (= the longest row). */

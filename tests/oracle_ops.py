@@ -304,6 +304,32 @@ class OracleOps:
     def row_ids(self, offsets, n_rows, n):
         return _h(np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(offsets.host())))
 
+    def vec_ratio_rows(self, sums, offsets, n):
+        off = offsets.host()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return _h(sums.host()[:n].astype(np.float64) / (off[1:n + 1] - off[:n]).astype(np.float64))
+
+    def vec_compare(self, x, op, scalar):
+        import operator
+        f = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge, "==": operator.eq, "!=": operator.ne}[op]
+        return _h(f(x.host(), scalar).astype(np.uint8))
+
+    def mask_logic(self, a, b, op):
+        x = a.host().astype(bool)
+        y = b.host().astype(bool) if b is not None else None
+        out = {"and": lambda: x & y, "or": lambda: x | y, "xor": lambda: x ^ y, "not": lambda: ~x}[op]()
+        return _h(out.astype(np.uint8))
+
+    def mask_fill(self, mask, start, step, count, value):
+        mask.host()[start:start + count * step:step] = 1 if value else 0
+
+    def mask_rows(self, mask):
+        rows = np.flatnonzero(mask.host()).astype(np.int64)
+        return _h(rows), int(rows.size)
+
+    def slice_copy(self, x, start, stop):
+        return _h(x.host()[start:stop].copy())
+
     def unique_pairs(self, keys, values, key_bits=62, n_values=None, with_counts=False):
         if keys.size:
             pairs, counts = np.unique(np.stack([keys.host(), values.host()], axis=1), axis=0, return_counts=True)

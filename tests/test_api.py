@@ -213,6 +213,46 @@ def test_kmer_index(bnp):
     assert lookup.get_sequences(kmer="CGT").tolist() == ["ACGTAA"]
 
 
+def test_row_values_stay_numpy_like(bnp):
+    # scripts/small_example.py:36-46: np.mean(chunk.quality, axis=1) > 30, masks combined, chunk[mask] — the per-row values
+    # live in HBM (device_vector.py) and have to behave like the numpy arrays the reference returns
+    rng = np.random.default_rng(9)
+    n = 3000
+    lens = rng.integers(1, 60, size=n)
+    seqs = ["".join(rng.choice(list("ACGT"), size=int(l))) for l in lens]
+    quals = [bytes(rng.integers(33, 74, size=int(l)).astype(np.uint8)).decode() for l in lens]
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, s, q) for i, (s, q) in enumerate(zip(seqs, quals)))
+    chunk = _reader(bnp, text, bnp.FastQBuffer).read()
+    scores = [np.frombuffer(q.encode(), dtype=np.uint8).astype(np.int64) - 33 for q in quals]
+    means_ref = np.array([s.mean() for s in scores])
+    mins_ref = np.array([s.min() for s in scores])
+    means = np.mean(chunk.quality, axis=1)
+    mins = np.min(chunk.quality, axis=1)
+    assert np.array_equal(np.asarray(means), means_ref) and np.array_equal(np.asarray(mins), mins_ref)
+    assert means.shape == (n,) and len(means) == n and means.dtype == np.float64
+    assert float(np.median(means[:1000])) == float(np.median(means_ref[:1000]))
+    assert means[7] == means_ref[7] and np.array_equal(means[10:20], means_ref[10:20])
+    mask = (means > 20) & (mins >= 3)
+    mask_ref = (means_ref > 20) & (mins_ref >= 3)
+    assert np.array_equal(np.asarray(mask), mask_ref) and mask.sum() == mask_ref.sum() and np.sum(mask) == mask_ref.sum()
+    assert np.array_equal(np.flatnonzero(mask), np.flatnonzero(mask_ref))
+    assert np.array_equal(np.asarray(~mask), ~mask_ref) and np.array_equal(np.asarray(mask | (means < 5)), mask_ref | (means_ref < 5))
+    assert np.array_equal(np.asarray(mask & mask_ref), mask_ref)                    # a device mask and a numpy mask
+    mask[::3] = False
+    mask_ref[::3] = False
+    mask[5:9] = True
+    mask_ref[5:9] = True
+    assert np.array_equal(np.asarray(mask), mask_ref)
+    kept = chunk[mask]
+    assert len(kept) == int(mask_ref.sum())
+    assert kept.sequence.tolist() == [s for s, m in zip(seqs, mask_ref) if m]
+    assert kept.get_buffer().entry_bytes().host().tobytes().decode() == \
+        "".join("@r%d\n%s\n+\n%s\n" % (i, s, q) for i, (s, q, m) in enumerate(zip(seqs, quals, mask_ref)) if m)
+    assert np.allclose(means * 2 + 1, means_ref * 2 + 1) and np.allclose(np.sqrt(means), np.sqrt(means_ref))
+    assert means.tolist() == means_ref.tolist() and (means == means_ref).all() and not (means != means_ref).any()
+    assert np.array_equal(np.asarray(means[mask]), means_ref[mask_ref])
+
+
 def test_debruijn_graphs(bnp):
     # tests/test_debruijn.py:10-35
     from bionumpy_amd.sequence.debruin import DeBruijnGraph, ColoredDeBruijnGraph

@@ -596,3 +596,47 @@ def test_heavy_hitter_buckets(ops, n_hot, copies):
     ek, ec = oracle.count_sparse(v)
     keys, counts = ops.count_sparse(_h(v), key_bits=62)
     assert np.array_equal(keys.host(), ek) and np.array_equal(counts.host(), ec)
+
+
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 100_003, 3_000_001])
+def test_elementwise_helpers_of_the_read_filters(ops, n):
+    """bnpk_vec_ratio_rows / bnpk_vec_compare / bnpk_mask_logic / bnpk_mask_fill and the mask row list
+    (bnpk_byte_census + bnpk_byte_positions with value 1) == the numpy expressions they replace"""
+    rng = np.random.default_rng(n + 3)
+    lens = rng.integers(0, 40, size=n).astype(np.int64)
+    off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    sums = rng.integers(0, 5000, size=n).astype(np.int64)
+    got = ops.vec_ratio_rows(_h(sums), _h(off), n).host()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        expect = sums.astype(np.float64) / lens.astype(np.float64)
+    assert np.array_equal(got, expect, equal_nan=True)
+    import operator
+    table = {"<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge, "==": operator.eq, "!=": operator.ne}
+    x64 = expect.copy()
+    for op, f in table.items():
+        for scalar in (17.5, 0.0, float("nan")):
+            with np.errstate(invalid="ignore"):
+                assert np.array_equal(ops.vec_compare(_h(x64), op, scalar).host().astype(bool), f(x64, scalar)), (op, scalar)
+        assert np.array_equal(ops.vec_compare(_h(sums), op, 2500).host().astype(bool), f(sums, 2500))
+        u8 = (sums % 256).astype(np.uint8)
+        assert np.array_equal(ops.vec_compare(_h(u8), op, 30).host().astype(bool), f(u8, 30))
+    a = (rng.random(n) < 0.4).astype(np.uint8)
+    b = (rng.random(n) < 0.7).astype(np.uint8)
+    assert np.array_equal(ops.mask_logic(_h(a), _h(b), "and").host(), a & b)
+    assert np.array_equal(ops.mask_logic(_h(a), _h(b), "or").host(), a | b)
+    assert np.array_equal(ops.mask_logic(_h(a), _h(b), "xor").host(), a ^ b)
+    assert np.array_equal(ops.mask_logic(_h(a), None, "not").host(), 1 - a)
+    rows, total = ops.mask_rows(_h(a))
+    assert total == int(a.sum()) and np.array_equal(rows.host(), np.flatnonzero(a))
+    for start, stop, step, value in ((0, n, 3, 0), (1, n, 2, 1), (n // 2, n, 1, 0), (0, 0, 1, 1), (5, n - 3, 7, 1)):
+        if n == 0 and (start or stop):
+            continue
+        m = _h(a.copy())
+        m.dev()
+        start, stop, step2 = slice(start, max(stop, 0), step).indices(n)
+        count = max(0, (stop - start + step2 - 1) // step2)
+        ops.mask_fill(m, start, step2, count, value)
+        m.drop_host()
+        ref = a.copy()
+        ref[start:stop:step2] = value
+        assert np.array_equal(m.host(), ref)
