@@ -640,3 +640,33 @@ def test_elementwise_helpers_of_the_read_filters(ops, n):
         ref = a.copy()
         ref[start:stop:step2] = value
         assert np.array_equal(m.host(), ref)
+
+
+def test_fast_and_general_decode_kernels_agree_on_random_line_structures(ops):
+    """differential test of bnpk_fastq_census + bnpk_fastq_encode: the fast tile kernels against the general ones
+    (which the tests above pin to the oracle) on 200 random texts — same bits or the same exception
+    (scripts/exp/fuzz_decode.py runs the same generator for minutes: 9388 cases, no mismatch)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from fuzz_text import random_text
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import Device
+
+    def run(buf, lpe, seq_line, check_plus, encoder):
+        assert lib.bnpk_set_option(Device.get().ctx, b"fastq_encoder", encoder) == 0
+        try:
+            packed, ends, n_records, n_bases = ops.fastq_encode(_h(buf), buf.size, lpe, seq_line, ord("@"), check_plus)
+            return ("ok", n_records, n_bases, packed.host().tobytes(), ends.host().tobytes())
+        except Exception as e:                                  # noqa: BLE001
+            return ("error", type(e).__name__, str(e), getattr(e, "line_number", None), getattr(e, "offset", None))
+    try:
+        decoded = 0
+        for seed in range(100_000, 100_200):
+            buf, lpe, seq_line, check_plus = random_text(np.random.default_rng(seed))
+            fast, general = run(buf, lpe, seq_line, check_plus, 1), run(buf, lpe, seq_line, check_plus, 0)
+            assert fast == general, (seed, fast[:3], general[:3])
+            decoded += fast[0] == "ok"
+        assert decoded > 50
+    finally:
+        lib.bnpk_set_option(Device.get().ctx, b"fastq_encoder", 1)
