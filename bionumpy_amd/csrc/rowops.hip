@@ -103,6 +103,13 @@ __global__ void mask_logic_kernel(const uint8_t* __restrict__ a, const uint8_t* 
   }
 }
 
+__global__ void take_i64_kernel(const int64_t* __restrict__ arr, const int64_t* __restrict__ idx, int64_t m,
+                                int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += stride) out[i] = arr[idx[i]];
+}
+
 __global__ void mask_fill_kernel(uint8_t* __restrict__ mask, int64_t start, int64_t step, int64_t count, uint8_t value) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -146,6 +153,16 @@ int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "mask_logic", s);
   hipLaunchKernelGGL(mask_logic_kernel, dim3(grid_for(ceil_div(n, 256))), dim3(256), 0, s, d_a, op == 3 ? nullptr : d_b, n, op, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_take_i64(bnpk_ctx* ctx, const int64_t* d_arr, const int64_t* d_idx, int64_t m, int64_t* d_out, void* stream) {
+  if (!ctx || m < 0 || (m > 0 && (!d_arr || !d_idx || !d_out))) return BNPK_ERR_ARG;
+  if (m == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "take_i64", s);
+  hipLaunchKernelGGL(take_i64_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_arr, d_idx, m, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

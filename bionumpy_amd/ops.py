@@ -436,6 +436,17 @@ class HipOps:
         self._chk(lib.bnpk_byte_positions(self.ctx, ptr(d), n, 1, ptr(tile_off), total, ptr(pos), self._s()))
         return HArray(dev=pos), total
 
+    def take_i64(self, arr, idx):
+        """arr[idx] for device int64 arrays"""
+        out = self._empty(idx.size, np.int64)
+        self._chk(lib.bnpk_take_i64(self.ctx, ptr(arr.dev()), ptr(idx.dev()), idx.size, ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def dense_to_sparse(self, hist):
+        """(indices of the non-zero bins, their counts): a dense histogram in the sorted (key, count) form"""
+        keys, _ = self.mask_rows(self.vec_compare(hist, "!=", 0))
+        return keys, self.take_i64(hist, keys)
+
     def slice_copy(self, x, start, stop):
         """x[start:stop] as its own buffer"""
         return HArray(dev=x.dev()[start:stop].clone())

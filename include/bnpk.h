@@ -213,12 +213,15 @@ int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_of
  *                        (scalar_i64); op 0 <, 1 <=, 2 >, 3 >=, 4 ==, 5 != (IEEE: comparisons with nan are false, != true)
  *   bnpk_mask_logic      d_out = d_a AND / OR / XOR d_b (op 0 / 1 / 2) or NOT d_a (op 3, d_b unused); masks are 0/1 bytes
  *   bnpk_mask_fill       d_mask[start + i * step] = value for i < count   — mask[start:stop:step] = value
+ *   bnpk_take_i64        d_out[i] = d_arr[d_idx[i]], i < m   — arr[idx]; with the row list of `hist != 0` it turns a dense
+ *                        k-mer histogram into the sorted (key, count) form (count_kmers for 9 <= k <= 13)
  * (the set bits of a mask are counted and listed by bnpk_byte_census / bnpk_byte_positions with value 1) */
 int bnpk_vec_ratio_rows(bnpk_ctx* ctx, const int64_t* d_sums, const int64_t* d_offsets, int64_t n, double* d_out, void* stream);
 int bnpk_vec_compare(bnpk_ctx* ctx, const void* d_x, int64_t n, int dtype, int op, double scalar_f64, int64_t scalar_i64,
                      uint8_t* d_out, void* stream);
 int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64_t n, int op, uint8_t* d_out, void* stream);
 int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int64_t step, int64_t count, int value, void* stream);
+int bnpk_take_i64(bnpk_ctx* ctx, const int64_t* d_arr, const int64_t* d_idx, int64_t m, int64_t* d_out, void* stream);
 
 /* Per-column sums of ragged uint8 data: np.sum / np.mean(ragged, axis=0) (scripts/small_example.py:20-22,49-52).
  * d_sums[c] = sum over the rows with more than c elements of their element c, d_counts[c] = number of such rows,

@@ -327,6 +327,13 @@ class OracleOps:
         rows = np.flatnonzero(mask.host()).astype(np.int64)
         return _h(rows), int(rows.size)
 
+    def take_i64(self, arr, idx):
+        return _h(arr.host()[idx.host()])
+
+    def dense_to_sparse(self, hist):
+        keys = np.flatnonzero(hist.host()).astype(np.int64)
+        return _h(keys), _h(hist.host()[keys])
+
     def slice_copy(self, x, start, stop):
         return _h(x.host()[start:stop].copy())
 

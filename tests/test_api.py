@@ -467,6 +467,16 @@ def test_count_kmers_fused_equals_get_kmers_then_count(bnp):
         assert int(fused.counts.sum()) == sum(max(0, len(r) - k + 1) for r in rows)
     short = bnp.as_encoded_array(["ACGT", "AC"], bnp.DNAEncoding)
     assert len(bnp.sequence.count_kmers(short, 31)) == 0
+    # 9 <= k <= 13 with enough k-mers: one dense counting pass + compaction of the non-zero bins, the same pairs
+    rows = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(0, 400, size=300)]
+    sequences = bnp.as_encoded_array(rows, bnp.DNAEncoding)
+    codes = np.concatenate([oracle.encode_dna(np.frombuffer(r.encode(), dtype=np.uint8)) for r in rows]).astype(np.uint8)
+    lens = np.array([len(r) for r in rows])
+    for k in (9, 10):
+        fused = bnp.sequence.count_kmers(sequences, k)
+        ek, ec = oracle.count_sparse(oracle.get_kmers(codes, lens, k)[0])
+        assert np.array_equal(np.asarray(fused.keys), ek) and np.array_equal(np.asarray(fused.counts), ec)
+        assert fused == bnp.count_encoded(bnp.sequence.get_kmers(sequences, k), axis=None)
 
 
 def test_reverse_complement(bnp):
