@@ -187,7 +187,7 @@ int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int
 namespace {
 
 constexpr int JL_MAX_LINES = 4;
-constexpr int JL_BYTES_PER_LANE = 8;
+constexpr int JL_BYTES_PER_LANE = 16;
 constexpr int64_t JL_TILE = (int64_t)BNPK_BLOCK * JL_BYTES_PER_LANE;
 
 struct jl_line {
@@ -219,7 +219,15 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
   const int64_t p1 = min(p0 + JL_BYTES_PER_LANE, total);
   int64_t e0 = entry_off[r], e1 = entry_off[r + 1];
   int64_t p = p0;
-  uint64_t word = 0;                                           // the lane's eight output bytes, stored once
+  uint64_t word[3] = {0, 0, 0};                                // the lane's sixteen output bytes, stored once
+  // m (1..8) bytes, the low bytes of x, go to the lane's next output positions
+  auto emit = [&](uint64_t x, int m) {
+    if (m < 8) x &= (1ull << (8 * m)) - 1ull;
+    const int j = (int)(p - p0), sh = 8 * (j & 7);
+    word[j >> 3] |= x << sh;
+    if (sh) word[(j >> 3) + 1] |= x >> (64 - sh);
+    p += m;
+  };
   while (p < p1) {
     while (e1 <= p) { ++r; e0 = e1; e1 = entry_off[r + 1]; }
     int64_t t = p - e0;                                        // offset inside entry r
@@ -229,22 +237,38 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
       const int64_t flen = L.data ? L.off[r + 1] - fs : 1;
       const int64_t line_len = L.prefix + flen + 1;
       if (t >= line_len) { t -= line_len; continue; }
-      while (t < line_len && p < p1) {                        // bytes of this line that belong to the lane
-        uint8_t b;
-        if (t < L.prefix) b = header;
-        else if (t < L.prefix + flen) b = L.data ? (uint8_t)(L.data[fs + t - L.prefix] + L.add) : L.fill;
-        else b = 10;
-        word |= (uint64_t)b << (8 * (int)(p - p0));
-        ++p;
-        ++t;
+      // the bytes of this line that belong to the lane: the header byte, a span of the field (one unaligned 8-byte load,
+      // the per-byte addition done on the whole word), the newline
+      if (t < L.prefix) { emit(header, 1); ++t; }
+      while (p < p1 && t < L.prefix + flen) {
+        const int m = (int)min(min((int64_t)L.prefix + flen - t, p1 - p), (int64_t)8);
+        uint64_t x;
+        if (!L.data) {
+          x = L.fill;
+        } else {
+          const uint8_t* src = L.data + fs + (t - L.prefix);
+          if (fs + (t - L.prefix) + 8 <= L.off[n_rows]) {
+            __builtin_memcpy(&x, src, 8);
+          } else {                                             // the last bytes of the field's buffer
+            x = 0;
+            for (int q = 0; q < m; ++q) x |= (uint64_t)src[q] << (8 * q);
+          }
+          if (L.add) {                                         // per-byte wrap-around addition without carries between bytes
+            const uint64_t a = (uint64_t)(L.add & 0xff) * 0x0101010101010101ull;
+            x = ((x & 0x7f7f7f7f7f7f7f7full) + (a & 0x7f7f7f7f7f7f7f7full)) ^ ((x ^ a) & 0x8080808080808080ull);
+          }
+        }
+        emit(x, m);
+        t += m;
       }
+      if (p < p1 && t == L.prefix + flen) emit(10, 1);
       t = 0;                                                   // the next line starts at its first byte
     }
   }
-  if (p1 - p0 == JL_BYTES_PER_LANE) {
-    *reinterpret_cast<uint64_t*>(out + p0) = word;             // (p0 is a multiple of 8, the buffer 16-byte aligned)
+  if (p1 - p0 == JL_BYTES_PER_LANE) {                          // (p0 is a multiple of 16, the buffer 16-byte aligned)
+    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)word[0], (uint32_t)(word[0] >> 32), (uint32_t)word[1], (uint32_t)(word[1] >> 32));
   } else {
-    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word >> (8 * j));
+    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
   }
 }
 
