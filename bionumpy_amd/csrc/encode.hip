@@ -127,42 +127,93 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
 }
 
 // plain gather (optionally subtracting a constant from every byte), 16 output bytes per lane
+// The rows a workgroup's 4 KiB of output come from (usually a dozen) are staged in LDS first — their offsets relative to
+// the block and their starts — with one coalesced load each: without that every lane walks a chain of six to eight
+// dependent global loads (binary search, row end, start, data) and the kernel runs at the rate of that latency
+// (0.7 TB/s); blocks with more rows than the table holds (rows of a few bytes) keep the direct path.
+constexpr int GR_ROWS = 1024;
+
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
     int64_t n_rows, int64_t total, int subtract, const int64_t* __restrict__ tile_rows,
     uint8_t* __restrict__ out) {
+  __shared__ int rel[GR_ROWS + 1];                             // offsets[rr0 + i] - blk_first (clamped below)
+  __shared__ int64_t st[GR_ROWS];                              // starts[rr0 + i]
+  __shared__ int64_t first_off;                                // offsets[rr0] (rel[0] is clamped: the row may start gigabytes back)
   int64_t rr[2];
   constexpr int PER = 16;
   int64_t blk_first = (int64_t)blockIdx.x * BNPK_BLOCK * PER;
   if (blk_first >= total) return;
   tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
+  const int n_stage = (int)min(rr[1] - rr[0] + 1, (int64_t)GR_ROWS + 1);      // rows rr0 .. rr0 + n_stage - 1 (if they all fit)
+  const bool staged = rr[1] - rr[0] + 1 <= GR_ROWS;
+  if (staged) {
+    for (int i = threadIdx.x; i <= n_stage; i += BNPK_BLOCK) {
+      const int64_t d = offsets[rr[0] + i] - blk_first;
+      rel[i] = (int)max(d, (int64_t)-(1 << 30));
+      if (i < n_stage) st[i] = starts[rr[0] + i];
+      if (i == 0) first_off = offsets[rr[0]];
+    }
+    __syncthreads();
+  }
   int64_t pos = blk_first + (int64_t)threadIdx.x * PER;
   if (pos >= total) return;
   const int64_t end = min(pos + PER, total);
-  int64_t row = find_row(offsets, rr[0], rr[1], pos);
-  int64_t row_end = offsets[row + 1];
-  const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
   uint64_t v[3] = {0, 0, 0};
   const int64_t p0 = pos;
   const uint64_t sub = (uint64_t)(subtract & 0xff) * REP01;
   int j = 0;
-  while (pos < end) {
-    while (pos >= row_end) {
-      ++row;
-      row_end = offsets[row + 1];
-      src = buf + starts[row];
+  if (staged) {
+    const int at = (int)(pos - blk_first);
+    int lo = 0, hi = n_stage - 1;                              // last i with rel[i] <= at (skips empty rows)
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo + 1) >> 1);
+      if (rel[mid] <= at) lo = mid; else hi = mid - 1;
     }
-    int seg = (int)min(row_end - pos, end - pos);
-    while (seg > 0) {
-      int m;
-      uint64_t x = load_upto8(src, seg, &m);
-      // per-byte wrap-around subtraction without borrows between bytes
-      x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
-      if (m < 8) x &= (1ull << (8 * m)) - 1ull;
-      int sh = 8 * (j & 7);
-      v[j >> 3] |= x << sh;
-      if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
-      j += m; src += m; pos += m; seg -= m;
+    int row = lo, p = at;
+    const int e = (int)(end - blk_first);
+    int row_end = rel[row + 1];
+    const uint8_t* src = buf + st[row] + (row == 0 ? pos - first_off : (int64_t)(p - rel[row]));
+    while (p < e) {
+      while (p >= row_end) {
+        ++row;
+        row_end = rel[row + 1];
+        src = buf + st[row];
+      }
+      int seg = min(row_end - p, e - p);
+      while (seg > 0) {
+        int m;
+        uint64_t x = load_upto8(src, seg, &m);
+        x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
+        if (m < 8) x &= (1ull << (8 * m)) - 1ull;
+        int sh = 8 * (j & 7);
+        v[j >> 3] |= x << sh;
+        if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
+        j += m; src += m; p += m; seg -= m;
+      }
+    }
+  } else {
+    int64_t row = find_row(offsets, rr[0], rr[1], pos);
+    int64_t row_end = offsets[row + 1];
+    const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
+    while (pos < end) {
+      while (pos >= row_end) {
+        ++row;
+        row_end = offsets[row + 1];
+        src = buf + starts[row];
+      }
+      int seg = (int)min(row_end - pos, end - pos);
+      while (seg > 0) {
+        int m;
+        uint64_t x = load_upto8(src, seg, &m);
+        // per-byte wrap-around subtraction without borrows between bytes
+        x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
+        if (m < 8) x &= (1ull << (8 * m)) - 1ull;
+        int sh = 8 * (j & 7);
+        v[j >> 3] |= x << sh;
+        if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
+        j += m; src += m; pos += m; seg -= m;
+      }
     }
   }
   if (p0 + PER <= total && (((uintptr_t)(out + p0)) & 15) == 0) {
