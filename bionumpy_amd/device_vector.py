@@ -60,6 +60,9 @@ class DeviceVector:
     def __iter__(self):
         return iter(self.host())
 
+    def __bool__(self):                                # (as numpy: ambiguous for more than one element)
+        return bool(self.host())
+
     def __getattr__(self, name):                       # anything else: the host array's (astype, tolist, mean, std, ...)
         if name.startswith("_"):
             raise AttributeError(name)
