@@ -1,6 +1,4 @@
 """NpDataclassReader: what ``bnp.open`` returns (bionumpy/io/npdataclassreader.py:14-142)."""
-from itertools import takewhile, repeat
-
 from ..exceptions import FormatException
 from ..streams import NpDataclassStream
 
@@ -44,8 +42,18 @@ class NpDataclassReader:
             raise e
 
     def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
-        data_stream = takewhile(len, (self.read_chunk(min_chunk_size, max_chunk_size) for _ in repeat(None)))
-        return NpDataclassStream(data_stream, dataclass=self._reader._buffer_type.dataclass)
+        def chunks():                                  # the file reader's own generator: it reads ahead for big batches
+            for chunk in self._reader.read_chunks(min_chunk_size, max_chunk_size):
+                n_lines_read = self._reader.n_lines_read - chunk.n_lines
+                try:
+                    wrapped = self._wrap(chunk, n_lines_read)
+                except FormatException as e:
+                    e.line_number += n_lines_read
+                    raise e
+                if len(wrapped) == 0:
+                    return
+                yield wrapped
+        return NpDataclassStream(chunks(), dataclass=self._reader._buffer_type.dataclass)
 
     def __iter__(self):
         return self.read_chunks()

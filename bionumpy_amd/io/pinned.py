@@ -7,6 +7,7 @@ This replaces ``np.frombuffer(file.read(n))`` + ``cp.asanyarray(chunk)`` of the 
 (bionumpy/io/parser.py:203-206, bionumpy/cupy_compatible/parser.py:11-17).
 """
 import ctypes as C
+import threading
 import weakref
 
 import numpy as np
@@ -37,12 +38,40 @@ class PinnedBuffer:
             self.wait()
             lib.bnpk_host_free(self.ptr)
             self.ptr = None
+            self.array = np.zeros(0, dtype=np.uint8)   # (no view of freed memory is handed out again)
 
     def __del__(self):
         try:
             self.free()
         except Exception:
             pass
+
+
+# Page-locking a gigabyte costs ~0.1 s: buffers a reader gives back are kept for the next reader of the process (up to
+# _CACHE_BYTES), so that opening a file does not pay for its staging again.
+_CACHE_BYTES = 8 << 30
+_cache, _cache_lock = [], threading.Lock()
+
+
+def _from_cache(nbytes):
+    with _cache_lock:
+        fits = [b for b in _cache if b.ptr and b.nbytes >= nbytes]
+        if not fits:
+            return None
+        buf = min(fits, key=lambda b: b.nbytes)
+        _cache.remove(buf)
+        return buf
+
+
+def _to_cache(buf):
+    if not buf.ptr:                # already freed (the collector may finalise a buffer before the pool that holds it)
+        return
+    buf.wait()
+    with _cache_lock:
+        if sum(b.nbytes for b in _cache) + buf.nbytes <= _CACHE_BYTES:
+            _cache.append(buf)
+            return
+    buf.free()
 
 
 class PinnedPool:
@@ -61,16 +90,22 @@ class PinnedPool:
             buf.wait()
         if buf is None or buf.nbytes < nbytes:
             if buf is not None:
-                buf.free()
-            buf = PinnedBuffer(max(nbytes + (nbytes >> 3), 1 << 20))
+                _to_cache(buf)
+            buf = _from_cache(nbytes) or PinnedBuffer(max(nbytes + (nbytes >> 3), 1 << 20))
             self._buffers[i] = buf
         return buf
 
     def release(self):
         for i, buf in enumerate(self._buffers):
             if buf is not None:
-                buf.free()
+                _to_cache(buf)
                 self._buffers[i] = None
+
+    def __del__(self):                                 # a reader dropped without close() still hands its buffers on
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 def owner_of(array):

@@ -1,0 +1,102 @@
+"""The reader's path for big batches of a plain file (io/parser.py: parallel ``preadv`` into the staging buffer, a
+background thread that reads the next batch's bytes while the current one is parsed): with the thresholds turned down it
+must deliver the same entries as the serial path — long entries, batches without a complete entry, a file that ends on a
+batch boundary, no final newline, an abandoned iteration."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from backends import bnp  # noqa: E402,F401
+
+
+def _fastq(rng, n, max_len, final_newline=True):
+    parts = []
+    for i in range(n):
+        ln = int(rng.integers(1, max_len))
+        seq = "".join(rng.choice(list("ACGT"), size=ln))
+        parts.append("@read%d\n%s\n+\n%s\n" % (i, seq, "I" * ln))
+    text = "".join(parts)
+    return text if final_newline else text[:-1]
+
+
+@pytest.fixture
+def small_thresholds(monkeypatch):
+    from bionumpy_amd.io import parser
+    monkeypatch.setattr(parser, "_BIG", 1 << 12)
+    monkeypatch.setattr(parser, "_FRONT", 1 << 9)
+    monkeypatch.setattr(parser, "_READ_THREADS", 4)
+    return parser
+
+
+@pytest.mark.parametrize("seed,n,max_len,chunk,final_newline", [
+    (1, 400, 60, 5000, True), (2, 400, 60, 4096, False), (3, 50, 3000, 4096, True), (4, 30, 20000, 8192, True),
+    (5, 1, 50, 4096, True), (6, 300, 100, 1 << 16, True)])
+def test_big_batch_path_delivers_the_entries_of_the_serial_path(bnp, small_thresholds, tmp_path, seed, n, max_len, chunk,
+                                                               final_newline):
+    rng = np.random.default_rng(seed)
+    text = _fastq(rng, n, max_len, final_newline)
+    path = tmp_path / "reads.fq"
+    path.write_text(text)
+    serial = bnp.open(str(path)).read()
+    got_names, got_seqs, n_chunks = [], [], 0
+    reader = bnp.open(str(path))
+    for c in reader.read_chunks(min_chunk_size=chunk):
+        got_names += c.name.tolist()
+        got_seqs += c.sequence.tolist()
+        n_chunks += 1
+    assert got_names == serial.name.tolist() and got_seqs == serial.sequence.tolist()
+    assert n_chunks >= 1 and reader._reader.n_lines_read == 4 * n
+    # the file ends exactly where a batch ends: a last entry padded so that the size is a multiple of the batch size
+    head = _fastq(np.random.default_rng(seed + 100), 64, 40)
+    name = "@z" if (len(head) + len("@z\n\n+\n\n")) % 2 == 0 else "@zz"
+    fixed = len(head) + len(name) + 5                        # name, four newlines, '+'
+    pad = ((-fixed) % chunk) // 2
+    pad = pad if pad > 0 else chunk // 2
+    exact = head + "%s\n%s\n+\n%s\n" % (name, "A" * pad, "I" * pad)
+    assert len(exact) % chunk == 0
+    path2 = tmp_path / "exact.fq"
+    path2.write_text(exact)
+    want = bnp.open(str(path2)).read().sequence.tolist()
+    got = []
+    for c in bnp.open(str(path2)).read_chunks(min_chunk_size=chunk):
+        got += c.sequence.tolist()
+    assert got == want
+
+
+def test_abandoned_iteration_keeps_the_rest_of_the_file(bnp, small_thresholds, tmp_path):
+    rng = np.random.default_rng(9)
+    text = _fastq(rng, 500, 80)
+    path = tmp_path / "reads.fq"
+    path.write_text(text)
+    whole = bnp.open(str(path)).read().sequence.tolist()
+    reader = bnp.open(str(path))
+    seqs = []
+    for i, c in enumerate(reader.read_chunks(min_chunk_size=6000)):
+        seqs += c.sequence.tolist()
+        if i == 1:
+            break                                            # leaves a read-ahead behind
+    rest = reader.read_chunks(min_chunk_size=6000)
+    for c in rest:
+        seqs += c.sequence.tolist()
+    reader.close()
+    assert seqs == whole
+
+
+def test_parallel_fill_reads_what_readinto_reads(small_thresholds, tmp_path):
+    parser = small_thresholds
+    data = np.random.default_rng(3).integers(0, 255, size=70_001, dtype=np.uint8)
+    path = tmp_path / "blob.bin"
+    data.tofile(path)
+    r = parser.NumpyFileReader.__new__(parser.NumpyFileReader)
+    r._file_obj = open(path, "rb")
+    r._stream_mode = False
+    r._f_name = str(path)
+    out = np.zeros(50_000, dtype=np.uint8)
+    assert r._fill(out) == 50_000 and np.array_equal(out, data[:50_000])
+    out2 = np.zeros(50_000, dtype=np.uint8)
+    assert r._fill(out2) == 20_001 and np.array_equal(out2[:20_001], data[50_000:])
+    assert r._fill(out2) == 0
+    r._file_obj.close()
