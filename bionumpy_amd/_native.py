@@ -90,6 +90,8 @@ SIGNATURES = {
     "bnpk_mask_logic": (_int, [_p, _p, _p, _i64, _int, _p, _p]),
     "bnpk_mask_fill": (_int, [_p, _p, _i64, _i64, _i64, _i64, _int, _p]),
     "bnpk_take_i64": (_int, [_p, _p, _p, _i64, _p, _p]),
+    "bnpk_entry_table": (_int, [_p, _p, _int, _p, _i64, _p, _p, _p]),
+    "bnpk_join_line_lens": (_int, [_p, _i64, _int, _p, _p, _p, _p]),
     "bnpk_reverse_complement_packed": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_reverse_complement_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_canonical_kmers": (_int, [_p, _p, _i64, _int, _p]),

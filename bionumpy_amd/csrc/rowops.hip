@@ -103,6 +103,33 @@ __global__ void mask_logic_kernel(const uint8_t* __restrict__ a, const uint8_t* 
   }
 }
 
+// whole entries `rows` of a one-line-per-field buffer: starts[i] = byte behind the newline in front of entry rows[i] (0 for
+// entry 0), lens[i] = through the newline of its last line
+__global__ void entry_table_kernel(const int64_t* __restrict__ nl, int lpe, const int64_t* __restrict__ rows, int64_t m,
+                                   int64_t* __restrict__ starts, int64_t* __restrict__ lens) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < m; i += stride) {
+    const int64_t first = rows[i] * lpe;
+    const int64_t s = first > 0 ? nl[first - 1] + 1 : 0;
+    starts[i] = s;
+    lens[i] = nl[first + lpe - 1] + 1 - s;
+  }
+}
+
+struct jl_offsets { const int64_t* off[4]; int extra[4]; };    // per line: row offsets of its field (nullptr: one byte), prefix + newline
+
+// bytes of entry r when its lines are written out: sum over the lines of (field row length | 1) + prefix + 1
+__global__ void join_line_lens_kernel(jl_offsets lines, int n_lines, int64_t n_rows, int64_t* __restrict__ lens) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; r < n_rows; r += stride) {
+    int64_t total = 0;
+    for (int i = 0; i < n_lines; ++i) total += (lines.off[i] ? lines.off[i][r + 1] - lines.off[i][r] : 1) + lines.extra[i];
+    lens[r] = total;
+  }
+}
+
 __global__ void take_i64_kernel(const int64_t* __restrict__ arr, const int64_t* __restrict__ idx, int64_t m,
                                 int64_t* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,6 +180,34 @@ int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "mask_logic", s);
   hipLaunchKernelGGL(mask_logic_kernel, dim3(grid_for(ceil_div(n, 256))), dim3(256), 0, s, d_a, op == 3 ? nullptr : d_b, n, op, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_entry_table(bnpk_ctx* ctx, const int64_t* d_newlines, int lines_per_entry, const int64_t* d_rows, int64_t m,
+                     int64_t* d_starts, int64_t* d_lens, void* stream) {
+  if (!ctx || m < 0 || lines_per_entry < 1 || (m > 0 && (!d_newlines || !d_rows || !d_starts || !d_lens))) return BNPK_ERR_ARG;
+  if (m == 0) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "entry_table", s);
+  hipLaunchKernelGGL(entry_table_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_newlines, lines_per_entry, d_rows, m,
+                     d_starts, d_lens);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_join_line_lens(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const int64_t* const* d_field_offsets, const int* prefix,
+                        int64_t* d_lens, void* stream) {
+  if (!ctx || n_rows < 0 || n_lines < 1 || n_lines > 4 || !d_field_offsets || !prefix || (n_rows > 0 && !d_lens)) return BNPK_ERR_ARG;
+  if (n_rows == 0) return BNPK_OK;
+  jl_offsets lines;
+  for (int i = 0; i < 4; ++i) {
+    lines.off[i] = i < n_lines ? d_field_offsets[i] : nullptr;
+    lines.extra[i] = i < n_lines ? prefix[i] + 1 : 0;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "join_line_lens", s);
+  hipLaunchKernelGGL(join_line_lens_kernel, dim3(grid_for(ceil_div(n_rows, 256))), dim3(256), 0, s, lines, n_lines, n_rows, d_lens);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -150,12 +150,11 @@ class HipOps:
     def entry_table(self, newlines, lines_per_entry, rows):
         """(starts, lens) of whole entries ``rows`` (header byte .. newline of the last line): index arithmetic on the
         newline table (device tensors; io/file_buffers.py:426-440 keeps entry_starts / entry_ends for this)"""
-        t = torch_mod()
-        nl, r = newlines.dev(), rows.dev()
-        first = r * lines_per_entry
-        starts = t.where(first > 0, nl[(first - 1).clamp(min=0)] + 1, t.zeros_like(first))
-        ends = nl[first + (lines_per_entry - 1)] + 1
-        return HArray(dev=starts.contiguous()), HArray(dev=(ends - starts).contiguous())
+        m = rows.size
+        starts, lens = self._empty(m, np.int64), self._empty(m, np.int64)
+        self._chk(lib.bnpk_entry_table(self.ctx, ptr(newlines.dev()), lines_per_entry, ptr(rows.dev()), m, ptr(starts),
+                                       ptr(lens), self._s()))
+        return HArray(dev=starts), HArray(dev=lens)
 
     def take_bytes(self, buf, positions, delta):
         m = positions.size
@@ -368,19 +367,15 @@ class HipOps:
     def join_lines(self, n_rows, lines, header):
         """lines: per line (data HArray | None, offsets HArray | None, add, prefix, fill byte).  Returns the text
         (HArray uint8) of all entries: every line = prefix header bytes + field row (+ add) + newline."""
-        t = torch_mod()
-        lens = None
-        for data, off, add, prefix, fill in lines:
-            ln = (off.dev()[1:] - off.dev()[:-1]) if data is not None else None
-            part = (ln + (prefix + 1)) if ln is not None else t.full((n_rows,), prefix + 2, dtype=t.int64, device=self.device.tdev)
-            lens = part if lens is None else lens + part
-        entry_off, total = self.row_offsets(HArray(dev=lens.contiguous()), 1)
-        out = self._empty(total, np.uint8)
         n = len(lines)
-        datas = (C.c_void_p * n)(*[ptr(d.dev()) if d is not None else None for d, _, _, _, _ in lines])
         offs = (C.c_void_p * n)(*[ptr(o.dev()) if o is not None else None for _, o, _, _, _ in lines])
-        adds = (C.c_int * n)(*[int(a) for _, _, a, _, _ in lines])
         prefixes = (C.c_int * n)(*[int(p) for _, _, _, p, _ in lines])
+        lens = self._empty(n_rows, np.int64)
+        self._chk(lib.bnpk_join_line_lens(self.ctx, n_rows, n, offs, prefixes, ptr(lens), self._s()))
+        entry_off, total = self.row_offsets(HArray(dev=lens), 1)
+        out = self._empty(total, np.uint8)
+        datas = (C.c_void_p * n)(*[ptr(d.dev()) if d is not None else None for d, _, _, _, _ in lines])
+        adds = (C.c_int * n)(*[int(a) for _, _, a, _, _ in lines])
         fills = (C.c_uint8 * n)(*[int(f) for _, _, _, _, f in lines])
         self._chk(lib.bnpk_join_lines(self.ctx, n_rows, n, datas, offs, adds, prefixes, fills, header, ptr(entry_off.dev()),
                                       total, ptr(out), self._s()))

@@ -223,6 +223,18 @@ int bnpk_mask_logic(bnpk_ctx* ctx, const uint8_t* d_a, const uint8_t* d_b, int64
 int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int64_t step, int64_t count, int value, void* stream);
 int bnpk_take_i64(bnpk_ctx* ctx, const int64_t* d_arr, const int64_t* d_idx, int64_t m, int64_t* d_out, void* stream);
 
+/* The index arithmetic of the write-back path:
+ *   bnpk_entry_table     whole entries d_rows[i] of a one-line-per-field buffer: d_starts[i] = the byte behind the newline
+ *                        in front of the entry (0 for entry 0), d_lens[i] = through the newline of its last line —
+ *                        TextThroughputExtractor's entry_starts / entry_ends (bionumpy/io/file_buffers.py:426-440)
+ *   bnpk_join_line_lens  d_lens[r] = bytes of entry r once its lines are written out: per line the field's row length (one
+ *                        byte for a line without a field) + prefix[i] header bytes + the newline — the `lengths`
+ *                        OneLineBuffer.join_fields sums up (bionumpy/io/one_line_buffer.py:119-134); input of bnpk_join_lines */
+int bnpk_entry_table(bnpk_ctx* ctx, const int64_t* d_newlines, int lines_per_entry, const int64_t* d_rows, int64_t m,
+                     int64_t* d_starts, int64_t* d_lens, void* stream);
+int bnpk_join_line_lens(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const int64_t* const* d_field_offsets, const int* prefix,
+                        int64_t* d_lens, void* stream);
+
 /* Per-column sums of ragged uint8 data: np.sum / np.mean(ragged, axis=0) (scripts/small_example.py:20-22,49-52).
  * d_sums[c] = sum over the rows with more than c elements of their element c, d_counts[c] = number of such rows,
  * c < n_cols (= the longest row). */
