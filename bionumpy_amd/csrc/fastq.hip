@@ -1,4 +1,4 @@
-// Fused FASTQ / two-line-FASTA decode for the k-mer pipeline (A2-A7 in one read of the text after a census):
+// Fused FASTQ / two-line-FASTA decode for the k-mer pipeline (A2-A7 in two reads of the text):
 // newline scan, entry validation, sequence-line extraction and ASCII -> 2-bit packing without ever materialising
 // the newline table, the field tables or the row offsets.
 //
@@ -6,11 +6,15 @@
 //           each phase (line index mod lines_per_entry, relative to the tile's first line); after a scan of the
 //           newline counts every tile knows its absolute first line, picks "its" sequence-byte count and a second
 //           scan gives every tile the flat base index its sequence bytes start at
-//   encode  (reads the text once)  per tile: classify every byte by the phase of its line, rank the sequence
-//           bytes (wave scans), validate the first byte of header / '+' lines, 2-bit encode into an LDS staging
-//           area aligned like the global packed words, mark read ends in a bit mask, write both out (interior
-//           words with plain stores, the two edge words shared with the neighbouring tiles with atomicOr)
+//   encode  (reads the text once)  per tile: the sequence bytes 2-bit encoded into an LDS staging area aligned like the
+//           global packed words, read ends marked in a bit mask, the first byte of header / '+' lines validated, both
+//           written out (interior words with plain stores, the edge word shared with the neighbouring tile OR-ed)
 //   starts  bit-parallel pass over the read-end mask: a k-mer starts at base i iff no read ends in [i, i+k-2]
+//
+// Census and encode each come as a general kernel (every lane classifies its own 16 bytes, whatever the line structure
+// is) and a fast kernel (newline masks per byte, bookkeeping per line / per entry, dense lanes for the base runs,
+// persistent workgroups with the next tile's text in flight) that takes all tiles but the odd ones and hands those to
+// the general kernel through a list; see the comments at the kernels.  Same bits either way.
 //
 // Equivalent reference expressions: OneLineBuffer.from_raw_buffer + _validate (io/one_line_buffer.py:45-71,156-173,
 // io/fastq_buffer.py:39-45), _get_buffer_extractor + get_field_by_number(1) (io/one_line_buffer.py:140-152,
