@@ -52,24 +52,23 @@ class DeBruijnGraph:
         hi = ops.search_sorted(self._kmer_set, q, upper=True).host()
         return hi > lo
 
-    def _get_previous(self, kmer):                 # debruin.py:20-23
-        mask = 4 ** self._k - 1
-        base = (kmer << 2) & mask
-        return [base + i for i in range(4)]
-
-    def _get_next(self, kmer):                     # debruin.py:25-27
-        base = kmer >> 2
-        return [base + (i << (2 * (self._k - 1))) for i in range(4)]
+    def _neighbours(self, kmer, forward):
+        """the four k-mers that can follow (precede) ``kmer``: its last k - 1 bases shifted down and every base on top, or its
+        first k - 1 bases shifted up and every base below (debruin.py:20-27), as one int64 vector"""
+        bases = np.arange(4, dtype=np.int64)
+        if forward:
+            return (int(kmer) >> 2) + (bases << (2 * (self._k - 1)))
+        return ((int(kmer) << 2) & (4 ** self._k - 1)) + bases
 
     def _present(self, candidates):
-        found = self.contains(np.asarray(candidates, dtype=np.int64))
-        return [self._kmer_encoding.to_string(c) for c, f in zip(candidates, found) if f]
+        found = self.contains(candidates)
+        return [self._kmer_encoding.to_string(int(c)) for c, f in zip(candidates, found) if f]
 
     def forward(self, kmer):
-        return self._present(self._get_next(self._hash(kmer)))
+        return self._present(self._neighbours(self._hash(kmer), True))
 
     def backward(self, kmer):
-        return self._present(self._get_previous(self._hash(kmer)))
+        return self._present(self._neighbours(self._hash(kmer), False))
 
 
 class ColoredDeBruijnGraph:
