@@ -226,6 +226,16 @@ class AlphabetEncoding(OneToOneEncoding):
 
 ACGTEncoding = AlphabetEncoding("ACGT")
 DNAEncoding = ACGTEncoding
+# the other named alphabets of the reference (encodings/alphabet_encoding.py:102-111); everything but ACGT takes the
+# generic look-up / dot-product kernels (bnpk_lut_bytes, bnpk_kmers_generic)
+ACTGEncoding = AlphabetEncoding("ACTG")
+ACTGnEncoding = AlphabetEncoding("ACTGn")
+ACGTnEncoding = AlphabetEncoding("ACGTn")
+DigitEncoding = AlphabetEncoding("0123456789")
+ACUGEncoding = AlphabetEncoding("ACUG")
+RNAENcoding = ACUGEncoding
+AminoAcidEncoding = AlphabetEncoding("ACDEFGHIKLMNPQRSTVWY*")
+BamEncoding = AlphabetEncoding("=ACMGRSVTWYHKDBN")
 
 
 class _PackedDna:

@@ -41,6 +41,28 @@ def test_get_kmers_docstring(bnp):
                            "                      [TTG, TGG, GGC]], 3merEncoding(AlphabetEncoding('ACGT')))")
 
 
+def test_named_alphabets_of_the_reference(bnp):
+    # encodings/alphabet_encoding.py:102-111: the names a caller of the reference imports, with the reference's semantics
+    assert bnp.as_encoded_array("acgtn", bnp.ACGTnEncoding).raw().tolist() == [0, 1, 2, 3, 4]
+    assert bnp.as_encoded_array("ACTG", bnp.ACTGEncoding).raw().tolist() == [0, 1, 2, 3]
+    assert bnp.as_encoded_array("acug", bnp.RNAENcoding).raw().tolist() == [0, 1, 2, 3] and bnp.RNAENcoding is bnp.ACUGEncoding
+    assert bnp.as_encoded_array("0917", bnp.DigitEncoding).raw().tolist() == [0, 9, 1, 7]
+    prot = bnp.as_encoded_array(["MKV*", "ACDW"], bnp.AminoAcidEncoding)
+    labels = bnp.AminoAcidEncoding.get_labels()
+    assert [[labels[c] for c in row] for row in prot.raw()] == [list("MKV*"), list("ACDW")] and prot.tolist() == ["MKV*", "ACDW"]
+    assert bnp.as_encoded_array("=ACMN", bnp.BamEncoding).raw().tolist() == [0, 1, 2, 3, 15]
+    with pytest.raises(bnp.EncodingError):
+        bnp.as_encoded_array("ACGU", bnp.ACGTnEncoding)
+    # k-mers over a five-letter alphabet: the generic kernel against the oracle
+    reads = ["ACGTNNACGT", "NNN", "GATTACA"]
+    seqs = bnp.as_encoded_array(reads, bnp.ACGTnEncoding)
+    codes = np.concatenate([np.array(["ACGTN".index(c) for c in r], dtype=np.uint8) for r in reads])
+    expect, lens = oracle.get_kmers_generic(codes, np.array([len(r) for r in reads]), 3, 5)
+    kmers = bnp.sequence.get_kmers(seqs, 3)
+    assert np.array_equal(np.concatenate([np.asarray(r) for r in kmers.raw()]), expect) and [len(r) for r in kmers] == lens.tolist()
+    assert str(kmers[0][0]) == "ACG" and str(kmers[1][0]) == "NNN"
+
+
 def test_generic_alphabets(bnp):
     # any AlphabetEncoding encodes (encodings/alphabet_encoding.py:19-46) and hashes (sequence/kmers.py:17-27,82-87)
     acgtn = bnp.AlphabetEncoding("ACGTN")
