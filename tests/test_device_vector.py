@@ -24,7 +24,7 @@ _floats = st.lists(st.one_of(st.floats(-100, 100, allow_nan=False), st.just(floa
 _ops = st.sampled_from(["<", "<=", ">", ">=", "==", "!="])
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(values=_floats, op=_ops, scalar=st.one_of(st.floats(-100, 100, allow_nan=False), st.integers(-5, 5)),
        start=st.integers(0, 40), step=st.integers(1, 7), fill=st.booleans())
 def test_float_vector_compares_and_masks_like_numpy(bnp, values, op, scalar, start, step, fill):
@@ -53,7 +53,7 @@ def test_float_vector_compares_and_masks_like_numpy(bnp, values, op, scalar, sta
         assert np.array_equal(np.isnan(dv), np.isnan(a))
 
 
-@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@settings(max_examples=40, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(values=st.lists(st.integers(0, 255), min_size=0, max_size=300), op=_ops,
        scalar=st.one_of(st.integers(-3, 260), st.floats(-3, 260, allow_nan=False)))
 def test_uint8_and_int64_vectors_compare_like_numpy(bnp, values, op, scalar):
