@@ -39,7 +39,9 @@ struct bnpk_ctx {
   // finishing kernels (finish.hip): launch attributes set / co-resident workgroups of the fast kernel / forced path
   bool finish_ready = false;
   int finish_fast_grid = 0;
-  int finish_mode = 0;           // 0 = choose per call, 1 = general kernel only, 2 = fast kernel + redo list only
+  int finish_mode = 0;           // 0 = choose per call, 1 = general kernel only, 2 = fast kernel + redo list only, 3 = duplicate-aware only
+  bool finish_dup_ready = false; // finish_dup.hip: launch attributes set / co-resident workgroups
+  int finish_dup_grid = 0;
   int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
 };
 

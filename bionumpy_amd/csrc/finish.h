@@ -1,0 +1,28 @@
+// Internal: what the finishing kernels of the sparse k-mer histogram share (finish.hip, finish_dup.hip).
+#pragma once
+#include "common.h"
+
+// d_state header words.  [0] flags (1 = over-capacity bucket without a pre-counted entry, 2 = the general kernel's
+// look-back gave up, 4 = too many buckets with duplicates for the fast kernel), [1] ticket counter of the general
+// kernel, [2] distinct keys, [3] redo list length, [4] announcements of the fast kernel, [5] buckets only the general
+// kernel holds; the fast kernel's ticket counter has a 128-byte line of its own ([96, 112)); the per-bucket arrays
+// start at word FS_FAST.
+constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_LOG = 8;
+constexpr int FS_FTICKET = 96, FS_FAST = 112;
+
+// most keys a bucket may hold (the general kernel and the duplicate-aware kernel; the fast kernel takes 7680)
+constexpr int FINISH_CAP = 8192;
+
+// Duplicate-aware finishing (finish_dup.hip).  `part` is read AND overwritten: every bucket's sorted distinct keys are
+// first written back over the bucket's own keys (a bucket never has more distinct keys than keys), their counts to the
+// same positions of `loose_counts`, and D[b] = its number of distinct keys to Dv[b]; buckets the kernel gives up on
+// (more distinct keys than its table holds, long probe sequences) are appended to redo_ids / header[FS_REDO] with
+// Dv[b] = 0 for the general kernel to finish the same way.
+int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
+                           unsigned long long* header, int64_t* Dv, unsigned* redo_ids, int64_t* loose_counts,
+                           const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
+                           hipStream_t s);
+// dst[T[b] + i] = src[bucket_off[b] + i] for i < T[b + 1] - T[b]: the loose per-bucket runs moved to their final place
+// (src and dst must be different buffers); header[FS_UNIQUE] = T[n_buckets].
+int bnpk_finish_compact_launch(bnpk_ctx* ctx, const int64_t* src, int64_t* dst, const int64_t* bucket_off, const int64_t* T,
+                               int64_t n_buckets, unsigned long long* header, hipStream_t s);

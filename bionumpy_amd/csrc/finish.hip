@@ -5,7 +5,7 @@
 // finish_sorted_kernel (any multiplicities; also works off the fast kernel's redo list).
 #include <algorithm>
 
-#include "common.h"
+#include "finish.h"
 #include "scan.h"
 
 namespace {
@@ -18,7 +18,7 @@ namespace {
 // by wavefront 0 (64 predecessors per poll) while the other wavefronts rank the bucket's keys, so its latency
 // is hidden.  The next bucket's keys are loaded while the current one is processed.
 constexpr int FN_THREADS = 1024;
-constexpr int FN_CAP = 8192;
+constexpr int FN_CAP = FINISH_CAP;
 constexpr int FN_ITEMS = FN_CAP / FN_THREADS;
 constexpr int FN_MAXBITS = 12;
 constexpr int FN_MAXBINS = 1 << FN_MAXBITS;
@@ -26,9 +26,9 @@ constexpr int FN_WORDS = FN_CAP / 64;                // first-occurrence mask wo
 constexpr int FN_WPL = FN_WORDS / 64;                // ... per lane of a wavefront
 constexpr int FN_BINS_PER_LANE = FN_MAXBINS / FN_THREADS;
 static_assert(FN_WPL == 1 || FN_WPL == 2, "the mask-prefix code below keeps one or two mask words per lane");
-// d_state words: [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
+// d_state words (finish.h): [0] error flags (1 = bucket over capacity, 2 = look-back gave up), [1] ticket counter,
 // [2] number of distinct keys, [8 + b] status word of bucket b
-constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_BUCKETS = 8;
+constexpr int FS_BUCKETS = 8;
 constexpr unsigned long long FN_AGG = 1ull << 62, FN_INC = 2ull << 62, FN_VALUE = (1ull << 62) - 1;
 constexpr unsigned FN_SPIN_LIMIT = 1u << 22;
 #ifndef FN_SLEEP
@@ -86,7 +86,11 @@ __device__ __forceinline__ fn_bucket fn_open(int64_t n_buckets, int64_t b, int64
   return x;
 }
 
-template <bool REDO>
+// MODE 0: every bucket, output positions by look-back.  MODE 1 (redo): the buckets of a list, at the positions given with
+// it.  MODE 2 (loose): the buckets of a list whose length is read from the state on the device (the duplicate-aware
+// kernel's hand-backs); every bucket's distinct keys go back over the bucket's own keys (keys_out == A), the counts to
+// the same positions of counts_out, its number of distinct keys to loose_D — finish_dup.hip's convention.
+template <int MODE>
 __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_t* __restrict__ A,
                                                                    const int64_t* __restrict__ bucket_off,
                                                                    int64_t n_buckets, int sshift, int sbits,
@@ -98,7 +102,9 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
                                                                    const int64_t* __restrict__ big_counts,
                                                                    const unsigned* __restrict__ redo_ids,
                                                                    const int64_t* __restrict__ redo_bases,
-                                                                   int64_t n_redo) {
+                                                                   int64_t n_redo_arg, int64_t* __restrict__ loose_D) {
+  constexpr bool REDO = MODE != 0, LOOSE = MODE == 2;
+  const int64_t n_redo = LOOSE ? fn_uniform((int64_t)state[FS_REDO]) : n_redo_arg;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   unsigned* bins = reinterpret_cast<unsigned*>(smem + FN_OFF_BINS);            // bins of the bucket being sorted
@@ -209,6 +215,10 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   int64_t prev_b = 0, prev_t = 0, prev_big = -1;
   unsigned prev_D = 0;
   auto resolve_prev = [&]() {                          // wavefront 0: where the previous bucket's output goes
+    if (LOOSE) {
+      if (lane == 0) { sh[1] = bucket_off[prev_b]; loose_D[prev_b] = prev_D; }
+      return;
+    }
     if (REDO) {
       if (lane == 0) sh[1] = redo_bases[prev_t];
       return;
@@ -582,7 +592,7 @@ static_assert(FF_CAP <= (1 << 13), "slot / rank are packed in 13 bits");
 // redo list (ids, bases).
 // The fast kernel's ticket counter has a 128-byte line of its own ([96, 112)): every workgroup hits it once per bucket,
 // and the flags / announcements, which every workgroup reads once per bucket, must not share a line with it.
-constexpr int FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_LOG = 8, FS_SPARE [[maybe_unused]] = FS_LOG + FF_LOG, FS_FTICKET = 96, FS_FAST = 112;
+constexpr int FS_SPARE [[maybe_unused]] = FS_LOG + FF_LOG;
 constexpr unsigned FF_BAD = 0x80000000u;
 
 template <int N> struct ff_int { static constexpr int value = N; };
@@ -1023,7 +1033,7 @@ int64_t bnpk_finish_state_words(int64_t n_buckets) {
   return FS_FAST + (n + 1) + 3 * fs_half(n) + n + (n + 1) + 8;
 }
 
-int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
+int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                        const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream) {
@@ -1033,13 +1043,16 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
   *h_n_unique = 0;
   *h_overflow = 0;
   if (n == 0) return BNPK_OK;
-  if (!d_part || !d_keys_out || !d_counts_out || d_keys_out == d_part) return BNPK_ERR_ARG;
+  if (!d_part || !d_keys_out || !d_counts_out || d_keys_out == d_part || d_counts_out == d_part || d_counts_out == d_keys_out)
+    return BNPK_ERR_ARG;
   if (n_buckets >= (1ll << 31)) return BNPK_ERR_RANGE;
   hipStream_t s = (hipStream_t)stream;
   if (!ctx->finish_ready) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)FN_LDS));
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)FN_LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_sorted_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)FN_LDS));
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)FF_LDS));
@@ -1059,7 +1072,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
   unsigned* redo_ids = marks + 2 * fs_half(n_buckets);
   int64_t* redo_bases = reinterpret_cast<int64_t*>(redo_ids + 2 * fs_half(n_buckets));
   int64_t* out_off_buf = redo_bases + n_buckets;
-  const uint64_t* part = reinterpret_cast<const uint64_t*>(d_part);
+  uint64_t* part = reinterpret_cast<uint64_t*>(d_part);
   uint64_t* keys_out = reinterpret_cast<uint64_t*>(d_keys_out);
   const uint64_t* big_keys = reinterpret_cast<const uint64_t*>(d_big_keys);
   int64_t host[6] = {0, 0, 0, 0, 0, 0};
@@ -1074,31 +1087,58 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
     const unsigned grid = (unsigned)std::min<int64_t>(redo ? n_redo : n_buckets, (int64_t)ctx->compute_units);
     if (redo) {
       BNPK_HIP(ctx, hipMemsetAsync(state + FS_TICKET, 0, 8, s));
-      hipLaunchKernelGGL(finish_sorted_kernel<true>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
+      hipLaunchKernelGGL(finish_sorted_kernel<1>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
                          n_buckets, sshift, sbits, state, keys_out, d_counts_out, d_big_table, n_big, big_keys,
-                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)redo_bases, n_redo);
+                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)redo_bases, n_redo, (int64_t*)nullptr);
     } else {
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)(FS_BUCKETS + n_buckets + 1) * 8, s));
-      hipLaunchKernelGGL(finish_sorted_kernel<false>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
+      hipLaunchKernelGGL(finish_sorted_kernel<0>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
                          n_buckets, sshift, sbits, state, keys_out, d_counts_out, d_big_table, n_big, big_keys,
-                         d_big_counts, (const unsigned*)nullptr, (const int64_t*)nullptr, (int64_t)0);
+                         d_big_counts, (const unsigned*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr);
     }
     BNPK_HIP(ctx, hipGetLastError());
     return BNPK_OK;
   };
   void* scan_scratch = nullptr;
-  bool use_general = ctx->finish_mode == 1 || n_big > FF_MAXBIG;
+  // The duplicate-aware path (finish_dup.hip): every bucket's distinct keys back over its own keys, the counts to the same
+  // positions of the key array, the buckets it hands back finished the same way by the general kernel (its list length
+  // is read on the device: no host round trip), one scan over the distinct counts, two copies into place.
+  auto duplicate_aware = [&]() -> int {
+    BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+    BNPK_CHECK(bnpk_finish_dup_launch(ctx, part, d_bucket_offsets, n_buckets, low_bits, state, Dv, redo_ids, d_keys_out,
+                                      d_big_table, n_big, big_keys, d_big_counts, s));
+    {
+      const int sbits = std::min(low_bits, FN_MAXBITS), sshift = low_bits - sbits;
+      const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
+      hipLaunchKernelGGL(finish_sorted_kernel<2>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, (const uint64_t*)part,
+                         d_bucket_offsets, n_buckets, sshift, sbits, state, part, d_keys_out, d_big_table, n_big, big_keys,
+                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)nullptr, (int64_t)0, Dv);
+      BNPK_HIP(ctx, hipGetLastError());
+    }
+    BNPK_CHECK(bnpk_scan_launch(ctx, Dv, n_buckets, 1, Dv, true, (int64_t*)scan_scratch, s));
+    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_keys_out, d_counts_out, d_bucket_offsets, Dv, n_buckets, state, s));
+    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_part, d_keys_out, d_bucket_offsets, Dv, n_buckets, state, s));
+    return BNPK_OK;
+  };
+  // finish_mode: 0 = the fast kernel first (it gives up within a bucket per workgroup when keys repeat), then the
+  // duplicate-aware path; 1 = general kernel only; 2 = fast kernel + redo list, general kernel if it gives up;
+  // 3 = duplicate-aware path only
+  const int mode = ctx->finish_mode;
+  bool use_general = mode == 1, use_dup = mode == 3;
+  bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
+  if (!try_fast && mode == 0) use_dup = true;
+  if (!try_fast && mode == 2) use_general = true;
   if (!use_general) BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
-    if (!use_general) {
+    if (try_fast) {
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
                          d_bucket_offsets, n_buckets, state);
       BNPK_CHECK(read_header());
-      use_general = host[FS_MISFIT] != 0;
+      if (host[FS_MISFIT] != 0) try_fast = false;
     }
-    if (!use_general) {
+    if (try_fast) {
       const int sbits = std::min(low_bits, FF_MAXBITS), sshift = low_bits - sbits;
       BNPK_HIP(ctx, hipMemsetAsync(marks, 0, (size_t)n_buckets * 4, s));
       const int64_t* out_off = d_bucket_offsets;
@@ -1110,11 +1150,11 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
       const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->finish_fast_grid);
       // keys of one bin differ only below bit sshift: 32-bit compares when that is all inside the low word
       if (sshift <= 32)
-        hipLaunchKernelGGL(finish_fast_kernel<true>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, part, d_bucket_offsets,
+        hipLaunchKernelGGL(finish_fast_kernel<true>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, (const uint64_t*)part, d_bucket_offsets,
                            out_off, n_buckets, sshift, sbits, state, Dv, meta, keys_out, d_counts_out, d_big_table,
                            n_big, big_keys, d_big_counts);
       else
-        hipLaunchKernelGGL(finish_fast_kernel<false>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, part, d_bucket_offsets,
+        hipLaunchKernelGGL(finish_fast_kernel<false>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, (const uint64_t*)part, d_bucket_offsets,
                            out_off, n_buckets, sshift, sbits, state, Dv, meta, keys_out, d_counts_out, d_big_table,
                            n_big, big_keys, d_big_counts);
       BNPK_HIP(ctx, hipGetLastError());
@@ -1126,9 +1166,13 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const in
                          n_buckets, state, redo_ids, redo_bases);
       BNPK_HIP(ctx, hipGetLastError());
       BNPK_CHECK(read_header());
-      if (host[FS_FLAGS] & 4) use_general = true;         // duplicate-heavy keys: everything again, with the general kernel
+      if (host[FS_FLAGS] & 4) try_fast = false;           // duplicate-heavy keys: everything again, with another kernel
       else if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
     }
+    if (!try_fast && !use_general && !use_dup) {
+      if (mode == 2) use_general = true; else use_dup = true;
+    }
+    if (use_dup) BNPK_CHECK(duplicate_aware());
     if (use_general) BNPK_CHECK(general(false, 0));
   }
   BNPK_CHECK(read_header());

@@ -600,18 +600,21 @@ class HipOps:
             # counted here, one by one, with the sort + run kernels and handed to the finishing kernel as
             # ready-made (key, count) runs.
             cap = int(lib.bnpk_finish_capacity())
-            big = None
+            big, fits = None, False
             for attempt in range(3):
                 sizes = offsets[1:] - offsets[:-1]
                 largest = int(sizes.max().item())
                 if largest <= cap:
+                    fits = True
                     break
                 over = (sizes > cap).nonzero().flatten()
                 bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
-                if over.numel() <= self.MAX_PRECOUNTED or attempt == 2 or bits <= 0:
-                    if over.numel() <= self.MAX_PRECOUNTED:
-                        big = self._precount_buckets(cur, offsets, over, key_bits)
+                if over.numel() <= self.MAX_PRECOUNTED:
+                    big = self._precount_buckets(cur, offsets, over, key_bits)
+                    fits = True
                     break
+                if attempt == 2 or bits <= 0:
+                    break                                # too many heavy buckets: the full sort below
                 if bits <= 4 and n_seg > 4096 and largest <= int(lib.bnpk_radix_small_capacity()):
                     out = spare if spare is not None else self._empty(n, np.int64)
                     child = self._empty(n_seg * (1 << bits) + 1, np.int64)
@@ -625,18 +628,22 @@ class HipOps:
                 cur, owned = out, True
                 done += bits
                 n_seg <<= bits
-            keys_out = spare if spare is not None else self._empty(n, np.int64)
-            counts = self._empty(n, np.int64)
-            state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
-            n_unique, overflow = C.c_int64(0), C.c_int(0)
-            table, big_keys, big_counts = big if big is not None else (None, None, None)
-            self._chk(lib.bnpk_finish_sorted(self.ctx, ptr(cur), n, ptr(offsets), n_seg, key_bits - skip - done,
-                                             ptr(keys_out), ptr(counts), ptr(state), ptr(table),
-                                             0 if table is None else table.numel() // 3, ptr(big_keys), ptr(big_counts),
-                                             C.byref(n_unique), C.byref(overflow), self._s()))
-            if not overflow.value:
+            if fits:
+                # bnpk_finish_sorted uses the partitioned keys as workspace: never the caller's array
+                work = cur if owned else cur.clone()
+                keys_out = spare if spare is not None else self._empty(n, np.int64)
+                counts = self._empty(n, np.int64)
+                state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
+                n_unique, overflow = C.c_int64(0), C.c_int(0)
+                table, big_keys, big_counts = big if big is not None else (None, None, None)
+                self._chk(lib.bnpk_finish_sorted(self.ctx, ptr(work), n, ptr(offsets), n_seg, key_bits - skip - done,
+                                                 ptr(keys_out), ptr(counts), ptr(state), ptr(table),
+                                                 0 if table is None else table.numel() // 3, ptr(big_keys), ptr(big_counts),
+                                                 C.byref(n_unique), C.byref(overflow), self._s()))
+                if overflow.value:                       # every bucket was checked against the capacity above
+                    raise RuntimeError("bnpk_finish_sorted reported an overflow on buckets that fit")
                 return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
-            del counts, state, keys_out, spare, big     # too many heavy buckets: fall back to the full sort
+            del spare, big
         keys_out, counts = self._count_by_sorting(cur if owned else cur.clone(), key_bits)
         return HArray(dev=keys_out), HArray(dev=counts)
 

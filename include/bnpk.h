@@ -71,7 +71,9 @@ int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes,
 
 /* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
  * "finish_mode": which finishing kernel bnpk_finish_sorted launches — 0 = chosen per call from a probe of
- *                the first buckets (default), 1 = the general kernel only, 2 = the fast kernel + redo list only.
+ *                the first buckets (default: the fast kernel, which gives up at once when keys repeat, then the
+ *                duplicate-aware kernel), 1 = the general kernel only, 2 = the fast kernel + redo list (general kernel
+ *                if it gives up), 3 = the duplicate-aware kernel (+ general kernel for the buckets it hands back) only.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
  * Unknown names and values out of range return BNPK_ERR_ARG. */
@@ -385,7 +387,9 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  *                         distinct keys, offset into d_big_keys / d_big_counts} int64 triples sorted by bucket;
  *                         their pairs are copied into place.  *h_overflow = 1 means a bucket exceeded the capacity
  *                         without being listed: the outputs must be discarded (bnpk_sort_keys + run kernels).
- *                         d_state needs bnpk_finish_state_words(n_buckets) int64. */
+ *                         d_state needs bnpk_finish_state_words(n_buckets) int64.  d_part is WORKSPACE: its contents
+ *                         are undefined afterwards (the duplicate-aware kernel writes every bucket's distinct keys
+ *                         back over the bucket's own keys before they are moved into place). */
 int64_t bnpk_radix_max_bits(void);
 int64_t bnpk_finish_capacity(void);
 int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
@@ -398,7 +402,7 @@ int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, 
                                int64_t n_seg, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets,
                                void* stream);
 int64_t bnpk_finish_state_words(int64_t n_buckets);
-int bnpk_finish_sorted(bnpk_ctx* ctx, const int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
+int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                        const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream);
