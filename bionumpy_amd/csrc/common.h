@@ -42,6 +42,8 @@ struct bnpk_ctx {
   int finish_mode = 0;           // 0 = choose per call, 1 = general kernel only, 2 = fast kernel + redo list only, 3 = duplicate-aware only
   bool finish_dup_ready = false; // finish_dup.hip: launch attributes set / co-resident workgroups
   int finish_dup_grid = 0;
+  bool finish_wave_ready = false;   // finish_wave.hip
+  int finish_wave_grid = 0;
   int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
 };
 

@@ -1100,13 +1100,20 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
     return BNPK_OK;
   };
   void* scan_scratch = nullptr;
-  // The duplicate-aware path (finish_dup.hip): every bucket's distinct keys back over its own keys, the counts to the same
-  // positions of the key array, the buckets it hands back finished the same way by the general kernel (its list length
-  // is read on the device: no host round trip), one scan over the distinct counts, two copies into place.
-  auto duplicate_aware = [&]() -> int {
+  unsigned* todo_ids = marks;                            // (the marks are the fast path's)
+  // The duplicate-aware path (finish_wave.hip, finish_dup.hip): every bucket's distinct keys back over its own keys, the
+  // counts to the same positions of the key array.  A cascade of three kernels, each taking what the one before could not
+  // hold, through lists whose lengths are read on the device (no host round trip): one wavefront per bucket with a
+  // 704-slot table (only when the probe found the keys duplicate-heavy), one workgroup per bucket with 6144 slots, the
+  // general kernel.  Then one scan over the distinct counts and two copies into place.
+  auto duplicate_aware = [&](bool wave_first) -> int {
     BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+    if (wave_first) {
+      BNPK_CHECK(bnpk_finish_wave_launch(ctx, false, 0, part, n, d_bucket_offsets, n_buckets, low_bits, state, Dv, todo_ids,
+                                         d_keys_out, d_big_table, n_big, big_keys, d_big_counts, s));
+    }
     BNPK_CHECK(bnpk_finish_dup_launch(ctx, part, d_bucket_offsets, n_buckets, low_bits, state, Dv, redo_ids, d_keys_out,
-                                      d_big_table, n_big, big_keys, d_big_counts, s));
+                                      d_big_table, n_big, big_keys, d_big_counts, wave_first ? todo_ids : nullptr, s));
     {
       const int sbits = std::min(low_bits, FN_MAXBITS), sshift = low_bits - sbits;
       const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
@@ -1120,26 +1127,38 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
     BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_part, d_keys_out, d_bucket_offsets, Dv, n_buckets, state, s));
     return BNPK_OK;
   };
-  // finish_mode: 0 = the fast kernel first (it gives up within a bucket per workgroup when keys repeat), then the
-  // duplicate-aware path; 1 = general kernel only; 2 = fast kernel + redo list, general kernel if it gives up;
-  // 3 = duplicate-aware path only
+  // finish_mode 0: a probe decides — a sample of the buckets goes through the wavefront kernel's table; if (nearly) all of
+  // them fit, the keys are duplicate-heavy and the cascade above runs.  Otherwise the fast kernel, which gives up within
+  // a bucket per workgroup when keys repeat after all; then the cascade without its first stage.
+  // 1 = general kernel only; 2 = fast kernel + redo list, general kernel if it gives up; 3 = the workgroup kernel of the
+  // cascade (+ general kernel); 4 = the whole cascade.
   const int mode = ctx->finish_mode;
-  bool use_general = mode == 1, use_dup = mode == 3;
+  const bool can_wave = n >= 2;
+  bool use_general = mode == 1, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
   bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
-  if (!try_fast && mode == 0) use_dup = true;
-  if (!try_fast && mode == 2) use_general = true;
   if (!use_general) BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
-    if (try_fast) {
+    if (mode == 0 || try_fast) {
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
                          d_bucket_offsets, n_buckets, state);
+      const int64_t probe_buckets = 1024;
+      if (mode == 0 && can_wave)
+        BNPK_CHECK(bnpk_finish_wave_launch(ctx, true, probe_buckets, part, n, d_bucket_offsets, n_buckets, low_bits, state, Dv,
+                                           todo_ids, d_keys_out, d_big_table, n_big, big_keys, d_big_counts, s));
+      int64_t probe[3] = {0, 0, 0};
+      BNPK_HIP(ctx, hipMemcpyAsync(probe, d_state + FS_PROBE_BAD, sizeof(probe), hipMemcpyDeviceToHost, s));
       BNPK_CHECK(read_header());
       if (host[FS_MISFIT] != 0) try_fast = false;
+      if (mode == 0 && can_wave && probe[2] > 0) {
+        const int64_t stride = std::max<int64_t>(1, n_buckets / probe_buckets), sampled = ceil_div(n_buckets, stride);
+        if (probe[0] * 16 <= sampled) { use_wave = true; try_fast = false; }
+      }
     }
     if (try_fast) {
       const int sbits = std::min(low_bits, FF_MAXBITS), sshift = low_bits - sbits;
+      BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       BNPK_HIP(ctx, hipMemsetAsync(marks, 0, (size_t)n_buckets * 4, s));
       const int64_t* out_off = d_bucket_offsets;
       if (n_big > 0) {
@@ -1169,10 +1188,11 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       if (host[FS_FLAGS] & 4) try_fast = false;           // duplicate-heavy keys: everything again, with another kernel
       else if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
     }
-    if (!try_fast && !use_general && !use_dup) {
+    if (!try_fast && !use_general && !use_dup && !use_wave) {
       if (mode == 2) use_general = true; else use_dup = true;
     }
-    if (use_dup) BNPK_CHECK(duplicate_aware());
+    if (use_wave) BNPK_CHECK(duplicate_aware(true));
+    else if (use_dup) BNPK_CHECK(duplicate_aware(false));
     if (use_general) BNPK_CHECK(general(false, 0));
   }
   BNPK_CHECK(read_header());

@@ -87,8 +87,11 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
     uint64_t* A, const int64_t* __restrict__ bucket_off, int64_t n_buckets, int sshift, int sbits,
     unsigned long long* __restrict__ header, int64_t* __restrict__ Dv, unsigned* __restrict__ redo_ids,
     int64_t* __restrict__ loose_counts, const int64_t* __restrict__ big_table, int n_big,
-    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts) {
+    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, const unsigned* __restrict__ todo_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // the buckets to finish: all of them, or (todo_ids) the ones the wavefront kernel listed — the length of its list is
+  // read here, on the device
+  const int64_t n_items = todo_ids ? fd_uniform((int64_t)header[FS_TODO]) : n_buckets;
   unsigned long long* T = reinterpret_cast<unsigned long long*>(smem + FD_OFF_T);
   unsigned* C = reinterpret_cast<unsigned*>(smem + FD_OFF_C);
   unsigned* BM = reinterpret_cast<unsigned*>(smem + FD_OFF_BM);
@@ -105,13 +108,18 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
   if (tid < 16) sh[tid] = 0;
   __syncthreads();
 
-  struct bucket_t { int64_t lo, size; int nb; };
-  auto fetch_offsets = [&](int64_t bb, int64_t& o0, int64_t& o1) {   // (scalar loads; consumed an iteration later)
-    o0 = 0; o1 = 0;
-    if (bb < n_buckets) { o0 = bucket_off[bb]; o1 = bucket_off[bb + 1]; }
+  struct bucket_t { int64_t id, lo, size; int nb; };
+  auto fetch_offsets = [&](int64_t j, int64_t& o0, int64_t& o1, int64_t& id) {   // (scalar loads; consumed an iteration later)
+    o0 = 0; o1 = 0; id = 0;
+    if (j < n_items) {
+      id = todo_ids ? (int64_t)todo_ids[j] : j;
+      o0 = bucket_off[id];
+      o1 = bucket_off[id + 1];
+    }
   };
-  auto open_bucket = [&](int64_t o0, int64_t o1) {
+  auto open_bucket = [&](int64_t o0, int64_t o1, int64_t id) {
     bucket_t x;
+    x.id = fd_uniform(id);
     x.lo = fd_uniform(o0);
     x.size = fd_uniform(o1) - x.lo;
     x.nb = x.size > FINISH_CAP ? 0 : (int)x.size;
@@ -185,11 +193,11 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
   };
 #pragma unroll
   for (int q = 0; q < FD_ITEMS; ++q) k[q] = 0;
-  int64_t f0, f1;
-  fetch_offsets((int64_t)blockIdx.x, f0, f1);
-  bucket_t cur = open_bucket(f0, f1);
+  int64_t f0, f1, fi;
+  fetch_offsets((int64_t)blockIdx.x, f0, f1, fi);
+  bucket_t cur = open_bucket(f0, f1, fi);
   load_keys(cur);
-  fetch_offsets((int64_t)blockIdx.x + G, f0, f1);
+  fetch_offsets((int64_t)blockIdx.x + G, f0, f1, fi);
 
 #ifdef FD_PHASES
   unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
@@ -197,9 +205,10 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
 #else
 #define FD_MARK(i)
 #endif
-  for (int64_t b = blockIdx.x; b < n_buckets; b += G) {
-    const bucket_t nxt = open_bucket(f0, f1);            // bucket b + G (its offsets were fetched an iteration ago)
-    fetch_offsets(b + 2 * G, f0, f1);
+  for (int64_t j = blockIdx.x; j < n_items; j += G) {
+    const bucket_t nxt = open_bucket(f0, f1, fi);        // item j + G (its offsets were fetched an iteration ago)
+    fetch_offsets(j + 2 * G, f0, f1, fi);
+    const int64_t b = cur.id;
     const int nb = cur.nb;
     if (nb == 0) {                                       // empty, or a heavy-hitter bucket counted by the caller beforehand
       unsigned D = 0;
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256) void finish_compact_kernel(const int64_t* __re
 int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                            unsigned long long* header, int64_t* Dv, unsigned* redo_ids, int64_t* loose_counts,
                            const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
-                           hipStream_t s) {
+                           const unsigned* todo_ids, hipStream_t s) {
   if (!ctx->finish_dup_ready) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_dup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS));
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_dup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS));
@@ -426,10 +435,10 @@ int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_
   const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->finish_dup_grid);
   if (sshift >= 32)
     hipLaunchKernelGGL(finish_dup_kernel<true>, dim3(grid), dim3(FD_THREADS), FD_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
-                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts);
+                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids);
   else
     hipLaunchKernelGGL(finish_dup_kernel<false>, dim3(grid), dim3(FD_THREADS), FD_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
-                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts);
+                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

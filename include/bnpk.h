@@ -70,10 +70,13 @@ int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t*
 int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s, void* stream);
 
 /* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
- * "finish_mode": which finishing kernel bnpk_finish_sorted launches — 0 = chosen per call from a probe of
- *                the first buckets (default: the fast kernel, which gives up at once when keys repeat, then the
- *                duplicate-aware kernel), 1 = the general kernel only, 2 = the fast kernel + redo list (general kernel
- *                if it gives up), 3 = the duplicate-aware kernel (+ general kernel for the buckets it hands back) only.
+ * "finish_mode": which finishing kernels bnpk_finish_sorted launches — 0 = chosen per call (default): a sample of the
+ *                buckets is probed; duplicate-heavy keys take the cascade of duplicate-aware kernels (one wavefront per
+ *                bucket, one workgroup per bucket, general kernel — each taking the buckets the one before could not
+ *                hold), other keys the fast kernel and, if it gives up, the cascade without its first stage;
+ *                1 = the general kernel only; 2 = the fast kernel + redo list (general kernel if it gives up);
+ *                3 = the workgroup-per-bucket duplicate-aware kernel (+ general kernel for what it hands back);
+ *                4 = the whole cascade.  Same results in every mode.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
  * Unknown names and values out of range return BNPK_ERR_ARG. */

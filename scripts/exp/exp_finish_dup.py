@@ -12,7 +12,7 @@ from bionumpy_amd._native import lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 skip_parity = len(sys.argv) > 3 and sys.argv[3] == "noparity"
-modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 3, 0]
+modes = [int(m) for m in sys.argv[4].split(",")] if len(sys.argv) > 4 else [1, 3, 4, 0]
 ops = get_ops(); dev = Device.get()
 G_GRID = 512    # workgroups of the duplicate-aware kernel (2 per CU): cycles/bucket is per workgroup
 g = torch.Generator(device="cuda"); g.manual_seed(1)
@@ -58,7 +58,7 @@ for name, make in cases:
         break
     v = make()
     ek, ec = torch.unique(v, sorted=True, return_counts=True)
-    for mode in (1, 3, 0):
+    for mode in (1, 3, 4, 0):
         set_mode(mode)
         k, c = ops.count_sparse(HArray(dev=v.clone()), key_bits=62, consume=True)
         ok = k.dev().numel() == ek.numel() and bool((k.dev() == ek).all()) and bool((c.dev() == ec).all())
@@ -84,7 +84,7 @@ def direct(name, v, top_bits):
     off = torch.zeros(nb + 1, dtype=torch.int64, device="cuda")
     off[1:] = torch.cumsum(torch.bincount(ids, minlength=nb), 0)
     ek, ec = torch.unique(v, sorted=True, return_counts=True)
-    for mode in (1, 3, 0):
+    for mode in (1, 3, 4, 0):
         set_mode(mode)
         work = part.clone()
         out_k, out_c = torch.empty_like(part), torch.empty_like(part)
@@ -94,7 +94,7 @@ def direct(name, v, top_bits):
                                     C.byref(nu), C.byref(ov), dev.stream())
         ok = st == 0 and ov.value == 0 and nu.value == ek.numel() and bool((out_k[:nu.value] == ek).all()) and bool((out_c[:nu.value] == ec).all())
         bad += 0 if ok else 1
-        print("direct %-12s mode %d: %s (keys %d distinct %d, handed back %d)" % (name, mode, "OK" if ok else "MISMATCH", v.numel(), ek.numel(), int(state[3])), flush=True)
+        print("direct %-12s mode %d: %s (keys %d distinct %d, handed back %d / %d)" % (name, mode, "OK" if ok else "MISMATCH", v.numel(), ek.numel(), int(state[6]), int(state[3])), flush=True)
 
 
 if not skip_parity:
@@ -141,10 +141,15 @@ for cov in (60, 6):
         sig = (nu.value, int(counts[:nu.value].sum()), int(a[:nu.value].sum()), int((a[:nu.value] * counts[:nu.value]).sum()))
         if ref is None:
             ref = sig
+        if int(state[14]) > 0:
+            print("   slow-path lanes %d, wave-instructions with a slow lane %d of %d" % (int(state[12]), int(state[13]), int(state[14])))
+        wph = state[16:24].tolist()
+        if sum(wph) > 0 and mode == 4:
+            print("   wave phases (share of cycles): " + " ".join("%.3f" % (x / sum(wph)) for x in wph) + "  cycles per bucket and wave %.0f" % (sum(wph) / nseg))
         ph = state[8:16].tolist()
         if sum(ph) > 0 and mode == 3:
             print("   phases (share of cycles): " + " ".join("%.3f" % (x / sum(ph)) for x in ph) + "  cycles/bucket %.0f" % (sum(ph) / nseg * G_GRID))
-        print("mode %d: finish ms %s status %d n_unique %d overflow %d sorted %s sum_counts %d same_as_first %s redo %d"
-              % (mode, times, st, nu.value, ov.value, srt, sig[1], sig == ref, int(state[3])), flush=True)
+        print("mode %d: finish ms %s status %d n_unique %d overflow %d sorted %s sum_counts %d same_as_first %s handed back %d / %d"
+              % (mode, times, st, nu.value, ov.value, srt, sig[1], sig == ref, int(state[6]), int(state[3])), flush=True)
     del a, b, b0, counts, state
 set_mode(0)

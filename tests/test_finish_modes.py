@@ -1,0 +1,132 @@
+"""-m gpu: the four finishing kernels of the sparse histogram (include/bnpk.h "finish_mode") give np.unique's answer
+(oracle.count_sparse; reference semantics: bionumpy/sequence/count_encoded.py:150-188 extended to k > 8)
+on keys of every shape — duplicate-free, every key ~60 times (S-genome), read errors on top of that, heavy hitters,
+keys that differ only in their low bits (one home slot of the duplicate-aware kernel's table), more distinct keys than
+that table holds — and the finishing call itself (bnpk_finish_sorted) does on hand-made buckets."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+from bionumpy_amd.device import HArray
+
+pytestmark = pytest.mark.gpu
+
+M62 = (1 << 62) - 1
+MODES = (1, 2, 3, 4, 0)         # general / fast + redo / workgroup-per-bucket duplicate-aware / whole cascade / chosen per call
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from bionumpy_amd import ops as ops_mod
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import Device, ptr
+    ops_mod.set_ops(None)
+    yield ops_mod.get_ops(), lib, Device.get(), ptr, torch
+    lib.bnpk_set_option(Device.get().ctx, b"finish_mode", 0)
+
+
+def _mix(x):
+    """a bijection of uint64 (splitmix64 finaliser) cut to 62 bits: distinct ids -> (almost surely) distinct keys"""
+    x = x.astype(np.uint64)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xbf58476d1ce4e5b9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94d049bb133111eb)
+    x = x ^ (x >> np.uint64(31))
+    return (x & np.uint64(M62)).astype(np.int64)
+
+
+def _genome_like(rng, n, coverage):
+    return _mix(rng.integers(0, max(n // coverage, 1), size=n))
+
+
+def _cases():
+    rng = np.random.default_rng(20260926)
+    n = 2_000_000
+    yield "every key ~60 times", _genome_like(rng, n, 60)
+    yield "every key ~6 times", _genome_like(rng, n, 6)
+    yield "every key ~2 times", _genome_like(rng, n, 2)
+    yield "distinct", rng.integers(0, 1 << 62, size=n, dtype=np.int64)
+    yield "read errors", np.concatenate([_genome_like(rng, 3 * n // 4, 60), rng.integers(0, 1 << 62, size=n // 4, dtype=np.int64)])
+    yield "low bits", (rng.integers(0, 1 << 12, size=n, dtype=np.int64) << 50) | rng.integers(0, 3000, size=n, dtype=np.int64)
+    yield "clusters", (rng.integers(0, 1 << 12, size=n, dtype=np.int64) << 50) | (rng.integers(0, 8, size=n, dtype=np.int64) << 44) \
+        | rng.integers(0, 200, size=n, dtype=np.int64)
+    yield "heavy hitters", np.concatenate([_genome_like(rng, n // 2, 60), np.full(300_000, 12345678901234567, dtype=np.int64),
+                                           np.full(20_000, M62, dtype=np.int64), np.zeros(9000, dtype=np.int64)])
+    yield "few values", rng.integers(0, 50, size=5000, dtype=np.int64)
+    yield "one key", np.full(1, 7, dtype=np.int64)
+
+
+@pytest.mark.parametrize("name,keys", list(_cases()), ids=[c[0] for c in _cases()])
+def test_every_finishing_kernel_counts_like_np_unique(env, name, keys):
+    ops, lib, dev, ptr, torch = env
+    ek, ec = oracle.count_sparse(keys)
+    for mode in MODES:
+        assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
+        h = HArray(host=keys.copy())
+        gk, gc = ops.count_sparse(h, key_bits=62)
+        assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), (name, mode)
+        # bnpk_finish_sorted uses the partitioned keys as workspace — never the caller's array
+        assert np.array_equal(h.dev().cpu().numpy(), keys), (name, mode)
+
+
+def _direct(env, keys, top_bits):
+    """bnpk_finish_sorted on hand-made buckets: the keys grouped (not sorted) by their top `top_bits` bits"""
+    ops, lib, dev, ptr, torch = env
+    nb = 1 << top_bits
+    ids = keys >> (62 - top_bits) if top_bits else np.zeros_like(keys)
+    part = keys[np.argsort(ids, kind="stable")]
+    off = np.zeros(nb + 1, dtype=np.int64)
+    off[1:] = np.cumsum(np.bincount(ids, minlength=nb))
+    ek, ec = oracle.count_sparse(keys)
+    handed_back = {}
+    for mode in MODES:
+        assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
+        work, d_off = torch.from_numpy(part.copy()).cuda(), torch.from_numpy(off).cuda()
+        out_k, out_c = torch.empty_like(work), torch.empty_like(work)
+        state = torch.empty(lib.bnpk_finish_state_words(nb), dtype=torch.int64, device="cuda")
+        nu, ov = C.c_int64(0), C.c_int(0)
+        assert lib.bnpk_finish_sorted(dev.ctx, ptr(work), keys.size, ptr(d_off), nb, 62 - top_bits, ptr(out_k), ptr(out_c), ptr(state),
+                                      None, 0, None, None, C.byref(nu), C.byref(ov), dev.stream()) == 0
+        assert ov.value == 0 and nu.value == ek.size, mode
+        assert np.array_equal(out_k[:nu.value].cpu().numpy(), ek) and np.array_equal(out_c[:nu.value].cpu().numpy(), ec), mode
+        handed_back[mode] = int(state[3].item())
+        handed_back[(mode, "wave")] = int(state[6].item())          # buckets the wavefront kernel left to the workgroup kernel
+    return handed_back
+
+
+def test_buckets_the_duplicate_aware_kernel_hands_back(env):
+    """its table has 6144 slots and gives up after 48 probes: such buckets reach the general kernel through the redo list
+    (state word 3) and come out right all the same"""
+    rng = np.random.default_rng(5)
+    r = lambda hi, m: rng.integers(0, hi, size=m, dtype=np.int64)
+    assert _direct(env, (5 << 40) | r(4000, 8000), 0)[3] == 1               # ~3400 distinct keys on one home slot
+    assert _direct(env, r(1 << 62, 8192), 0)[3] == 1                          # more distinct keys than slots
+    assert _direct(env, M62 - r(100, 8000), 0)[3] == 1                        # a long cluster at the last home slot
+    assert _direct(env, M62 - r(40, 8000), 0)[3] == 0                         # ... a short one stays
+    assert _direct(env, r(40, 8000), 0)[3] == 0                               # ... and one at the first
+    assert _direct(env, np.concatenate([np.full(5000, 99, dtype=np.int64), np.full(3000, 98, dtype=np.int64)]), 0)[3] == 0
+    # 64 buckets, one of them hopeless (4000 keys differing in their low bits), some empty
+    mixed = np.concatenate([(r(60, 200_000) << 56) | r(60, 200_000), (7 << 56) | (1 << 40) | r(5000, 4000)])
+    assert _direct(env, mixed, 6)[3] == 1
+    assert _direct(env, (r(3, 9000) << 60) | r(1 << 20, 9000), 4)[3] >= 0
+    # the wavefront kernel of the cascade (704 slots, 32 probes, at most 448 entries) passes on what it cannot hold
+    got = _direct(env, (r(60, 200_000) << 56) | r(60, 200_000), 6)
+    assert got[(4, "wave")] == 0 and got[4] == 0
+    got = _direct(env, np.concatenate([(r(60, 200_000) << 56) | r(60, 200_000), (7 << 56) | (r(3000, 4000) << 40)]), 6)
+    assert got[(4, "wave")] == 1 and got[4] == 0                              # 3000 spread keys: the workgroup kernel's
+    got = _direct(env, mixed, 6)
+    assert got[(4, "wave")] == 1 and got[4] == 1                              # ... on one home slot: the general kernel's
+
+
+def test_clusters_of_the_duplicate_aware_table_are_ranked(env):
+    """neighbouring home slots: entries of one cluster are placed by comparing them with their neighbours — runs of
+    adjacent homes of every length up to the table, keys arriving in random order"""
+    rng = np.random.default_rng(6)
+    # the home slot of a key is its top 16 free bits scaled to the table: 65536 / 6080 ~ 10.8 values per slot, so tops 10
+    # apart fall on adjacent slots and now and then on the same one: one cluster, its probe sequences growing with it
+    for run, back in ((2, 0), (3, 0), (17, 0), (64, 0), (65, 0), (300, 0), (2500, 1)):
+        tops = (np.arange(run, dtype=np.int64) * 10 + 7000) << 46
+        keys = rng.permutation(np.concatenate([tops | (np.arange(run, dtype=np.int64) * 2654435761 & 0xFFFFF)] * 3))
+        assert _direct(env, keys, 0)[3] == back, run
