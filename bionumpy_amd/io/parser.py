@@ -166,8 +166,11 @@ class NumpyFileReader:
                 room, got = take(ahead)
                 ahead = None
                 self._is_finished = got < min_chunk_size
-                if got == 0:
-                    break                                    # (as in the reference, an incomplete tail is dropped)
+                if got == 0 and held.size == 0:
+                    break
+                # (got == 0 with bytes held: the batch before ended exactly at the end of the file, so what it left over was
+                # never terminated — the reference reads that tail again, finds it short, terminates and parses it,
+                # parser.py:183-200 — it gets its newline / marker here and is parsed as the last batch)
                 if held.size <= _FRONT:
                     room[_FRONT - held.size:_FRONT] = held
                     first, n = _FRONT - held.size, _FRONT + got
@@ -213,13 +216,15 @@ class NumpyFileReader:
         want = min_chunk_size if (self._stream_mode or held.size >= min_chunk_size) else min_chunk_size - held.size
         while True:
             batch, n_new = self._extend(held, want)
-            if n_new == 0:
-                return None                                  # (as in the reference, an incomplete tail is dropped)
+            if batch.size == 0:
+                return None
             if max_chunk_size is not None and batch.size > max_chunk_size:
                 raise Exception("No complete entry found")
             buff = self._parse(batch)
             if buff is not None:
                 break
+            if n_new == 0:
+                return None                                  # (as in the reference, an incomplete tail is dropped)
             held, want = batch, min_chunk_size
         if not self._is_finished:
             self._left_over = batch[buff.size:]
@@ -246,7 +251,9 @@ class NumpyFileReader:
         got = self._fill(room[held.size:held.size + want])
         self._is_finished = got < want
         n = held.size + got
-        if got and self._is_finished:
+        # the end of the file — also when the read before ended exactly there and left an unterminated tail behind (the
+        # reference reads that tail again, finds it short, terminates and parses it: parser.py:183-200)
+        if n and self._is_finished:
             n = self._terminate(room, n)
         return room[:n], got
 

@@ -739,3 +739,44 @@ def test_filtering_rows(bnp, big_fq_gz):
     assert len(sub) == int(mask.sum())
     assert np.array_equal(sub.sequence.lengths, chunk.sequence.lengths[mask])
     assert sub.sequence[0].to_string() == chunk.sequence[int(np.flatnonzero(mask)[0])].to_string()
+
+
+# ------------------------------------------------------------------------------------ a read that ends exactly at the end of the file
+def _records_through(bnp, monkeypatch, text, buffer_type, min_chunk_size, ahead, tmp_path):
+    """entries seen by read_chunk / read_chunks (with the read-ahead of big batches forced on when `ahead`)"""
+    from bionumpy_amd.io import parser
+    p = tmp_path / ("f%d_%d.txt" % (min_chunk_size, int(ahead)))
+    p.write_bytes(text)
+    if ahead:
+        monkeypatch.setattr(parser, "_BIG", 4)
+        monkeypatch.setattr(parser, "_READ_AHEAD", True)
+    reader = parser.NumpyFileReader(open(str(p), "rb"), buffer_type)
+    names = []
+    if ahead:
+        for buff in reader.read_chunks(min_chunk_size):
+            names += [str(n) for n in buff.get_data().name]
+    else:
+        while True:
+            buff = reader.read_chunk(min_chunk_size)
+            if buff is None:
+                break
+            names += [str(n) for n in buff.get_data().name]
+    reader.close()
+    return names
+
+
+@pytest.mark.parametrize("ahead", [False, True])
+def test_last_entry_when_the_file_size_is_a_multiple_of_the_chunk_size(bnp, monkeypatch, tmp_path, ahead):
+    # bionumpy/io/parser.py:183-200: the reference seeks back, reads the tail again, finds it shorter than min_chunk_size,
+    # terminates it ('\n', and '>' for multi-line FASTA) and parses it.  Multi-line FASTA ALWAYS carries a tail (its last
+    # record ends at the next '>'), a FASTQ file without a trailing newline does when the last read fills its window.
+    fasta = b"".join(b">r%d\nACGTACG\n" % i for i in range(10))                 # 120 bytes, 10 records
+    assert len(fasta) == 120
+    for size in (20, 24, 30, 40, 60, 120, 121, 7, 1000):
+        got = _records_through(bnp, monkeypatch, fasta, bnp.io.MultiLineFastaBuffer, size, ahead, tmp_path)
+        assert got == ["r%d" % i for i in range(10)], (size, got)
+    fastq = b"".join(b"@q%d\nACGT\n+\nIIII\n" % i for i in range(10))[:-1]      # 159 bytes, no trailing newline
+    assert len(fastq) == 159
+    for size in (159, 53, 63, 160, 16, 3, 1000):
+        got = _records_through(bnp, monkeypatch, fastq, bnp.io.FastQBuffer, size, ahead, tmp_path)
+        assert got == ["q%d" % i for i in range(10)], (size, got)
