@@ -410,7 +410,9 @@ def main():
         torch.cuda.empty_cache()
         try:
             out["host_fed"] = host_fed_leg(args, text, rs)
-        except Exception as e:                               # (e.g. the box cannot page-lock 16 GB)
+        except AssertionError:                               # a histogram that differs from the resident one fails the run
+            raise
+        except (RuntimeError, MemoryError, OSError) as e:    # (e.g. the box cannot page-lock 16 GB)
             out["host_fed"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and not args.no_cpu_baseline:
         m = min(args.reads, args.cpu_sample_reads)

@@ -9,6 +9,8 @@ assignment, ``sum`` / ``np.flatnonzero`` of masks and ``chunk[mask]`` run as ker
 plain numpy array the moment anything else is asked of it (``__array__``, attribute access, iteration, arithmetic) —
 the values and the results are those numpy would give either way.
 """
+import math
+
 import numpy as np
 
 from .device import HArray
@@ -98,7 +100,19 @@ class DeviceVector:
     def _compare(self, name, other):
         if isinstance(other, (int, float, np.integer, np.floating)) and not isinstance(other, bool) and \
                 self._dtype in (np.float64, np.int64, np.uint8):
-            if self._dtype == np.float64 or (float(other) == int(other) and (self._dtype != np.uint8 or 0 <= int(other) <= 255)):
+            if self._dtype == np.float64:
+                on_device = not isinstance(other, (int, np.integer)) or abs(int(other)) <= (1 << 53)   # (exact as a double)
+            else:
+                # an integer vector against a scalar that is an integer of its range; anything else — a fraction, NaN,
+                # an infinity, an int beyond int64 — is numpy's business (all-False / all-True masks, no exceptions)
+                if isinstance(other, (int, np.integer)):
+                    whole, value = True, int(other)
+                else:
+                    whole = math.isfinite(float(other)) and float(other) == int(other)
+                    value = int(other) if whole else 0
+                lo, hi = (0, 255) if self._dtype == np.uint8 else (-(1 << 63), (1 << 63) - 1)
+                on_device = whole and lo <= value <= hi
+            if on_device:
                 return DeviceVector(get_ops().vec_compare(self._data, _OPS[name], other), np.bool_)
         other = other.host() if isinstance(other, DeviceVector) else other
         return getattr(self.host(), name)(other)

@@ -83,6 +83,7 @@ class HostFedCounter:
         self.filled = [torch.cuda.Event() for _ in range(ring)]
         self.freed = [torch.cuda.Event() for _ in range(ring)]
         self.free_slots = threading.Semaphore(ring)
+        self._stop = threading.Event()
         self._h2d_events = []
 
     # -- feeder thread: host memory -> ring buffers on the copy stream ---------------------------------------------------
@@ -94,6 +95,9 @@ class HostFedCounter:
                 at = 0
                 for c, end in enumerate(cuts):
                     self.free_slots.acquire()
+                    if self._stop.is_set():                  # the consumer has gone (an exception, an abandoned generator)
+                        out.put(None)
+                        return
                     slot = i % len(self.ring)
                     n = end - at
                     s = self.copy_stream.cuda_stream
@@ -125,9 +129,25 @@ class HostFedCounter:
         for ev in self.freed:
             ev.record(compute)
         self._h2d_events, n_chunks, total_bytes = [], 0, 0
+        self._stop.clear()
+        self.free_slots = threading.Semaphore(len(self.ring))
         t0 = time.perf_counter()
-        feeder = threading.Thread(target=self._feed, args=(plan, q), daemon=True)
+        feeder = threading.Thread(target=self._feed, args=(plan, q), name="bnpk-feeder", daemon=True)
         feeder.start()
+        try:
+            yield from self._consume(plan, q, compute, t0)
+        finally:
+            # however the consumer ends — all batches done, malformed input raising out of _count, the generator dropped
+            # half way — the feeder must not stay blocked on a slot (it holds this object and its ring of chunk buffers)
+            self._stop.set()
+            for _ in self.ring:
+                self.free_slots.release()
+            feeder.join()
+            self.copy_stream.synchronize()
+
+    def _consume(self, plan, q, compute, t0):
+        t, ops = self._t, self.ops
+        n_chunks, total_bytes = 0, 0
         compute_s, paused = 0.0, 0.0                     # (paused: time the consumer of the generator spends between batches)
         state = None
         while True:
@@ -147,7 +167,7 @@ class HostFedCounter:
                                                           state["ends"], state["bases"])
             self.freed[slot].record(compute)
             self.free_slots.release()
-            state["errs"].append((err, state["reads"], state["bases"]))
+            state["errs"].append((err, state["reads"], state["real_bases"]))
             state["reads"] += n_reads
             state["real_bases"] += n_bases
             state["bytes"] += n
@@ -169,7 +189,6 @@ class HostFedCounter:
                 paused += time.perf_counter() - p0
             else:
                 compute_s += time.perf_counter() - c0
-        feeder.join()
         t.cuda.synchronize()
         wall = time.perf_counter() - t0 - paused
         h2d_s = sum(a.elapsed_time(b) for a, b, _ in self._h2d_events) * 1e-3          # time the copy engine was busy
@@ -179,14 +198,18 @@ class HostFedCounter:
 
     def _count(self, state):
         ops, k = self.ops, self.k
-        for err, reads_before, bases_before in state["errs"]:
-            e = err.cpu().numpy()
+        # the reference validates the whole buffer before it encodes anything (io/one_line_buffer.py:45-71, then
+        # encodings/alphabet_encoding.py:37-45 on the gathered sequences): format errors of any chunk come first; the
+        # offset of an invalid base counts the bases of the whole batch, not of its chunk
+        cells = [(err.cpu().numpy(), reads_before, bases_before) for err, reads_before, bases_before in state["errs"]]
+        for e, reads_before, _ in cells:
             if e[0] != NONE:
                 raise FormatException("Expected header line to start with @", line_number=(int(e[0]) + reads_before) * 4)
             if e[1] != NONE:
                 raise FormatException("Expected '+' at third line of entry", line_number=2 + (int(e[1]) + reads_before) * 4)
+        for e, _, bases_before in cells:
             if e[2] != NONE:
-                raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character", int(e[2]))
+                raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character", int(e[2]) + bases_before)
         n_pos = state["bases"]
         packed, ends = HArray(dev=state["packed"]), HArray(dev=state["ends"])
         starts_mask, n_kmers = ops.kmer_starts_from_ends(ends, n_pos, k)

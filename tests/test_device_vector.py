@@ -67,3 +67,18 @@ def test_uint8_and_int64_vectors_compare_like_numpy(bnp, values, op, scalar):
     assert int(np.sum(dv)) == int(a.sum()) and dv.tolist() == a.tolist() and list(dv) == list(a)
     if len(a):
         assert dv[0] == a[0] and dv[-1] == a[-1] and float(np.mean(dv)) == float(a.mean()) and dv.max() == a.max()
+
+
+@pytest.mark.parametrize("scalar", [float("nan"), float("inf"), float("-inf"), 1 << 70, -(1 << 70), 2.5, np.float64("nan"), 1 << 63])
+def test_scalars_no_integer_vector_holds_compare_like_numpy(bnp, scalar):
+    """NaN, infinities, fractions and ints beyond int64 against uint8 / int64 vectors: numpy answers with all-False / all-True
+    masks; nothing raises (int(nan) and int(inf) do) and nothing is truncated on its way to the kernel"""
+    import operator
+    for dtype in (np.uint8, np.int64, np.float64):
+        dv, a = _vec([0, 1, 2, 200, 255], dtype)
+        for f in (operator.lt, operator.le, operator.gt, operator.ge, operator.eq, operator.ne):
+            try:
+                expect = f(a, scalar)
+            except OverflowError:                            # (numpy itself refuses uint8 < 2**70 in some versions)
+                continue
+            assert np.array_equal(np.asarray(f(dv, scalar)), expect), (dtype, f, scalar)

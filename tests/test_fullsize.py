@@ -134,13 +134,40 @@ def test_host_fed_pipeline_equals_the_oracle_and_the_resident_path(ops):
         assert stats.n_reads == rstats.n_reads and stats.n_kmers == rstats.n_kmers and stats.n_bases == rstats.n_bases
         assert np.array_equal(keys.host(), rk.host()) and np.array_equal(counts.host(), rc.host())
     assert counter.timing.h2d_gb_per_s > 0 and 0.0 <= counter.timing.overlap_frac <= 1.0
-    # a bad base is reported with the reference's exception
+    # a bad base is reported with the reference's exception and the reference's offset: the flat index of the byte among the
+    # sequence bytes of the WHOLE batch (encodings/alphabet_encoding.py:37-45 on the gathered sequences), whichever chunk of
+    # the batch it was uploaded in; a malformed record anywhere comes first, as in the reference, which validates the
+    # buffer before it encodes
+    from bionumpy_amd.exceptions import EncodingError, FormatException
+
+    def oracle_offset(text):
+        res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+        with pytest.raises(oracle.EncodingError) as e:
+            oracle.encode_dna(oracle.gather_rows(text, res.field_starts[:, 1], res.field_lens[:, 1]))
+        return e.value.offset
+
+    for read, pos in ((777, 20), (0, 0), (199_999, 149), (150_000, 75)):          # first chunk, very first base, last chunk, a middle one
+        bad = batches[0].copy()
+        bad[316 * read + 12 + pos] = ord("N")
+        bad[316 * 199_999 + 12 + 149] = ord("n") if read != 199_999 else ord("N")  # a second, later one: the first is reported
+        assert oracle_offset(bad) == 150 * read + pos
+        kb, tb = _pinned_copy(bad)
+        counter = HostFedCounter(k, chunk_bytes=8 << 20, ring=2)
+        assert len(cut_points(tb, 8 << 20)) > 4
+        with pytest.raises(EncodingError) as e:
+            list(counter.run([tb]))
+        assert e.value.offset == 150 * read + pos
+        del counter
     bad = batches[0].copy()
-    bad[316 * 777 + 20] = ord("N")
+    bad[316 * 5 + 12 + 3] = ord("N")                      # an invalid base early ...
+    bad[316 * 190_000] = ord(">")                         # ... and a malformed header in the last chunk: the format error wins
     kb, tb = _pinned_copy(bad)
-    from bionumpy_amd.exceptions import EncodingError
-    with pytest.raises(EncodingError):
+    with pytest.raises(FormatException) as e:
         list(HostFedCounter(k, chunk_bytes=8 << 20, ring=2).run([tb]))
+    assert e.value.line_number == 4 * 190_000
+    # the feeder thread ends with the run, however it ends (it holds the counter and its ring of chunk buffers)
+    import threading
+    assert not [th for th in threading.enumerate() if th.name.startswith("bnpk-feeder")]
 
 
 def test_saccer3_decoded_on_the_device_equals_the_oracle(ops, tmp_path):
