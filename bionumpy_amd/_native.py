@@ -80,6 +80,7 @@ SIGNATURES = {
     "bnpk_pair_compose": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_pair_split": (_int, [_p, _p, _i64, _i64, _p, _p, _p, _p]),
     "bnpk_kmers_generic": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
+    "bnpk_minimizers_generic": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _int, _p, _p]),
     "bnpk_lut_bytes": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
     "bnpk_kmer_start_mask": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_join_lines": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _u8, _p, _i64, _p, _p]),
@@ -103,6 +104,7 @@ SIGNATURES = {
     "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
     "bnpk_count_dense": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "bnpk_count_dense_rows": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
+    "bnpk_count_weighted": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_int), _p]),
     "bnpk_sort_keys": (_int, [_p, _p, _p, _i64, _int, _int, C.POINTER(_int), _p]),
     "bnpk_sort_pairs": (_int, [_p, _p, _p, _p, _p, _i64, _int, C.POINTER(_int), _p]),
     "bnpk_radix_max_bits": (_i64, []),

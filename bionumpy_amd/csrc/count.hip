@@ -172,6 +172,46 @@ __global__ void pair_split_kernel(const int64_t* __restrict__ ids, int64_t n, in
   }
 }
 
+
+// ---- weighted counts: np.bincount(values, weights=w) (bionumpy/sequence/count_encoded.py:166-187) ------------------------
+// hist[r][values[r * vstride + i]] += w[r * wstride + i]: one histogram per row r — of the weights (2-D weights over flat
+// values: vstride 0), of the values (a matrix of values under 1-D weights: wstride 0), or one row altogether.  T = int64_t
+// for integer / bool weights (exact), double for floating-point ones.  Few bins: a private histogram in LDS per
+// workgroup (64-bit LDS atomics), flushed with global atomics; many bins: global atomics (the bins then see little
+// contention).  blockIdx.y = row.
+constexpr int HW_LDS_BINS = 4096;
+template <typename T>
+__device__ __forceinline__ void hw_add(T* p, T v) { atomicAdd(p, v); }
+template <>
+__device__ __forceinline__ void hw_add<int64_t>(int64_t* p, int64_t v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+template <typename T, bool LDS>
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_weighted_kernel(const int64_t* __restrict__ values, const T* __restrict__ weights,
+                                                                   int64_t n, int64_t vstride, int64_t wstride, int64_t n_bins,
+                                                                   T* __restrict__ hist, unsigned long long* __restrict__ bad) {
+  __shared__ T local[LDS ? HW_LDS_BINS : 1];
+  const int64_t r = blockIdx.y;
+  const int64_t* v = values + r * vstride;
+  const T* w = weights + r * wstride;
+  T* out = hist + r * n_bins;
+  if (LDS) {
+    for (int64_t c = threadIdx.x; c < n_bins; c += BNPK_BLOCK) local[c] = T(0);
+    __syncthreads();
+  }
+  const int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const int64_t b = v[i];
+    if (b < 0 || b >= n_bins) { atomicOr(bad, 1ull); continue; }
+    hw_add<T>(LDS ? &local[b] : &out[b], w[i]);
+  }
+  if (LDS) {
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < n_bins; c += BNPK_BLOCK)
+      if (local[c] != T(0)) hw_add<T>(&out[c], local[c]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -212,6 +252,45 @@ int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t*
   hipLaunchKernelGGL(hist_rows_kernel, dim3(grid_for(ceil_div(n, BNPK_BLOCK))), dim3(BNPK_BLOCK), 0, s, d_values, d_offsets, n_rows, n,
                      n_bins, reinterpret_cast<unsigned long long*>(d_hist));
   BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_count_weighted(bnpk_ctx* ctx, const int64_t* d_values, const void* d_weights, int weights_f64, int64_t n,
+                        int64_t n_rows, int64_t value_stride, int64_t weight_stride, int64_t n_bins, void* d_hist,
+                        int* h_out_of_range, void* stream) {
+  if (!ctx || n < 0 || n_rows < 1 || n_bins < 1 || value_stride < 0 || weight_stride < 0 || !h_out_of_range || !d_hist)
+    return BNPK_ERR_ARG;
+  *h_out_of_range = 0;
+  if (n_rows > 65535) return BNPK_ERR_RANGE;              // (gridDim.y)
+  if (n == 0) return BNPK_OK;
+  if (!d_values || !d_weights) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  void* flag = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, 64, &flag, s));
+  BNPK_HIP(ctx, hipMemsetAsync(flag, 0, 8, s));
+  {
+    bnpk_timer t(ctx, "count_weighted", s);
+    const unsigned gx = grid_for(std::min<int64_t>(ceil_div(n, BNPK_BLOCK), std::max<int64_t>(1, (int64_t)ctx->compute_units * 16 / n_rows)));
+    const dim3 grid(gx, (unsigned)n_rows);
+    unsigned long long* bad = reinterpret_cast<unsigned long long*>(flag);
+    const bool lds = n_bins <= HW_LDS_BINS;
+    if (weights_f64) {
+      const double* w = reinterpret_cast<const double*>(d_weights);
+      double* h = reinterpret_cast<double*>(d_hist);
+      if (lds) hipLaunchKernelGGL((hist_weighted_kernel<double, true>), grid, dim3(BNPK_BLOCK), 0, s, d_values, w, n, value_stride, weight_stride, n_bins, h, bad);
+      else hipLaunchKernelGGL((hist_weighted_kernel<double, false>), grid, dim3(BNPK_BLOCK), 0, s, d_values, w, n, value_stride, weight_stride, n_bins, h, bad);
+    } else {
+      const int64_t* w = reinterpret_cast<const int64_t*>(d_weights);
+      int64_t* h = reinterpret_cast<int64_t*>(d_hist);
+      if (lds) hipLaunchKernelGGL((hist_weighted_kernel<int64_t, true>), grid, dim3(BNPK_BLOCK), 0, s, d_values, w, n, value_stride, weight_stride, n_bins, h, bad);
+      else hipLaunchKernelGGL((hist_weighted_kernel<int64_t, false>), grid, dim3(BNPK_BLOCK), 0, s, d_values, w, n, value_stride, weight_stride, n_bins, h, bad);
+    }
+    BNPK_HIP(ctx, hipGetLastError());
+  }
+  unsigned long long host_flag = 0;
+  BNPK_HIP(ctx, hipMemcpyAsync(&host_flag, flag, 8, hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  *h_out_of_range = host_flag ? 1 : 0;
   return BNPK_OK;
 }
 

@@ -295,7 +295,8 @@ __global__ void kmer_start_mask_kernel(const int64_t* __restrict__ off, int64_t 
 __global__ __launch_bounds__(BNPK_BLOCK) void kmer_generic_kernel(const uint8_t* __restrict__ codes,
                                                                   const int64_t* __restrict__ in_off,
                                                                   const int64_t* __restrict__ out_off, int64_t n_rows,
-                                                                  int64_t n_out, int k, uint64_t alphabet_size,
+                                                                  int64_t n_out, int k, int kmers_per_window,
+                                                                  uint64_t alphabet_size,
                                                                   const int64_t* __restrict__ tile_rows,
                                                                   int64_t* __restrict__ out) {
   int64_t rr[2];
@@ -305,12 +306,18 @@ __global__ __launch_bounds__(BNPK_BLOCK) void kmer_generic_kernel(const uint8_t*
   for (int64_t o = tile + threadIdx.x; o < min(tile + (int64_t)TILE_OUT, n_out); o += BNPK_BLOCK) {
     const int64_t row = find_row(out_off, rr[0], rr[1], o);
     const uint8_t* src = codes + in_off[row] + (o - out_off[row]);
-    uint64_t h = 0, w = 1;
-    for (int j = 0; j < k; ++j) {
-      h += (uint64_t)src[j] * w;
-      w *= alphabet_size;
+    // kmers_per_window > 1: the minimizer of the window — the smallest of its hashes AS numpy compares them, i.e. as
+    // signed 64-bit integers (Minimizers.__call__: kmer_hashes.raw().min(axis=-1), sequence/minimizers.py:15-17)
+    int64_t best = 0;
+    for (int m = 0; m < kmers_per_window; ++m) {
+      uint64_t h = 0, w = 1;
+      for (int j = 0; j < k; ++j) {
+        h += (uint64_t)src[m + j] * w;
+        w *= alphabet_size;
+      }
+      best = (m == 0 || (int64_t)h < best) ? (int64_t)h : best;
     }
-    out[o] = (int64_t)h;
+    out[o] = best;
   }
 }
 
@@ -458,7 +465,27 @@ int bnpk_kmers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_i
   bnpk_timer t(ctx, "kmers_generic", s);
   BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
   hipLaunchKernelGGL(kmer_generic_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, d_in_offsets,
-                     d_out_offsets, n_rows, n_out, k, (uint64_t)alphabet_size, (const int64_t*)table, d_hashes);
+                     d_out_offsets, n_rows, n_out, k, 1, (uint64_t)alphabet_size, (const int64_t*)table, d_hashes);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_minimizers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
+                            int64_t n_rows, int64_t n_out, int k, int window_size, int alphabet_size, int64_t* d_out,
+                            void* stream) {
+  if (!ctx || k < 1 || window_size < k || alphabet_size < 1 || alphabet_size > 255 || n_rows < 0 || n_out < 0) return BNPK_ERR_ARG;
+  if (n_out == 0) return BNPK_OK;
+  if (!d_codes || !d_in_offsets || !d_out_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
+  int64_t blocks = ceil_div(n_out, TILE_OUT);
+  if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  void* table = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
+  bnpk_timer t(ctx, "minimizers_generic", s);
+  BNPK_CHECK(build_tile_rows(ctx, d_out_offsets, n_rows, TILE_OUT, (int64_t*)table, s));
+  hipLaunchKernelGGL(kmer_generic_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_codes, d_in_offsets,
+                     d_out_offsets, n_rows, n_out, k, window_size - k + 1, (uint64_t)alphabet_size, (const int64_t*)table,
+                     d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

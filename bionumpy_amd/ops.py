@@ -300,6 +300,14 @@ class HipOps:
                                              n_rows, n_out, k, alphabet_size, ptr(out), self._s()))
         return HArray(dev=out)
 
+    def minimizers_generic(self, codes, in_offsets, out_offsets, n_rows, n_out, k, window_size, alphabet_size):
+        """the smallest (signed) generic k-mer hash of every window of window_size codes (bnpk_minimizers_generic)"""
+        out = self._empty(n_out, np.int64)
+        if n_out:
+            self._chk(lib.bnpk_minimizers_generic(self.ctx, ptr(codes.dev()), ptr(in_offsets.dev()), ptr(out_offsets.dev()),
+                                                  n_rows, n_out, k, window_size, alphabet_size, ptr(out), self._s()))
+        return HArray(dev=out)
+
     def lut_bytes(self, data, lut, what="AlphabetEncoding"):
         """lut[data] on the device (bnpk_lut_bytes); EncodingError(offset of the first byte that maps to 255)"""
         n = data.size
@@ -489,6 +497,19 @@ class HipOps:
         hist = self.device.zeros(n_rows * n_bins, np.int64)
         self._chk(lib.bnpk_count_dense_rows(self.ctx, ptr(values.dev()), ptr(offsets.dev()), n_rows, values.size,
                                             n_bins, ptr(hist), self._s()))
+        return HArray(dev=hist)
+
+    def count_weighted(self, values, weights, n, n_rows, value_stride, weight_stride, n_bins):
+        """bnpk_count_weighted: hist[r, values[r * value_stride + i]] += weights[r * weight_stride + i].  weights: an HArray
+        of int64 (exact) or float64; returns the [n_rows, n_bins] histogram of the same dtype."""
+        f64 = weights.dtype == np.float64
+        assert f64 or weights.dtype == np.int64
+        hist = self.device.zeros(n_rows * n_bins, np.float64 if f64 else np.int64)
+        bad = C.c_int(0)
+        self._chk(lib.bnpk_count_weighted(self.ctx, ptr(values.dev()), ptr(weights.dev()), 1 if f64 else 0, n, n_rows,
+                                          value_stride, weight_stride, n_bins, ptr(hist), C.byref(bad), self._s()))
+        if bad.value:
+            raise ValueError("count_encoded: a value outside the alphabet")
         return HArray(dev=hist)
 
     def sort_keys(self, keys_t, key_bits, begin_bit=0):

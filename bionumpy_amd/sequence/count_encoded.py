@@ -149,7 +149,7 @@ def count_encoded(values, weights=None, axis=-1):
 
     axis=None: flattened counts; axis=-1 on a ragged array: one histogram per row."""
     if weights is not None:
-        raise NotImplementedError("weights are not on the MI355X path")
+        return _count_weighted(values, weights, axis)
     ops = get_ops()
     encoding = values.encoding
     flat_request = axis is None or (isinstance(values, EncodedArray) and values.ndim == 1)
@@ -171,6 +171,60 @@ def count_encoded(values, weights=None, axis=-1):
     values._compact()
     hist = ops.count_dense_rows(_as_int64(values._flat_data()), values.offsets(), len(values), n_bins)
     return EncodedCounts(alphabet, hist.host().reshape(len(values), n_bins).copy())
+
+
+def _count_weighted(values, weights, axis):
+    """count_encoded(values, weights, axis) — bionumpy/sequence/count_encoded.py:166-187: np.bincount(values, weights=weights)
+    over flat values (float64 counts, as np.bincount returns them), per row of a matrix of values under 1-D weights
+    ("for row in values"), or per row of 2-D weights over flat values ("for row in weights"; integer counts unless the weights
+    are floating-point).  The histograms are accumulated on the device (bnpk_count_weighted): integer and bool weights in
+    int64 — exact — floating-point ones in float64 with atomic adds."""
+    ops = get_ops()
+    w = np.asanyarray(weights)
+    if w.dtype == np.bool_ or np.issubdtype(w.dtype, np.integer):
+        on_device = w.astype(np.int64)
+    elif np.issubdtype(w.dtype, np.floating):
+        on_device = w.astype(np.float64)
+    else:
+        raise TypeError("count_encoded: weights of dtype %s" % w.dtype)
+    if axis is None:
+        values = values.ravel()
+    encoding = values.encoding
+    alphabet = encoding.get_alphabet() if hasattr(encoding, "get_alphabet") else encoding.get_labels()
+    n_bins = len(alphabet)
+    flat = isinstance(values, EncodedArray) and values.ndim == 1
+    if flat and w.ndim <= 1:
+        n, n_rows, vstride, wstride = len(values), 1, 0, 0
+        if w.size != n:
+            raise ValueError("The weights and list don't have the same length.")
+    elif axis == -1 and w.ndim == 2:
+        assert flat, "2-D weights count flat values once per row of the weights"
+        n, n_rows, vstride, wstride = len(values), w.shape[0], 0, w.shape[1]
+        if w.shape[1] != n:
+            raise ValueError("The weights and list don't have the same length.")
+    elif axis == -1:
+        lens = np.asarray(values.shape[1]) if isinstance(values, EncodedRaggedArray) else np.full(values.shape[0], values.shape[1])
+        if np.any(lens != w.size):
+            raise ValueError("The weights and list don't have the same length.")
+        n, n_rows, vstride, wstride = w.size, len(values), w.size, 0
+    else:
+        raise ValueError("count_encoded: axis %r with these values and weights" % (axis,))
+    store = _as_int64(_flat_store(values))
+    hist = np.zeros((n_rows, n_bins), dtype=on_device.dtype)
+    step = 32768                                             # rows per launch
+    for r0 in range(0, n_rows, step):
+        r1 = min(n_rows, r0 + step)
+        v_part = store if vstride == 0 else HArray(host=store.host()[r0 * n:r1 * n]) if not store.on_device else \
+            HArray(dev=store.dev()[r0 * n:r1 * n])
+        w_part = HArray(host=np.ascontiguousarray(on_device.reshape(-1) if wstride == 0 else on_device[r0:r1].reshape(-1)))
+        hist[r0:r1] = ops.count_weighted(v_part, w_part, n, r1 - r0, vstride, wstride, n_bins).host().reshape(r1 - r0, n_bins)
+    if w.ndim == 2:
+        counts = hist if np.issubdtype(w.dtype, np.floating) else hist.astype(int)
+    else:
+        counts = hist.astype(np.float64)                     # np.bincount(..., weights=...) returns float64
+        if flat:
+            counts = counts[0]
+    return EncodedCounts(alphabet, counts)
 
 
 def _flat_store(values):

@@ -7,7 +7,27 @@ writes the minimizers; the reference's N*w*k intermediate never exists.
 """
 from ..encoded_array import EncodedArray, EncodedRaggedArray, AlphabetEncoding
 from ..encodings.kmer_encodings import KmerEncoding
+from ..ops import get_ops
 from .kmers import _rolling, _trimmed_lens
+
+
+def _get_minimizers_generic(sequence, k, window_size):
+    """Minimizers(window_size - k + 1, KmerEncoder(k, encoding)).rolling_window(sequence) for alphabets that are not 4 letters
+    wide: the smallest hash codes . alphabet_size ** arange(k) of every window, compared as numpy compares int64"""
+    ops = get_ops()
+    single = isinstance(sequence, EncodedArray)
+    if single:
+        sequence = EncodedRaggedArray(sequence.ravel(), [sequence.size])
+    sequence._compact()
+    lens, n_rows = sequence._lens, len(sequence)
+    out_off, n_out = ops.row_offsets(lens, window_size)
+    values = ops.minimizers_generic(sequence._data, sequence.offsets(), out_off, n_rows, n_out, k, window_size,
+                                    sequence.encoding.alphabet_size)
+    encoding = KmerEncoding(sequence.encoding, k)
+    if single:
+        return EncodedArray(values, encoding)
+    return EncodedRaggedArray._from_parts(values, None, _trimmed_lens(out_off, lens, window_size), out_off, n_rows, n_out,
+                                          encoding)
 
 
 def get_minimizers(sequence, k, window_size):
@@ -15,8 +35,8 @@ def get_minimizers(sequence, k, window_size):
         "Sequence needs to be encoded with an AlphabetEncoding, e.g. DNAEncoding"
     assert k <= window_size, "kmer size must be smaller than window size"
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
-    if sequence.encoding.alphabet_size != 4:
-        raise NotImplementedError("only 4-letter alphabets are on the MI355X path")
+    if sequence.encoding.alphabet_size != 4:             # any AlphabetEncoding (minimizers.py:48-52): the generic hashes
+        return _get_minimizers_generic(sequence, k, window_size)
     values, out_off, lens, n_rows, n_out, single = _rolling(
         sequence, window_size, lambda ops, p, i, o, n, m: ops.minimizers(p, i, o, n, m, k, window_size))
     encoding = KmerEncoding(sequence.encoding, k)

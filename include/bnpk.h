@@ -352,6 +352,13 @@ int bnpk_kmers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_i
 int bnpk_minimizers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offsets,
                     const int64_t* d_out_offsets, int64_t n_rows, int64_t n_out, int k,
                     int window_size, int64_t* d_out, void* stream);
+/* the same for alphabets that are not 4 letters wide (get_minimizers accepts any AlphabetEncoding,
+ * bionumpy/sequence/minimizers.py:48-52): the smallest — as signed int64, which is how numpy's .min compares the wrapped
+ * hashes of wide alphabets — of the window_size-k+1 hashes bnpk_kmers_generic gives for the window's k-mers.
+ * d_out_offsets = bnpk_row_offsets(lens, window = window_size). */
+int bnpk_minimizers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t* d_in_offsets, const int64_t* d_out_offsets,
+                            int64_t n_rows, int64_t n_out, int k, int window_size, int alphabet_size, int64_t* d_out,
+                            void* stream);
 
 /* ---- A9: counting ---------------------------------------------------------------------------------
  * dense: replaces np.bincount(values, minlength=4^k) of count_encoded
@@ -363,6 +370,20 @@ int bnpk_count_dense(bnpk_ctx* ctx, const int64_t* d_values, int64_t n, int64_t 
  * d_hist is [n_rows, n_bins] int64, zero-initialised by the caller */
 int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t* d_offsets,
                           int64_t n_rows, int64_t n, int64_t n_bins, int64_t* d_hist, void* stream);
+
+/* weighted counts: np.bincount(values, weights=w, minlength=n_bins) as count_encoded(values, weights) calls it
+ * (bionumpy/sequence/count_encoded.py:166-187) — 1-D weights over flat values (n_rows = 1), 2-D weights over flat values
+ * ("for row in weights": value_stride = 0, weight_stride = n), or 1-D weights over the rows of a matrix of values ("for
+ * row in values": value_stride = n, weight_stride = 0):
+ *     d_hist[r * n_bins + d_values[r * value_stride + i]] += d_weights[r * weight_stride + i],  r < n_rows, i < n.
+ * weights_f64 = 0: int64 weights and an int64 histogram (exact: what numpy's double accumulation of integer weights gives
+ * below 2^53), 1: float64 weights and a float64 histogram — accumulated with atomics, i.e. in another order than numpy's
+ * left-to-right loop: equal to it up to the rounding of the additions (tests state the tolerance).  d_hist is accumulated
+ * into (zero it first).  *h_out_of_range = 1 if a value was not in [0, n_bins) (it was skipped; numpy would have grown
+ * the histogram or raised).  Synchronous. */
+int bnpk_count_weighted(bnpk_ctx* ctx, const int64_t* d_values, const void* d_weights, int weights_f64, int64_t n,
+                        int64_t n_rows, int64_t value_stride, int64_t weight_stride, int64_t n_bins, void* d_hist,
+                        int* h_out_of_range, void* stream);
 
 /* sparse (k > 8 has no reference implementation; defined as np.unique(h, return_counts=True),
  * SURVEY.md §3.5): step 1 sorts the keys (d_alt is an n-element ping-pong buffer; only bits

@@ -34,7 +34,7 @@ from .encode import (dna_lut, gather_rows, encode_dna, decode_dna,
                      quality_scores)
 from .kmers import (pack_2bit, sliding_window_2bit, kmer_hashes_flat,
                     get_kmers, get_kmers_generic, get_minimizers,
-                    kmer_to_string, kmer_labels, count_dense, count_sparse,
+                    kmer_to_string, kmer_labels, count_dense, count_weighted, count_sparse,
                     merge_sparse, build_kmer_index, kmer_index_pairs, debruijn_neighbours, colored_debruijn, kmer_from_string,
                     reverse_complement, reverse_complement_hash, canonical_kmers,
                     match_string, pwm_scores)

@@ -92,8 +92,8 @@ def get_kmers_generic(codes, lengths, k, alphabet_size=4):
     return _trim_rows(_generic_flat(codes, k, alphabet_size), lengths, k)
 
 
-def get_minimizers(codes, lengths, k, window_size):
-    """get_minimizers (sequence/minimizers.py:20-54).
+def get_minimizers(codes, lengths, k, window_size, alphabet_size=4):
+    """get_minimizers (sequence/minimizers.py:20-54) for any AlphabetEncoding (alphabet_size letters).
 
     For every window of ``window_size`` bases: the minimum raw hash among its
     window_size-k+1 k-mers (Minimizers.__call__, minimizers.py:15-17); one value per
@@ -102,7 +102,7 @@ def get_minimizers(codes, lengths, k, window_size):
     assert k <= window_size, "kmer size must be smaller than window size"
     codes = np.asarray(codes)
     n_kmers = window_size - k + 1
-    hashes = _generic_flat(codes, k)
+    hashes = _generic_flat(codes, k, alphabet_size)
     if hashes.size < n_kmers:
         mins = np.zeros(0, dtype=np.int64)
     else:
@@ -145,6 +145,27 @@ def count_dense_rows(hashes, lengths, k):
     n_bins = 4 ** k
     return np.array([np.bincount(hashes[s:s + l], minlength=n_bins)
                      for s, l in zip(starts, lengths)], dtype=np.int64).reshape(len(lengths), n_bins)
+
+
+def count_weighted(values, weights, n_bins, axis=-1):
+    """count_encoded(values, weights, axis) — the counts array of count_encoded.py:166-187, statement by statement:
+    flat values and weights of less than two dimensions: np.bincount(values, weights=weights, minlength) (float64);
+    axis == -1 and 2-D weights: one bincount of the flat values per row of the weights, made integer unless the weights are
+    floating-point; axis == -1 otherwise: one bincount per row of the values under the same weights."""
+    weights = np.asanyarray(weights)
+    weights2d = weights.ndim == 2
+    values = np.asarray(values)
+    if axis is None:
+        values = values.ravel()
+    if values.ndim == 1 and not weights2d:
+        return np.bincount(values, weights=weights, minlength=n_bins)
+    assert axis == -1
+    if not weights2d:
+        return np.array([np.bincount(row, weights=weights, minlength=n_bins) for row in values])
+    counts = np.array([np.bincount(values, weights=row, minlength=n_bins) for row in weights])
+    if not np.issubdtype(counts.dtype, np.integer) and not np.issubdtype(weights.dtype, np.floating):
+        counts = counts.astype(int)
+    return counts
 
 
 def count_sparse(hashes):

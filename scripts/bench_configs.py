@@ -52,6 +52,9 @@ out["config3_minimizers"] = {"reads": reads, "k": 31, "window_size": 40, "n_mini
                                                             (prof["minimizers_flat"]["total_ms"] / 2 * 1e-3) / 1e9, 1)}
 from bionumpy_amd.pipeline import fastq_minimizers
 m, st = fastq_minimizers(text, 31, 40); assert st.n_kmers == n_out; del m
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fullsize                                            # full-size parity of config 3 (outside the timed regions)
+out["config3_parity"] = fullsize.check_minimizers(ops, text, reads, 150, 31, 40, 20260925, 0, 0)
 sync(); dev.prof_enable(True); dev.prof_reset()
 t0 = time.perf_counter()
 for _ in range(2):

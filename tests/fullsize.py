@@ -111,3 +111,48 @@ def check_histogram(ops, text, n_reads, read_len, k, seed, mode, genome_len, fir
                                     canonical, sample_reads)
     return {"kmers": flat[0], "distinct": keys.size, "sampled_kmers_vs_oracle": n_sampled,
             "checksums": ["count", "sum", "sum of squares", "sum of mixed"], "slabs": -(-n_reads // slab_reads)}
+
+
+def check_minimizers(ops, text, n_reads, read_len, k, window_size, seed, mode, genome_len, first_read=0, sample_reads=3000,
+                     slab_reads=2_000_000):
+    """BASELINE config 3 at full size: the minimizers of every window of every read as the fused pipeline produces them
+    (pipeline.fastq_minimizers: fused decode + bnpk_windows_flat, position-flat, no row lookups) against
+
+    * **another kernel, element for element**: bnpk_minimizers (one lane per output, row lookups, windows of any width —
+      itself pinned to the oracle in tests/test_gpu_parity.py) over the same reads, slab by slab;
+    * **the oracle on sampled reads**: the minimizers of reads at the start, in the middle and at the end of the batch,
+      computed by the numpy oracle (oracle.get_minimizers, sequence/minimizers.py:8-54) from the generator's numpy twin,
+      against the same rows of the device's output.
+    Returns what was checked; raises AssertionError on the first difference."""
+    import torch
+    from bionumpy_amd.pipeline import fastq_minimizers
+    rec = synth.record_bytes(read_len)
+    per_read = read_len - window_size + 1
+    assert text.size == n_reads * rec and per_read > 0
+    out, stats = fastq_minimizers(text, k, window_size)
+    assert stats.n_reads == n_reads and stats.n_kmers == n_reads * per_read == out.size
+    got = out.dev()
+    t = text.dev()
+    compared = 0
+    for r0 in range(0, n_reads, slab_reads):
+        r1 = min(n_reads, r0 + slab_reads)
+        slab = HArray(dev=t[r0 * rec:r1 * rec])
+        packed, ends, n, n_bases = ops.fastq_encode(slab, slab.size, 4, 1, ord("@"), True)
+        m = r1 - r0
+        in_off = HArray(dev=torch.arange(m + 1, dtype=torch.int64, device=got.device) * read_len)
+        out_off = HArray(dev=torch.arange(m + 1, dtype=torch.int64, device=got.device) * per_read)
+        by_rows = ops.minimizers_by_rows(packed, in_off, out_off, m, m * per_read, k, window_size).dev()
+        assert torch.equal(by_rows, got[r0 * per_read:r1 * per_read]), "minimizers of reads %d..%d differ between the kernels" % (r0, r1)
+        compared += m * per_read
+        del packed, ends, slab, by_rows
+    per = max(1, min(sample_reads, n_reads) // 3)
+    sampled = 0
+    for f in sorted({0, max(0, n_reads // 2 - per // 2), max(0, n_reads - per)}):
+        m = min(per, n_reads - f)
+        codes = synth.read_codes(m, read_len, seed, mode, genome_len, first_read + f)
+        expect, lens = oracle.get_minimizers(codes.reshape(-1), np.full(m, read_len, dtype=np.int64), k, window_size)
+        assert np.all(lens == per_read)
+        assert np.array_equal(got[f * per_read:(f + m) * per_read].cpu().numpy(), expect), "minimizers of reads %d..%d differ from the oracle" % (f, f + m)
+        sampled += expect.size
+    return {"minimizers": compared, "compared_with": "bnpk_minimizers (row-lookup kernel), element for element",
+            "sampled_minimizers_vs_oracle": sampled}

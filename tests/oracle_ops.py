@@ -266,6 +266,12 @@ class OracleOps:
         assert h.size == n_out
         return _h(h)
 
+    def minimizers_generic(self, codes, in_offsets, out_offsets, n_rows, n_out, k, window_size, alphabet_size):
+        off = in_offsets.host()
+        m, _ = oracle.get_minimizers(codes.host()[:int(off[-1])], np.diff(off), k, window_size, alphabet_size)
+        assert m.size == n_out
+        return _h(m)
+
     def lut_bytes(self, data, lut, what="AlphabetEncoding"):
         try:
             return _h(oracle.encode_dna(data.host(), np.asarray(lut, dtype=np.uint8), 255))
@@ -290,6 +296,14 @@ class OracleOps:
         v = values.host()
         return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins) for r in range(n_rows)],
                            dtype=np.int64).reshape(-1))
+
+    def count_weighted(self, values, weights, n, n_rows, value_stride, weight_stride, n_bins):
+        v, w = values.host(), weights.host()
+        out = np.zeros((n_rows, n_bins), dtype=w.dtype)
+        for r in range(n_rows):
+            out[r] = np.bincount(v[r * value_stride:r * value_stride + n], weights=w[r * weight_stride:r * weight_stride + n],
+                                 minlength=n_bins).astype(w.dtype)
+        return _h(out.reshape(-1))
 
     def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0):
         k, c = oracle.count_sparse(values.host())

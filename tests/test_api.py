@@ -780,3 +780,74 @@ def test_last_entry_when_the_file_size_is_a_multiple_of_the_chunk_size(bnp, monk
     for size in (159, 53, 63, 160, 16, 3, 1000):
         got = _records_through(bnp, monkeypatch, fastq, bnp.io.FastQBuffer, size, ahead, tmp_path)
         assert got == ["q%d" % i for i in range(10)], (size, got)
+
+
+# ------------------------------------------------------------------------------------ count_encoded(weights=...)
+def test_count_encoded_with_weights(bnp):
+    # bionumpy/sequence/count_encoded.py:166-187 against its statement-by-statement restatement (oracle.count_weighted).
+    # Integer / bool weights are accumulated in int64: bit-exact.  Floating-point weights are added with atomics, in
+    # another order than numpy's loop: equal up to the rounding of the additions — rtol 1e-12 of the bin's sum of |w|.
+    rng = np.random.default_rng(11)
+    seq = "".join(rng.choice(list("ACGT"), size=5000))
+    values = bnp.as_encoded_array(seq, bnp.DNAEncoding)
+    codes = np.array(["ACGT".index(c) for c in seq])
+    for w in (rng.integers(0, 100, size=5000), rng.integers(-5, 5, size=5000).astype(np.int32), rng.random(5000) < 0.3):
+        got = bnp.count_encoded(values, weights=w)
+        expect = oracle.count_weighted(codes, w, 4)
+        assert got.counts.dtype == expect.dtype == np.float64 and np.array_equal(got.counts, expect)
+        assert got.alphabet == ["A", "C", "G", "T"] and got["G"] == expect[2]
+        assert np.array_equal(bnp.count_encoded(values, weights=w, axis=None).counts, expect)
+    wf = rng.normal(size=5000) * 10.0 ** rng.integers(-3, 6, size=5000)
+    got, expect = bnp.count_encoded(values, weights=wf).counts, oracle.count_weighted(codes, wf, 4)
+    scale = np.bincount(codes, weights=np.abs(wf), minlength=4)
+    assert got.dtype == np.float64 and np.all(np.abs(got - expect) <= 1e-12 * scale)
+    # 2-D weights: one histogram of the flat values per row of the weights; integer counts unless the weights are floats
+    w2 = rng.integers(0, 7, size=(6, 5000))
+    got, expect = bnp.count_encoded(values, weights=w2).counts, oracle.count_weighted(codes, w2, 4)
+    assert got.shape == (6, 4) and np.issubdtype(got.dtype, np.integer) and np.array_equal(got, expect)
+    w2f = rng.random((3, 5000))
+    got, expect = bnp.count_encoded(values, weights=w2f).counts, oracle.count_weighted(codes, w2f, 4)
+    assert got.dtype == np.float64 and np.allclose(got, expect, rtol=1e-12, atol=0)
+    assert np.array_equal(bnp.count_encoded(values, weights=(w2 > 3)).counts, oracle.count_weighted(codes, w2 > 3, 4))
+    # rows of values under the same 1-D weights ("for row in values")
+    reads = ["".join(rng.choice(list("ACGT"), size=40)) for _ in range(25)]
+    rows = bnp.as_encoded_array(reads, bnp.DNAEncoding)
+    w1 = rng.integers(1, 9, size=40)
+    mat = np.array([["ACGT".index(c) for c in r] for r in reads])
+    got, expect = bnp.count_encoded(rows, weights=w1).counts, oracle.count_weighted(mat, w1, 4)
+    assert got.shape == (25, 4) and got.dtype == np.float64 and np.array_equal(got, expect)
+    assert np.array_equal(bnp.count_encoded(rows, weights=np.tile(w1, 25), axis=None).counts, oracle.count_weighted(mat, np.tile(w1, 25), 4, axis=None))
+    # k-mers (dense alphabets of 4^k bins): every 3-mer weighted by its position
+    kmers = bnp.sequence.get_kmers(values, 3)
+    h = oracle.kmer_hashes_flat(codes.astype(np.uint8), 3)
+    pos = np.arange(h.size)
+    got = bnp.count_encoded(kmers, weights=pos)
+    assert np.array_equal(got.counts, oracle.count_weighted(h, pos, 64)) and got["ACG"] == float(pos[h == 0 + 4 * 1 + 16 * 2].sum())
+    # what numpy refuses is refused
+    with pytest.raises(ValueError):
+        bnp.count_encoded(values, weights=np.ones(4999))
+    with pytest.raises(ValueError):
+        bnp.count_encoded(bnp.as_encoded_array(["ACGT", "AC"], bnp.DNAEncoding), weights=np.ones(4))
+
+
+def test_minimizers_of_any_alphabet(bnp):
+    # get_minimizers accepts any AlphabetEncoding (sequence/minimizers.py:48-52): the rolling hash of KmerEncoder
+    # (codes . alphabet_size ** arange(k), wrapping int64) and the smallest of each window as numpy compares int64
+    rng = np.random.default_rng(12)
+    for letters, k, window in (("ACGTN", 3, 6), ("ACGTN", 5, 5), ("ACDEFGHIKLMNPQRSTVWY", 4, 9), ("AB", 7, 20),
+                               ("ACDEFGHIKLMNPQRSTVWY", 15, 17)):          # 20^15 wraps int64: negative hashes take part in the min
+        enc = bnp.AlphabetEncoding(letters)
+        reads = ["".join(rng.choice(list(letters), size=n)) for n in (40, 0, window - 1, window, 200, 3)]
+        seqs = bnp.as_encoded_array(reads, enc)
+        got = bnp.sequence.get_minimizers(seqs, k, window)
+        codes = np.concatenate([np.array([letters.index(c) for c in r], dtype=np.uint8) for r in reads])
+        lens = np.array([len(r) for r in reads])
+        expect, new_lens = oracle.get_minimizers(codes, lens, k, window, len(letters))
+        assert [len(r) for r in got] == new_lens.tolist() == [max(0, n - window + 1) for n in lens]
+        assert np.array_equal(np.concatenate([np.asarray(r) for r in got.raw()]), expect), (letters, k, window)
+        assert got.encoding == bnp.sequence.get_kmers(seqs, k).encoding
+    # one sequence (an EncodedArray) gives an EncodedArray
+    enc = bnp.AlphabetEncoding("ACGTN")
+    one = bnp.sequence.get_minimizers(bnp.as_encoded_array("ACGTNNACGTNACG", enc), 2, 5)
+    codes = np.array(["ACGTN".index(c) for c in "ACGTNNACGTNACG"], dtype=np.uint8)
+    assert np.array_equal(one.raw(), oracle.get_minimizers(codes, np.array([14]), 2, 5, 5)[0]) and str(one[0]) == "AC"

@@ -2,6 +2,7 @@
 
 * more than 2^32 base positions in one batch (the regression test for the 32-bit position overflow that
   scripts/debug_large.py chased in round 1): size-independent checks of tests/fullsize.py;
+* BASELINE config 3 at its configuration: the minimizers (k = 31, window 40) of 30 M reads, every one of them;
 * S-genome (reads of a fixed genome, every 31-mer ~60 times): the WHOLE histogram of 1 M reads against
   oracle.count_sparse (np.unique) — the duplicate-heavy path: general finishing kernel, pre-counted buckets;
 * config 5: the 31-mer index of sacCer3 (12 Mbases, 17 records, multi-line FASTA) pair for pair against the oracle's
@@ -38,6 +39,15 @@ def test_histogram_of_more_than_2_pow_32_base_positions(ops):
     assert stats.n_kmers == n_reads * (read_len - k + 1)
     done = fullsize.check_histogram(ops, text, n_reads, read_len, k, seed, 0, 0, 0, keys, counts)
     assert done["kmers"] == stats.n_kmers and done["sampled_kmers_vs_oracle"] > 300_000
+
+
+def test_config3_minimizers_at_full_size(ops):
+    """BASELINE config 3 (k = 31, window_size = 40: w = 10 k-mers per window) on 30 M reads — 3.33e9 minimizers: the fused
+    pipeline's output against the row-lookup kernel element for element, and against the oracle on sampled reads"""
+    n_reads, read_len, k, window, seed = 30_000_000, 150, 31, 40, 20260925
+    text = ops.synth_fastq(n_reads, read_len, seed, 0, 0, 0)
+    done = fullsize.check_minimizers(ops, text, n_reads, read_len, k, window, seed, 0, 0)
+    assert done["minimizers"] == n_reads * (read_len - window + 1) and done["sampled_minimizers_vs_oracle"] >= 3000 * 111 - 111
 
 
 @pytest.mark.parametrize("canonical,n_reads,genome_len", [(False, 1_000_000, 2_000_000), (True, 300_000, 600_000)])
