@@ -169,7 +169,7 @@ def virtual_ranks_mode(args, ops, dev, mode):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        hists, stats, received = fastq_kmer_histogram_virtual_ranks(texts, args.k, canonical=args.canonical)
+        hists, stats, received, plan = fastq_kmer_histogram_virtual_ranks(texts, args.k, canonical=args.canonical, with_plan=True)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     sums = [0, 0, 0, 0]
@@ -185,7 +185,7 @@ def virtual_ranks_mode(args, ops, dev, mode):
     print(json.dumps({"mode": "virtual ranks (one GPU plays N ranks; functional, not a scaling number)", "virtual_ranks": n,
                       "reads_total": args.reads, "k": args.k, "ms_per_step": round(dt * 1e3, 2),
                       "gbases_per_s_one_gpu_doing_all_ranks": round(sum(s.n_bases for s in stats) / dt / 1e9, 3),
-                      "keys_received_per_rank": received, "distinct_per_rank": [k.size for k, _ in hists],
+                      "plan": plan, "int64_words_received_per_rank": received, "distinct_per_rank": [k.size for k, _ in hists],
                       "parity": "count / sum / sum of squares / mixed sum of all ranks' (key, count) == k-mers in read order; "
                                 "key ranges disjoint and ascending"}))
 
@@ -324,6 +324,8 @@ def main():
         ek, ec = oracle.count_sparse(oracle.canonical_kmers(h, args.k) if args.canonical else h)
         assert np.array_equal(sub[0].host(), ek) and np.array_equal(sub[1].host(), ec), "verify failed"
 
+    from bionumpy_amd import parallel
+    merge = parallel.last
     gbases = world * stats.n_bases * args.steps / dt / 1e9
     # dominant kernel and its roofline
     dom = max(prof, key=lambda kname: prof[kname]["total_ms"]) if prof else None
@@ -396,7 +398,9 @@ def main():
                    "reads_per_gpu": args.reads, "read_len": args.read_len, "k": args.k, "mode": args.mode,
                    "canonical": bool(args.canonical), "kmers_per_gpu": stats.n_kmers, "distinct_rank0": n_distinct,
                    "histogram": "dense" if args.k <= 13 else "sparse (sorted unique int64 keys + counts)",
-                   "parallelism": "chunk-sharded x%d%s" % (world, ", key-range all-to-all" if world > 1 else "")},
+                   "parallelism": "chunk-sharded x%d%s" % (world, ", key-range exchange of %s over %s" % (
+                       {"keys": "raw hashes", "counts": "(key, count) runs of the local histograms"}.get(merge["plan"], "dense bins"),
+                       merge["collectives"]) if world > 1 else "")},
         "roofline": roofline,
         "kernels": kernels,
         "per_rank": per_rank,

@@ -47,6 +47,14 @@ SIGNATURES = {
     "bnpk_prof_enable": (_int, [_p, _int]),
     "bnpk_copy_peak": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_set_option": (_int, [_p, C.c_char_p, _i64]),
+    "bnpk_comm_unique_id": (_int, [_p]),
+    "bnpk_comm_init": (_int, [_p, _p, _int, _int, C.POINTER(C.c_void_p)]),
+    "bnpk_comm_destroy": (_int, [_p]),
+    "bnpk_comm_shape": (_int, [_p, C.POINTER(_int), C.POINTER(_int)]),
+    "bnpk_last_comm_error": (C.c_char_p, []),
+    "bnpk_allreduce_hist": (_int, [_p, _p, _p, _i64, _p]),
+    "bnpk_exchange_counts": (_int, [_p, _p, _p, _int, _p, _p]),
+    "bnpk_exchange_by_key_range": (_int, [_p, _p, _p, _p, _p, _p, _p]),
     "bnpk_prof_reset": (_int, [_p]),
     "bnpk_prof_count": (_int, [_p]),
     "bnpk_prof_get": (_int, [_p, _int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbnpk.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "scan.hip", "decode.hip", "multiline.hip", "fastq.hip", "encode.hip", "kmers.hip", "revcomp.hip", "rowops.hip", "radix.hip", "finish.hip", "finish_dup.hip", "finish_wave.hip", "merge.hip", "count.hip", "synth.hip"]
+SOURCES = ["api.hip", "scan.hip", "decode.hip", "multiline.hip", "fastq.hip", "encode.hip", "kmers.hip", "revcomp.hip", "rowops.hip", "radix.hip", "finish.hip", "finish_dup.hip", "finish_wave.hip", "merge.hip", "count.hip", "synth.hip", "collectives.hip"]
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"), os.path.join(HERE, "rows.h"),
            os.path.join(HERE, "kmer_gen.h"), os.path.join(HERE, "finish.h"),
            os.path.join(ROOT, "include", "bnpk.h")]
@@ -85,7 +85,7 @@ def build(force=False, verbose=True):
         built = list(ex.map(lambda s: _compile(hipcc, s), SOURCES))
     objs = [o for o, _ in built]
     if True:                                              # the digest differs from the library's stamp: always relink
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

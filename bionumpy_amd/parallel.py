@@ -1,22 +1,36 @@
 """Multi-GPU: chunks shard embarrassingly (records are independent, k-mers never span records); the
 only exchange is the final merge of the per-GPU k-mer histograms.
 
-One process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm, "gloo" in the CPU
-tests).
+One process per GPU.  The collectives are the C-ABI's (include/bnpk.h: bnpk_allreduce_hist, bnpk_exchange_counts,
+bnpk_exchange_by_key_range — RCCL over xGMI behind ``libbnpk.so``); ``torch.distributed`` launches the ranks, hands
+rank 0's communicator id to the others, and carries the collectives itself only in the CPU tests ("gloo") or when the
+ABI's communicator cannot be made (reported, never silent).
 
-* dense histograms (k <= 13): ``all_reduce(sum)`` of the 4^k int64 bins.
-* sparse histograms (k up to 31): the 62-bit key space is cut into ``world`` contiguous ranges; every
-  rank stably partitions its raw hashes by the top bits of the key (one radix pass), the partitions
-  are exchanged with one uneven all-to-all (each of the 7 xGMI links of a GPU carries 1/8 of its keys
-  concurrently), and every rank then sorts + run-length-encodes only the range it owns.  The result
-  stays distributed: rank r holds the sorted distinct keys of range r and their global counts.
+* dense histograms (k <= 13): all-reduce (sum) of the 4^k int64 bins.
+* sparse histograms (k up to 31): the 62-bit key space is cut into ``world`` contiguous ranges and the result stays
+  distributed — rank r holds the sorted distinct keys of range r and their global counts.  Two plans, chosen from the
+  data (``choose_plan``: every rank counts one of its fine buckets; the distinct / total ratio is summed over ranks):
+
+  - ``keys``   (nearly) duplicate-free k-mers: every rank generates its hashes already grouped by their top bits
+    (bnpk_kmers_partition; the bucket boundaries are the send cuts), ONE exchange moves every raw 8-byte hash to the
+    rank that owns its range (each of a GPU's 7 xGMI links carries 1/8 of its keys concurrently), and every rank
+    partitions + finishes only its own range;
+  - ``counts`` duplicate-heavy k-mers (reads that cover a genome many times: S-genome holds every 31-mer ~60 times):
+    every rank counts its OWN k-mers first — the single-GPU path, unchanged — cuts its sorted (key, count) list at the
+    range boundaries, and the exchange moves 16 bytes per DISTINCT key instead of 8 per k-mer (S-genome: 1.6 GB
+    instead of 48 GB per GPU); the ``world`` sorted runs a rank receives are summed by a tree of merges (bnpk_merge_add).
 """
+import ctypes as C
+import sys
+
 import numpy as np
 
 from .device import HArray
 from .ops import get_ops
 
 FINE_BITS = 8          # partition granularity: 256 fine buckets, contiguous groups of them per rank
+COUNTS_PLAN_MAX_RATIO = 0.25      # distinct / total below which 16 B per distinct key beats 8 B per k-mer (with room)
+PROBE_KEYS = 4 << 20              # keys of one fine bucket that a rank counts to estimate the ratio
 
 
 def _dist():
@@ -37,83 +51,276 @@ def _from_tensor(t, ops):
     return HArray(dev=t)
 
 
+# ---- collectives ---------------------------------------------------------------------------------------------------
+class TorchCollectives:
+    """the three collectives over ``torch.distributed`` (gloo in the CPU tests)"""
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        self.group = group
+        dist = _dist()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def allreduce_sum(self, hist):
+        ops, dist = get_ops(), _dist()
+        t = _as_tensor(hist, ops)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return _from_tensor(t, ops)
+
+    def exchange_counts(self, send_counts):
+        import torch
+        dist = _dist()
+        send = np.ascontiguousarray(send_counts, dtype=np.int64)
+        dev = "cpu" if getattr(get_ops(), "host_only", False) else "cuda"
+        t_in = torch.from_numpy(send).to(dev)
+        t_out = torch.empty_like(t_in)
+        dist.all_to_all_single(t_out, t_in, group=self.group)
+        return t_out.cpu().numpy()
+
+    def exchange(self, send, send_counts, recv_counts):
+        import torch
+        ops, dist = get_ops(), _dist()
+        send_t = _as_tensor(send, ops)
+        recv_t = torch.empty(int(np.sum(recv_counts)), dtype=torch.int64, device=send_t.device)
+        dist.all_to_all_single(recv_t, send_t, output_split_sizes=[int(c) for c in recv_counts],
+                               input_split_sizes=[int(c) for c in send_counts], group=self.group)
+        return _from_tensor(recv_t, ops)
+
+
+class AbiCollectives:
+    """the same over the C-ABI (RCCL inside libbnpk.so): a communicator of its own, made from an id that rank 0 takes and
+    torch.distributed broadcasts"""
+    name = "bnpk C-ABI (RCCL)"
+
+    def __init__(self, group=None):
+        from ._native import lib, check
+        from .device import Device
+        dist = _dist()
+        self.lib, self._check = lib, check
+        self.dev = Device.get()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [None]
+        if self.rank == 0:
+            ident = (C.c_uint8 * 128)()
+            check(lib.bnpk_comm_unique_id(ident), self.dev.ctx)
+            box[0] = bytes(ident)
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        comm = C.c_void_p()
+        check(lib.bnpk_comm_init(self.dev.ctx, ident, self.world, self.rank, C.byref(comm)), self.dev.ctx)
+        self.comm = comm
+        # one small all-reduce before anything depends on it
+        import torch
+        probe = torch.ones(1, dtype=torch.int64, device=self.dev.tdev)
+        self._chk(lib.bnpk_allreduce_hist(self.dev.ctx, self.comm, C.c_void_p(probe.data_ptr()), 1, self.dev.stream()))
+        if int(probe.item()) != self.world:
+            raise RuntimeError("bnpk_allreduce_hist over %d ranks returned %d" % (self.world, int(probe.item())))
+
+    def _chk(self, status):
+        if status != 0:
+            raise RuntimeError("bnpk collective failed (status %d): %s" % (status, self.lib.bnpk_last_comm_error().decode()))
+
+    def allreduce_sum(self, hist):
+        t = hist.dev()
+        self._chk(self.lib.bnpk_allreduce_hist(self.dev.ctx, self.comm, C.c_void_p(t.data_ptr()), t.numel(), self.dev.stream()))
+        return HArray(dev=t)
+
+    def exchange_counts(self, send_counts):
+        send = np.ascontiguousarray(send_counts, dtype=np.int64)
+        recv = np.empty_like(send)
+        self._chk(self.lib.bnpk_exchange_counts(self.dev.ctx, self.comm, send.ctypes.data_as(C.c_void_p), send.size // self.world,
+                                                recv.ctypes.data_as(C.c_void_p), self.dev.stream()))
+        return recv
+
+    def exchange(self, send, send_counts, recv_counts):
+        import torch
+        send_t = send.dev()
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        recv_t = torch.empty(int(rc.sum()), dtype=torch.int64, device=send_t.device)
+        self._chk(self.lib.bnpk_exchange_by_key_range(self.dev.ctx, self.comm, C.c_void_p(send_t.data_ptr()), sc.ctypes.data_as(C.c_void_p),
+                                                      C.c_void_p(recv_t.data_ptr()), rc.ctypes.data_as(C.c_void_p), self.dev.stream()))
+        return HArray(dev=recv_t)
+
+
+_collectives = {}
+last = {"plan": None, "collectives": None}     # what the last sparse merge of this process did (bench.py reports it)
+
+
+def collectives(group=None):
+    """the collectives of a process group (made once): the C-ABI's on the GPU, torch.distributed's in the CPU tests"""
+    key = id(group)
+    if key not in _collectives:
+        if getattr(get_ops(), "host_only", False):
+            _collectives[key] = TorchCollectives(group)
+        else:
+            try:
+                _collectives[key] = AbiCollectives(group)
+            except Exception as e:                       # said aloud; the run goes on over torch.distributed's RCCL
+                sys.stderr.write("bionumpy_amd.parallel: the C-ABI communicator could not be made (%s: %s); the collectives "
+                                 "run over torch.distributed\n" % (type(e).__name__, e))
+                _collectives[key] = TorchCollectives(group)
+    return _collectives[key]
+
+
 def allreduce_dense(hist, group=None):
     """sum of dense histograms over all ranks (EncodedCounts.__add__ across GPUs)"""
-    ops = get_ops()
-    dist = _dist()
-    t = _as_tensor(hist, ops)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return _from_tensor(t, ops)
+    return collectives(group).allreduce_sum(hist)
 
 
+# ---- key ranges ------------------------------------------------------------------------------------------------------
 def rank_of_bucket(world):
     """fine bucket -> owning rank (contiguous, balanced)"""
     return (np.arange(1 << FINE_BITS, dtype=np.int64) * world) >> FINE_BITS
 
 
+def key_range_of(rank, world, key_bits):
+    mine = np.flatnonzero(rank_of_bucket(world) == rank)
+    return int(mine[0]) << (key_bits - FINE_BITS), (int(mine[-1]) + 1) << (key_bits - FINE_BITS)
+
+
+def _slice(h, a, b):
+    return HArray(dev=h.dev()[a:b]) if h.on_device else HArray(host=h.host()[a:b])
+
+
+def probe_ratio(part, cuts, key_bits, rank=0):
+    """(distinct, total) of one fine bucket of this rank's k-mers (at most PROBE_KEYS of them)"""
+    ops = get_ops()
+    sizes = np.diff(cuts)
+    if sizes.sum() == 0:
+        return 0, 0
+    order = np.flatnonzero(sizes > 0)
+    b = int(order[(rank * 37) % order.size])                 # (different ranks look at different buckets)
+    a, e = int(cuts[b]), int(min(cuts[b + 1], cuts[b] + PROBE_KEYS))
+    sample = _slice(part, a, e)
+    sample = HArray(dev=sample.dev().clone()) if sample.on_device else HArray(host=sample.host().copy())
+    keys, _ = ops.count_sparse(sample, key_bits=key_bits, consume=True)
+    return keys.size, e - a
+
+
+def choose_plan(distinct, total):
+    return "counts" if total > 0 and distinct <= COUNTS_PLAN_MAX_RATIO * total else "keys"
+
+
+def _merge_runs(runs):
+    """the sum of sorted (keys, counts) runs: a tree of pairwise merges along the merge path (bnpk_merge_add)"""
+    ops = get_ops()
+    runs = [r for r in runs if r[0].size]
+    if not runs:
+        empty = HArray(host=np.zeros(0, dtype=np.int64))
+        return empty, HArray(host=np.zeros(0, dtype=np.int64))
+    while len(runs) > 1:
+        merged = [ops.merge_add(a[0], a[1], b[0], b[1]) for a, b in zip(runs[0::2], runs[1::2])]
+        if len(runs) % 2:
+            merged.append(runs[-1])
+        runs = merged
+    return runs[0]
+
+
+def _range_cuts(keys, world, key_bits):
+    """positions in a sorted key list where the ranks' key ranges begin (world + 1 of them)"""
+    ops = get_ops()
+    bounds = np.array([key_range_of(r, world, key_bits)[0] for r in range(world)], dtype=np.int64)
+    pos = ops.search_sorted(keys, HArray(host=bounds)).host()
+    return np.concatenate([pos, [keys.size]]).astype(np.int64)
+
+
+# ---- the two plans -----------------------------------------------------------------------------------------------------
 def exchange_by_key_range(hashes, key_bits, group=None, cuts=None):
-    """all-to-all of raw k-mer hashes so that every rank ends up with exactly the keys of its own range.
+    """plan "keys": all-to-all of raw k-mer hashes so that every rank ends up with exactly the keys of its own range.
 
     ``hashes`` (HArray int64, consumed) -> (HArray int64 of the received keys, unsorted within the range,
     (lo, hi) key range this rank owns).
     cuts: bucket boundaries if the hashes are already grouped by their top FINE_BITS bits
     (bnpk_kmers_partition); otherwise one radix level partitions them here."""
     ops = get_ops()
-    dist = _dist()
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    owner = rank_of_bucket(world)
-    mine = np.flatnonzero(owner == rank)
-    key_range = (int(mine[0]) << (key_bits - FINE_BITS), (int(mine[-1]) + 1) << (key_bits - FINE_BITS))
+    coll = collectives(group)
+    world, rank = coll.world, coll.rank
+    key_range = key_range_of(rank, world, key_bits)
     if world == 1:
         return hashes, key_range
-    import torch
     if cuts is not None:
         part, cuts = hashes, np.asarray(cuts.host(), dtype=np.int64)
     else:
         part, cuts = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
-    bucket_sizes = np.diff(cuts)
-    send_counts = np.bincount(owner, weights=bucket_sizes, minlength=world).astype(np.int64)
-    send_t = _as_tensor(part, ops)
-    counts_in = torch.tensor(send_counts, dtype=torch.int64, device=send_t.device)
-    counts_out = torch.empty_like(counts_in)
-    dist.all_to_all_single(counts_out, counts_in, group=group)
-    recv_counts = counts_out.cpu().numpy()
-    recv_t = torch.empty(int(recv_counts.sum()), dtype=torch.int64, device=send_t.device)
-    dist.all_to_all_single(recv_t, send_t, output_split_sizes=recv_counts.tolist(),
-                           input_split_sizes=send_counts.tolist(), group=group)
-    return _from_tensor(recv_t, ops), key_range
+    send_counts = np.bincount(rank_of_bucket(world), weights=np.diff(cuts), minlength=world).astype(np.int64)
+    recv_counts = coll.exchange_counts(send_counts)
+    return coll.exchange(part, send_counts, recv_counts), key_range
 
 
-def count_sparse_virtual(shards, key_bits):
-    """The N > 1 sparse path on ONE GPU: ``shards`` = [(hashes partitioned by their top FINE_BITS bits, cuts)] of N
-    virtual ranks (what kmers_partitioned(FINE_BITS) leaves on every rank before the exchange).  The all-to-all is
-    replaced by what it delivers — for destination r the slices of its fine buckets from source 0, 1, .. N-1, one
-    after the other — and every destination then counts its own key range exactly as count_sparse_distributed does.
-    Returns [(keys, counts)] per virtual rank (concatenated: the histogram of all shards) and the per-rank key counts."""
-    ops = get_ops()
-    world = len(shards)
-    owner = rank_of_bucket(world)
-    cuts = [np.asarray(c.host(), dtype=np.int64) for _, c in shards]
-    out, received = [], []
-    for r in range(world):
-        mine = np.flatnonzero(owner == r)
-        lo_b, hi_b = int(mine[0]), int(mine[-1]) + 1
-        key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
-        pieces = [HArray(dev=part.dev()[c[lo_b]:c[hi_b]]) if not getattr(ops, "host_only", False)
-                  else HArray(host=part.host()[c[lo_b]:c[hi_b]]) for (part, _), c in zip(shards, cuts)]
-        recv = ops.concat(pieces)                       # == the receive buffer of all_to_all_single on rank r
-        received.append(recv.size)
-        out.append(ops.count_sparse(recv, key_bits=key_bits, consume=True, key_range=key_range))
-    return out, received
+def exchange_counted(keys, counts, key_bits, group=None):
+    """plan "counts": this rank's sorted (keys, counts) -> the global (keys, counts) of the key range it owns"""
+    coll = collectives(group)
+    world = coll.world
+    if world == 1:
+        return keys, counts
+    pos = _range_cuts(keys, world, key_bits)
+    send_counts = np.diff(pos)
+    recv_counts = coll.exchange_counts(send_counts)
+    rk = coll.exchange(keys, send_counts, recv_counts)
+    rc = coll.exchange(counts, send_counts, recv_counts)
+    off = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.int64)
+    return _merge_runs([(_slice(rk, int(off[q]), int(off[q + 1])), _slice(rc, int(off[q]), int(off[q + 1]))) for q in range(world)])
 
 
-def count_sparse_distributed(hashes, key_bits, group=None, cuts=None):
-    """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range"""
+def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto"):
+    """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range.
+    ``hashes`` grouped by their top FINE_BITS bits with bucket boundaries ``cuts`` (bnpk_kmers_partition), or raw."""
     ops = get_ops()
     if isinstance(hashes, list):              # [HArray]: the caller gave its only reference away
         held = hashes
         hashes = held.pop()
+    coll = collectives(group)
+    if cuts is None:
+        hashes, cuts_np = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
+        cuts = HArray(host=np.asarray(cuts_np, dtype=np.int64))
+    if plan == "auto":
+        d, t = probe_ratio(hashes, np.asarray(cuts.host(), dtype=np.int64), key_bits, coll.rank)
+        both = coll.allreduce_sum(HArray(host=np.array([d, t], dtype=np.int64))).host()
+        plan = choose_plan(int(both[0]), int(both[1]))
+    last["plan"], last["collectives"] = plan, coll.name
+    if plan == "counts":
+        keys, counts = ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, FINE_BITS))
+        del hashes
+        return exchange_counted(keys, counts, key_bits, group)
     mine, key_range = exchange_by_key_range(hashes, key_bits, group, cuts)
     del hashes
     return ops.count_sparse(mine, key_bits=key_bits, consume=True, key_range=key_range)
+
+
+def count_sparse_virtual(shards, key_bits, plan="auto"):
+    """The N > 1 sparse path on ONE GPU: ``shards`` = [(hashes partitioned by their top FINE_BITS bits, cuts)] of N
+    virtual ranks (what kmers_partitioned(FINE_BITS) leaves on every rank before the exchange).  The exchange is
+    replaced by what it delivers — for destination r the slices of its range from source 0, 1, .. N-1, one after the
+    other — and everything else is what count_sparse_distributed does: the probe and the choice of the plan, the
+    per-range counting (plan "keys") or the local histograms, their cuts and the tree of merges (plan "counts").
+    Returns ([(keys, counts)] per virtual rank — concatenated: the histogram of all shards —, the words every rank
+    received, the plan)."""
+    ops = get_ops()
+    world = len(shards)
+    owner = rank_of_bucket(world)
+    cuts = [np.asarray(c.host(), dtype=np.int64) for _, c in shards]
+    if plan == "auto":
+        d = t = 0
+        for r, ((part, _), c) in enumerate(zip(shards, cuts)):
+            dr, tr = probe_ratio(part, c, key_bits, r)
+            d, t = d + dr, t + tr
+        plan = choose_plan(d, t)
+    out, received = [], []
+    if plan == "counts":
+        local = [ops.count_sparse(part, key_bits=key_bits, partition=(c, FINE_BITS)) for part, c in shards]   # (c: the HArray)
+        pos = [_range_cuts(k, world, key_bits) for k, _ in local]
+        for r in range(world):
+            runs = [(_slice(k, int(p[r]), int(p[r + 1])), _slice(c, int(p[r]), int(p[r + 1]))) for (k, c), p in zip(local, pos)]
+            received.append(2 * sum(run[0].size for run in runs))
+            out.append(_merge_runs(runs))
+        return out, received, plan
+    for r in range(world):
+        mine = np.flatnonzero(owner == r)
+        lo_b, hi_b = int(mine[0]), int(mine[-1]) + 1
+        key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
+        pieces = [_slice(part, int(c[lo_b]), int(c[hi_b])) for (part, _), c in zip(shards, cuts)]
+        recv = ops.concat(pieces)                       # == the receive buffer of the exchange on rank r
+        received.append(recv.size)
+        out.append(ops.count_sparse(recv, key_bits=key_bits, consume=True, key_range=key_range))
+    return out, received, plan

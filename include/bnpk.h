@@ -58,6 +58,35 @@ const char* bnpk_last_hip_error(bnpk_ctx* ctx);
 /* name (<=63 chars), compute units, total HBM bytes of the ctx's device */
 int         bnpk_device_info(bnpk_ctx* ctx, char* name64, int* compute_units, int64_t* hbm_bytes);
 
+/* ---- multi-GPU: the merge of per-GPU histograms, RCCL over xGMI ------------------------------------
+ * One process per GPU.  The reference has no multi-device path; these entry points replace EncodedCounts.__add__ across
+ * chunks (bionumpy/sequence/count_encoded.py:38-55) for chunks counted on different GPUs.  `comm` is an ncclComm_t —
+ * the caller's own, or one from bnpk_comm_init: rank 0 takes an id with bnpk_comm_unique_id and hands its
+ * BNPK_COMM_ID_BYTES bytes to the other ranks (any side channel), then every rank calls bnpk_comm_init.  RCCL is loaded
+ * on first use; BNPK_ERR_NODEVICE if librccl is not there, BNPK_ERR_HIP + bnpk_last_comm_error() if RCCL reports an error.
+ *   bnpk_allreduce_hist         dense histograms (k <= 13): ncclAllReduce(int64, sum) over the bins, in place
+ *   bnpk_exchange_counts        every rank tells every rank n_per_peer int64 numbers (how much it will send: per rank, or
+ *                               per fine bucket of that rank's key range): h_send_counts[p * n_per_peer + i] goes to rank
+ *                               p, h_recv_counts[q * n_per_peer + i] came from rank q.  Synchronous.
+ *   bnpk_exchange_by_key_range  sparse histograms: d_send holds the items for rank 0, 1, ... back to back
+ *                               (h_send_counts[p] int64 words each — raw hashes grouped by key range, bnpk_kmers_partition's
+ *                               output, or the keys / the counts of a local histogram cut at the range boundaries), d_recv
+ *                               receives the slices of rank 0, 1, ... back to back (h_recv_counts[q] words, from
+ *                               bnpk_exchange_counts).  One grouped ncclSend/ncclRecv step: the N - 1 transfers of a GPU
+ *                               run concurrently, one per xGMI link; the rank's own slice is a device copy.  Asynchronous
+ *                               on `stream`. */
+#define BNPK_COMM_ID_BYTES 128
+int bnpk_comm_unique_id(uint8_t* id128);
+int bnpk_comm_init(bnpk_ctx* ctx, const uint8_t* id128, int n_ranks, int rank, void** comm_out);
+int bnpk_comm_destroy(void* comm);
+int bnpk_comm_shape(void* comm, int* n_ranks, int* rank);
+const char* bnpk_last_comm_error(void);
+int bnpk_allreduce_hist(bnpk_ctx* ctx, void* comm, int64_t* d_hist, int64_t bins, void* stream);
+int bnpk_exchange_counts(bnpk_ctx* ctx, void* comm, const int64_t* h_send_counts, int n_per_peer, int64_t* h_recv_counts,
+                         void* stream);
+int bnpk_exchange_by_key_range(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const int64_t* h_send_counts, int64_t* d_recv,
+                               const int64_t* h_recv_counts, void* stream);
+
 /* per-kernel hipEvent timers (used by bench.py for the live roofline numbers) */
 int bnpk_prof_enable(bnpk_ctx* ctx, int on);
 int bnpk_prof_reset(bnpk_ctx* ctx);

@@ -30,6 +30,15 @@ def main():
             out[k] = (hist[0].host().copy(), hist[1].host().copy())
         else:
             out[k] = hist.host().copy()
+    # both plans of the sparse merge, forced: raw hashes to their key range / local histograms cut at the range boundaries
+    ops = ops_mod.get_ops()
+    res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+    codes = oracle.encode_dna(oracle.gather_rows(text, res.field_starts[:, 1], res.field_lens[:, 1]))
+    mine, _ = oracle.get_kmers(codes, res.field_lens[:, 1], 31)
+    for plan in ("keys", "counts"):
+        keys, counts = parallel.count_sparse_distributed(HArray(host=mine.copy()), 62, plan=plan)
+        out[plan] = (keys.host().copy(), counts.host().copy())
+    assert parallel.collectives().name == "torch.distributed"
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:
@@ -50,6 +59,10 @@ def main():
                 bounds = [g[k][0] for g in gathered]
                 for a, b in zip(bounds[:-1], bounds[1:]):
                     assert a.size == 0 or b.size == 0 or a[-1] < b[0], "rank ranges overlap"
+                if k == 31:
+                    for plan in ("keys", "counts"):
+                        assert np.array_equal(np.concatenate([gathered[r][plan][0] for r in range(world)]), ek), plan
+                        assert np.array_equal(np.concatenate([gathered[r][plan][1] for r in range(world)]), ec), plan
         print("DIST_OK")
     dist.destroy_process_group()
 

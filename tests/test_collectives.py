@@ -1,0 +1,83 @@
+"""-m gpu: the multi-GPU entry points of the C-ABI (include/bnpk.h: bnpk_comm_*, bnpk_allreduce_hist, bnpk_exchange_counts,
+bnpk_exchange_by_key_range) on what one GPU can run — a communicator of ONE rank (RCCL is loaded, the communicator is
+made, every collective goes through RCCL's grouped send/recv or all-reduce and comes back with this rank's own data) —
+and the two plans of the sparse merge played by one GPU for N ranks (parallel.count_sparse_virtual) against the
+unsharded histogram.  N > 1 processes: tests/test_parallel.py (gloo, CPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import Device, ptr
+    return lib, Device.get(), ptr, torch
+
+
+def test_one_rank_communicator_through_the_abi(env):
+    lib, dev, ptr, torch = env
+    ident = (C.c_uint8 * 128)()
+    assert lib.bnpk_comm_unique_id(ident) == 0 and any(ident)
+    comm = C.c_void_p()
+    assert lib.bnpk_comm_init(dev.ctx, ident, 1, 0, C.byref(comm)) == 0, lib.bnpk_last_comm_error()
+    try:
+        world, rank = C.c_int(-1), C.c_int(-1)
+        assert lib.bnpk_comm_shape(comm, C.byref(world), C.byref(rank)) == 0 and (world.value, rank.value) == (1, 0)
+        hist = torch.arange(4 ** 8, dtype=torch.int64, device="cuda") * 3 - 7
+        expect = hist.clone()
+        assert lib.bnpk_allreduce_hist(dev.ctx, comm, ptr(hist), hist.numel(), dev.stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(hist, expect)                                  # the sum over one rank
+        send_counts = np.array([123_457], dtype=np.int64)
+        recv_counts = np.zeros(1, dtype=np.int64)
+        assert lib.bnpk_exchange_counts(dev.ctx, comm, send_counts.ctypes.data_as(C.c_void_p), 1,
+                                        recv_counts.ctypes.data_as(C.c_void_p), dev.stream()) == 0
+        assert recv_counts.tolist() == [123_457]
+        per_bucket = np.arange(32, dtype=np.int64) * 11                   # (per fine bucket of the peer's range)
+        got = np.zeros(32, dtype=np.int64)
+        assert lib.bnpk_exchange_counts(dev.ctx, comm, per_bucket.ctypes.data_as(C.c_void_p), 32, got.ctypes.data_as(C.c_void_p),
+                                        dev.stream()) == 0
+        assert np.array_equal(got, per_bucket)
+        keys = torch.randint(0, 1 << 62, (123_457,), dtype=torch.int64, device="cuda")
+        recv = torch.zeros_like(keys)
+        assert lib.bnpk_exchange_by_key_range(dev.ctx, comm, ptr(keys), send_counts.ctypes.data_as(C.c_void_p), ptr(recv),
+                                              recv_counts.ctypes.data_as(C.c_void_p), dev.stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(recv, keys)
+        # what cannot be right is refused before RCCL sees it
+        bad = np.array([5], dtype=np.int64)
+        assert lib.bnpk_exchange_by_key_range(dev.ctx, comm, ptr(keys), send_counts.ctypes.data_as(C.c_void_p), ptr(recv),
+                                              bad.ctypes.data_as(C.c_void_p), dev.stream()) == -1
+        assert lib.bnpk_allreduce_hist(dev.ctx, None, ptr(hist), 4, dev.stream()) == -1
+    finally:
+        assert lib.bnpk_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize("mode,genome_len,expect_plan", [(0, 0, "keys"), (1, 400_000, "counts")])
+def test_both_plans_of_the_sparse_merge_on_virtual_ranks(mode, genome_len, expect_plan):
+    """3 virtual ranks of 1 M reads: duplicate-free reads choose the exchange of raw hashes, reads that cover a genome 375
+    times per rank the exchange of (key, count) runs; either plan, forced, gives the histogram of all reads"""
+    from bionumpy_amd import ops as ops_mod
+    from bionumpy_amd.pipeline import fastq_kmer_histogram, fastq_kmer_histogram_virtual_ranks
+    from bionumpy_amd.device import HArray
+    ops_mod.set_ops(None)
+    ops = ops_mod.get_ops()
+    world, per, read_len, k, seed = 3, 1_000_000, 150, 31, 31
+    texts = [ops.synth_fastq(per, read_len, seed, mode, genome_len, r * per) for r in range(world)]
+    whole = ops.synth_fastq(world * per, read_len, seed, mode, genome_len, 0)
+    (ek, ec), st = fastq_kmer_histogram(whole, k)
+    for plan in ("auto", "keys", "counts"):
+        hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True)
+        assert chosen == (expect_plan if plan == "auto" else plan)
+        keys = ops.concat([h[0] for h in hists])
+        counts = ops.concat([h[1] for h in hists])
+        assert keys.size == ek.size and bool((keys.dev() == ek.dev()).all()) and bool((counts.dev() == ec.dev()).all()), plan
+        if chosen == "keys":
+            assert sum(received) == st.n_kmers
+        else:
+            assert sum(received) < st.n_kmers // 4 or mode == 0          # 16 bytes per distinct key of a rank: far fewer words

@@ -38,14 +38,23 @@ def test_virtual_ranks_on_the_host_logic():
     from bionumpy_amd.pipeline import fastq_kmer_histogram_virtual_ranks
     ops_mod.set_ops(OracleOps())
     try:
-        world, per, read_len, k = 3, 400, 90, 31
+        world, per, read_len, k = 3, 900, 90, 31
         texts = [HArray(host=synth.fastq_bytes(per, read_len, 9, 1, 7000, r * per)) for r in range(world)]
-        hists, stats, received = fastq_kmer_histogram_virtual_ranks(texts, k)
         codes = synth.read_codes(world * per, read_len, 9, 1, 7000, 0)
         h, _ = oracle.get_kmers(codes.reshape(-1), np.full(world * per, read_len, dtype=np.int64), k)
         ek, ec = oracle.count_sparse(h)
-        assert np.array_equal(np.concatenate([a.host() for a, _ in hists]), ek)
-        assert np.array_equal(np.concatenate([c.host() for _, c in hists]), ec)
-        assert sum(received) == h.size
+        for plan in ("keys", "counts", "auto"):
+            hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True)
+            assert np.array_equal(np.concatenate([a.host() for a, _ in hists]), ek), plan
+            assert np.array_equal(np.concatenate([c.host() for _, c in hists]), ec), plan
+            if chosen == "keys":
+                assert sum(received) == h.size                 # every k-mer crosses once, 8 bytes
+            else:
+                assert sum(received) == 2 * sum(np.unique(h[r * per * 60:(r + 1) * per * 60]).size for r in range(world))
+        # reads of a 7000-base genome 7 times over per rank: few distinct 31-mers per rank -> (key, count) runs; unique reads -> raw keys
+        assert chosen == "counts"
+        texts = [HArray(host=synth.fastq_bytes(per, read_len, 9, 0, 0, r * per)) for r in range(world)]
+        _, _, _, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, with_plan=True)
+        assert chosen == "keys"
     finally:
         ops_mod.set_ops(None)
