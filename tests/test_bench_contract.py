@@ -45,5 +45,5 @@ def test_bench_virtual_ranks_line():
                           "--warmup", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert d["virtual_ranks"] == 4 and len(d["keys_received_per_rank"]) == 4
-    assert sum(d["keys_received_per_rank"]) == 400000 * 120
+    assert d["virtual_ranks"] == 4 and len(d["int64_words_received_per_rank"]) == 4 and d["plan"] == "keys"
+    assert sum(d["int64_words_received_per_rank"]) == 400000 * 120
