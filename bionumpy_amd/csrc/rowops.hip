@@ -49,9 +49,67 @@ __global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_u8_kernel(const uint8_t
   }
 }
 
+// The same for 8-byte elements (k-mer hashes: Minimizers.__call__ takes kmer_hashes.raw().min(axis=-1),
+// bionumpy/sequence/minimizers.py:15-17; motif scores: float64).  One group of eight lanes per row.
+template <typename T>
+__global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_wide_kernel(const T* __restrict__ data, const int64_t* __restrict__ off,
+                                                                     int64_t n_rows, T* __restrict__ sums, T* __restrict__ mins,
+                                                                     T* __restrict__ maxs) {
+  const int g = threadIdx.x & (RR_GROUP - 1);
+  int64_t row = (int64_t)blockIdx.x * RR_ROWS_PER_BLOCK + (threadIdx.x / RR_GROUP);
+  const int64_t stride = (int64_t)gridDim.x * RR_ROWS_PER_BLOCK;
+  for (; row < n_rows; row += stride) {
+    const int64_t s = off[row], e = off[row + 1];
+    T sum = T(0), mn = T(0), mx = T(0);
+    bool any = false;
+    for (int64_t i = s + g; i < e; i += RR_GROUP) {
+      const T v = data[i];
+      sum += v;
+      // (numpy's min / max propagate NaN: v != v)
+      mn = !any ? v : ((v < mn || v != v) ? v : mn);
+      mx = !any ? v : ((v > mx || v != v) ? v : mx);
+      any = true;
+    }
+#pragma unroll
+    for (int m = 1; m < RR_GROUP; m <<= 1) {
+      const T os = __shfl_xor(sum, m, 64), on = __shfl_xor(mn, m, 64), ox = __shfl_xor(mx, m, 64);
+      const bool oa = __shfl_xor((int)any, m, 64) != 0;
+      sum += os;
+      if (oa) {
+        const bool keep_n = any && mn != mn, keep_x = any && mx != mx;           // this side already holds a NaN
+        mn = !any ? on : (keep_n ? mn : ((on < mn || on != on) ? on : mn));
+        mx = !any ? ox : (keep_x ? mx : ((ox > mx || ox != ox) ? ox : mx));
+        any = true;
+      }
+    }
+    if (g == 0) {
+      if (sums) sums[row] = sum;
+      if (mins) mins[row] = mn;
+      if (maxs) maxs[row] = mx;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int bnpk_row_reduce_wide(bnpk_ctx* ctx, const void* d_data, int is_f64, const int64_t* d_offsets, int64_t n_rows, void* d_sums,
+                         void* d_mins, void* d_maxs, void* stream) {
+  if (!ctx || n_rows < 0 || (n_rows > 0 && !d_offsets)) return BNPK_ERR_ARG;
+  if (n_rows == 0 || (!d_sums && !d_mins && !d_maxs)) return BNPK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "row_reduce_wide", s);
+  const dim3 grid(grid_for(ceil_div(n_rows, RR_ROWS_PER_BLOCK)));
+  if (is_f64)
+    hipLaunchKernelGGL(row_reduce_wide_kernel<double>, grid, dim3(BNPK_BLOCK), 0, s, (const double*)d_data, d_offsets, n_rows,
+                       (double*)d_sums, (double*)d_mins, (double*)d_maxs);
+  else
+    hipLaunchKernelGGL(row_reduce_wide_kernel<int64_t>, grid, dim3(BNPK_BLOCK), 0, s, (const int64_t*)d_data, d_offsets, n_rows,
+                       (int64_t*)d_sums, (int64_t*)d_mins, (int64_t*)d_maxs);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
 
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t* d_sums,
                        uint8_t* d_mins, uint8_t* d_maxs, void* stream) {

@@ -399,6 +399,15 @@ class HipOps:
                                          ptr(outs["min"]), ptr(outs["max"]), self._s()))
         return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
 
+    def row_reduce_wide(self, data, offsets, n_rows, want=("sum",)):
+        """{name: HArray} for name in want ⊆ {sum, min, max} over ragged int64 / float64 rows (bnpk_row_reduce_wide)"""
+        dtype = np.dtype(data.dtype)
+        assert dtype in (np.dtype(np.int64), np.dtype(np.float64))
+        outs = {name: self._empty(n_rows, dtype) if name in want else None for name in ("sum", "min", "max")}
+        self._chk(lib.bnpk_row_reduce_wide(self.ctx, ptr(data.dev()), 1 if dtype == np.float64 else 0, ptr(offsets.dev()), n_rows,
+                                           ptr(outs["sum"]), ptr(outs["min"]), ptr(outs["max"]), self._s()))
+        return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
+
     # -- per-row values that stay in HBM (device_vector.py) ---------------------------------------------------------
     def vec_ratio_rows(self, sums, offsets, n):
         """sums[i] / (offsets[i+1] - offsets[i]) as float64 — np.mean(ragged, axis=-1)"""

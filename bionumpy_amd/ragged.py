@@ -157,8 +157,16 @@ class RaggedArray:
 
     def _col_slice(self, sl):
         starts, lens = self._host_starts(), self.lengths
-        if not isinstance(sl, slice) or (sl.step not in (None, 1)):
-            raise NotImplementedError("only contiguous column slices are supported")
+        if not isinstance(sl, slice):
+            raise IndexError("ragged columns are indexed by an int or a slice")
+        if sl.step not in (None, 1):
+            # a strided column slice is not a (start, length) view of the flat data: the selected elements are gathered
+            # (npstructures RaggedArray does the same: index arithmetic, then one take)
+            picks = [np.arange(int(n))[sl] for n in lens]
+            new_lens = np.array([p.size for p in picks], dtype=np.int64)
+            flat_idx = np.concatenate([s0 + p for s0, p in zip(starts, picks)]) if len(picks) else np.zeros(0, dtype=np.int64)
+            data = as_harray(np.ascontiguousarray(self._flat_data().host()[flat_idx.astype(np.int64)]))
+            return self._like(data, None, as_harray(new_lens), None, len(new_lens), int(new_lens.sum()))
         lo = 0 if sl.start is None else sl.start
         lo_abs = np.minimum(lo, lens) if lo >= 0 else np.maximum(lens + lo, 0)
         if sl.stop is None:
@@ -198,51 +206,98 @@ class RaggedArray:
         return self._select_rows(idx.astype(np.int64))
 
     # -- per-row reductions (npstructures RaggedArray.sum/mean/min/max(axis=-1); scripts/small_example.py:36-46) ----
-    def _row_reduce(self, what):
-        if self.dtype not in (np.uint8, np.bool_):
-            raise NotImplementedError("row reductions on the MI355X path cover uint8 / bool data (quality scores, "
-                                      "match flags)")
+    def _row_reduce(self, what, as_float=False):
         self._compact()
-        data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
-        out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what]
-        if self.dtype == np.bool_ and what != "sum":
-            return out.host().astype(bool)
         from .device_vector import DeviceVector             # one value per row, left in HBM (device_vector.py)
+        dtype = np.dtype(self.dtype)
+        if dtype in (np.dtype(np.uint8), np.dtype(np.bool_)):
+            data = self._data if dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
+            out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what]
+            if dtype == np.bool_ and what != "sum":
+                return out.host().astype(bool)
+            return DeviceVector(out)
+        # everything else is reduced as int64 or float64 (k-mer hashes, motif scores): bnpk_row_reduce_wide
+        data = self._flat_data()
+        data = data._unpacked() if hasattr(data, "_unpacked") else data
+        if as_float and dtype != np.dtype(np.float64):      # (np.mean of integers accumulates in float64: no wrap-around)
+            data = HArray(dev=data.dev().double()) if data.on_device else HArray(host=data.host().astype(np.float64))
+        elif dtype not in (np.dtype(np.int64), np.dtype(np.float64)):
+            wide = np.float64 if np.issubdtype(dtype, np.floating) else np.int64
+            data = HArray(host=data.host().astype(wide))
+        out = get_ops().row_reduce_wide(data, self.offsets(), self._n_rows, want=(what,))[what]
+        if what != "sum" and out.dtype != dtype:            # min / max keep the element type (sums widen, as numpy's do)
+            return out.host().astype(dtype)
         return DeviceVector(out)
 
-    @staticmethod
-    def _row_axis(axis):
-        if axis not in (-1, 1):
-            raise NotImplementedError("min / max over ragged arrays: axis=-1 (per row)")
+    def _host_columns(self):
+        """(values, column index of every value) of the compact flat data, on the host: the column-wise reductions of
+        anything but uint8 / bool, and axis=None — index arithmetic for the rare shapes, not a hot path"""
+        self._compact()
+        data = self._flat_data()
+        data = data._unpacked() if hasattr(data, "_unpacked") else data
+        lens = self.lengths
+        cols = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        return data.host()[:int(lens.sum())], cols
 
     def _col_sums(self):
         """(sums, counts) per column: the rows that are long enough contribute (axis=0)"""
+        n_cols = int(self.lengths.max()) if self._n_rows else 0
         if self.dtype not in (np.uint8, np.bool_):
-            raise NotImplementedError("column reductions on the MI355X path cover uint8 / bool data")
+            values, cols = self._host_columns()
+            sums = np.zeros(n_cols, dtype=np.float64 if np.issubdtype(values.dtype, np.floating) else np.int64)
+            np.add.at(sums, cols, values)
+            return sums, np.bincount(cols, minlength=n_cols).astype(np.int64)
         self._compact()
         data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
-        n_cols = int(self.lengths.max()) if self._n_rows else 0
         sums, counts = get_ops().col_sums_u8(data, self.offsets(), self._n_rows, self.total(), n_cols)
         return sums.host(), counts.host()
 
+    def _flat_values(self):
+        self._compact()
+        data = self._flat_data()
+        data = data._unpacked() if hasattr(data, "_unpacked") else data
+        return data.host()[:self.total()]
+
     def sum(self, axis=-1):
+        if axis is None:
+            return self._flat_values().sum()
         if axis == 0:
             return self._col_sums()[0]
-        self._row_axis(axis)
         return self._row_reduce("sum")
 
     def mean(self, axis=-1):
+        if axis is None:
+            return self._flat_values().mean()
         if axis == 0:
+            if self.dtype not in (np.uint8, np.bool_):                      # (accumulated in float64, as np.mean does)
+                values, cols = self._host_columns()
+                n_cols = int(self.lengths.max()) if self._n_rows else 0
+                return np.bincount(cols, weights=values.astype(np.float64), minlength=n_cols) / np.bincount(cols, minlength=n_cols)
             sums, counts = self._col_sums()
             return sums / counts                                            # every column < max length has a row
-        self._row_axis(axis)
         with np.errstate(invalid="ignore", divide="ignore"):
             from .device_vector import DeviceVector
-            sums = self._row_reduce("sum").harray()
-            return DeviceVector(get_ops().vec_ratio_rows(sums, self.offsets(), self._n_rows))     # an empty row gives nan, as in numpy
+            if np.dtype(self.dtype) in (np.dtype(np.uint8), np.dtype(np.bool_)):
+                sums = self._row_reduce("sum")
+                return DeviceVector(get_ops().vec_ratio_rows(sums.harray(), self.offsets(), self._n_rows))   # an empty row gives nan, as in numpy
+            return np.asarray(self._row_reduce("sum", as_float=True)) / self.lengths
 
     def _extreme(self, what, axis):
-        self._row_axis(axis)
+        if axis is None:
+            values = self._flat_values()
+            return values.min() if what == "min" else values.max()
+        if axis == 0:                                                       # per column, over the rows that reach it
+            values, cols = self._host_columns()
+            n_cols = int(self.lengths.max()) if self._n_rows else 0
+            if what == "min":
+                out = np.full(n_cols, np.inf if np.issubdtype(values.dtype, np.floating) else np.iinfo(values.dtype).max, dtype=values.dtype)
+                np.minimum.at(out, cols, values)
+            else:
+                out = np.full(n_cols, -np.inf if np.issubdtype(values.dtype, np.floating) else np.iinfo(values.dtype).min, dtype=values.dtype)
+                np.maximum.at(out, cols, values)
+            return out
+        if axis not in (-1, 1):
+            raise ValueError("axis %r of a ragged (two-dimensional) array" % (axis,))
         if np.any(self.lengths == 0):
             raise ValueError("zero-size row in a reduction which has no identity")
         return self._row_reduce(what)
@@ -276,8 +331,6 @@ class RaggedArray:
         if name is None or not args or args[0] is not self:
             return NotImplemented
         axis = kwargs.get("axis", args[1] if len(args) > 1 else None)
-        if axis is None:
-            raise NotImplementedError("reductions over ragged arrays: axis=-1 (per row)")
         return getattr(self, name)(axis=axis)
 
     def __iter__(self):

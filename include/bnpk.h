@@ -240,6 +240,14 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
                        int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
 
+/* the same for 8-byte elements — int64 (k-mer hashes: Minimizers.__call__ is kmer_hashes.raw().min(axis=-1),
+ * bionumpy/sequence/minimizers.py:15-17) or float64 (is_f64: motif scores): sums / mins / maxs of the element type, any of
+ * them NULL.  Integer results are exact (wrapping sums, as numpy); float64 sums are added in another order than numpy's
+ * pairwise summation (equal up to rounding), min / max are exact and propagate NaN as numpy does.  An empty row gives 0
+ * in all three (the caller raises for min / max, as numpy does). */
+int bnpk_row_reduce_wide(bnpk_ctx* ctx, const void* d_data, int is_f64, const int64_t* d_offsets, int64_t n_rows, void* d_sums,
+                         void* d_mins, void* d_maxs, void* stream);
+
 /* Element-wise helpers of the read filters (scripts/small_example.py:36-46: `np.mean(chunk.quality, axis=1) > 30`,
  * `mask[::3] = False`, `mask1 & mask2`, `chunk[mask]`) on per-row values that stay in HBM (bionumpy_amd/device_vector.py):
  *   bnpk_vec_ratio_rows  d_out[i] = (double)d_sums[i] / (double)(d_offsets[i+1] - d_offsets[i])   — np.mean(ragged, axis=-1)

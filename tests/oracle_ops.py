@@ -230,6 +230,15 @@ class OracleOps:
         full = {"sum": sums, "min": mins, "max": maxs}
         return {k: _h(full[k]) for k in want}
 
+    def row_reduce_wide(self, data, offsets, n_rows, want=("sum",)):
+        flat, off = data.host(), offsets.host()
+        full = {name: np.zeros(n_rows, dtype=flat.dtype) for name in ("sum", "min", "max")}
+        for r in range(n_rows):
+            row = flat[off[r]:off[r + 1]]
+            if row.size:
+                full["sum"][r], full["min"][r], full["max"][r] = row.sum(), row.min(), row.max()
+        return {k: _h(full[k]) for k in want}
+
     def reverse_complement_packed(self, packed, offsets, n_rows, total):
         lens = np.diff(offsets.host())
         return _pack(oracle.reverse_complement(_unpack(packed, total), lens))

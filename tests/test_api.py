@@ -851,3 +851,47 @@ def test_minimizers_of_any_alphabet(bnp):
     one = bnp.sequence.get_minimizers(bnp.as_encoded_array("ACGTNNACGTNACG", enc), 2, 5)
     codes = np.array(["ACGTN".index(c) for c in "ACGTNNACGTNACG"], dtype=np.uint8)
     assert np.array_equal(one.raw(), oracle.get_minimizers(codes, np.array([14]), 2, 5, 5)[0]) and str(one[0]) == "AC"
+
+
+def test_ragged_reductions_of_every_shape(bnp):
+    """what npstructures' RaggedArray (the reference's base class, encoded_array.py:161) answers: row reductions of int64 and
+    float64 rows (k-mer hashes: Minimizers.__call__ is kmer_hashes.raw().min(axis=-1), minimizers.py:15-17; motif scores),
+    column reductions, axis=None, strided column slices — against numpy on the same rows"""
+    from bionumpy_amd.ragged import RaggedArray
+    rng = np.random.default_rng(13)
+    lens = np.array([5, 1, 12, 3, 40, 2, 9])
+    rows_i = [rng.integers(-(1 << 40), 1 << 61, size=n) for n in lens]
+    rows_f = [rng.normal(size=n) * 10.0 ** rng.integers(-2, 4) for n in lens]
+    rows_f[2][3] = np.nan                                                     # numpy's min / max propagate NaN
+    for rows, exact in ((rows_i, True), (rows_f, False)):
+        ra = RaggedArray(np.concatenate(rows), lens)
+        for name, f in (("sum", np.sum), ("min", np.min), ("max", np.max), ("mean", np.mean)):
+            got = np.asarray(f(ra, axis=-1))
+            expect = np.array([f(r) for r in rows])
+            if exact and name != "mean":
+                assert got.dtype == expect.dtype and np.array_equal(got, expect), name
+            else:                                                             # float sums: another order of additions
+                assert np.allclose(got, expect, rtol=1e-12, atol=0, equal_nan=True), name
+            assert np.asarray(getattr(ra, name)(axis=-1)).shape == (7,)
+        flat = np.concatenate(rows)
+        for name, f in (("sum", np.sum), ("min", np.min), ("max", np.max), ("mean", np.mean)):
+            assert np.allclose(getattr(ra, name)(axis=None), f(flat), equal_nan=True), name
+            assert np.allclose(f(ra), f(flat), equal_nan=True), name           # np.sum(ragged): axis=None
+        # per column, over the rows that reach it
+        width = lens.max()
+        cols = [np.array([r[c] for r in rows if r.size > c]) for c in range(width)]
+        assert np.allclose(ra.sum(axis=0), [c.sum() for c in cols], equal_nan=True)
+        assert np.allclose(ra.mean(axis=0), [c.mean() for c in cols], equal_nan=True)
+        if exact:
+            assert np.array_equal(ra.min(axis=0), [c.min() for c in cols]) and np.array_equal(ra.max(axis=0), [c.max() for c in cols])
+        # strided and reversed column slices
+        for sl in (slice(None, None, 2), slice(1, None, 3), slice(None, None, -1), slice(-2, 0, -2)):
+            sub = ra[:, sl]
+            assert [np.asarray(r).tolist() for r in sub] == [r[sl].tolist() for r in rows] or not exact
+            assert sub.lengths.tolist() == [r[sl].size for r in rows]
+    with pytest.raises(ValueError):
+        RaggedArray(np.arange(3), [3, 0]).min(axis=-1)
+    # the k-mer use: the smallest hash of every read == what get_minimizers gives for one window per read
+    seqs = bnp.as_encoded_array(["ACGTACGTAC", "TTTTGGGGCC", "GATTACAGAT"], bnp.DNAEncoding)
+    kmers = bnp.sequence.get_kmers(seqs, 4)
+    assert np.array_equal(np.asarray(kmers.raw().min(axis=-1)), bnp.sequence.get_minimizers(seqs, 4, 10).raw().ravel())
