@@ -126,12 +126,24 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
   }
 }
 
-// plain gather (optionally subtracting a constant from every byte), 16 output bytes per lane
-// The rows a workgroup's 4 KiB of output come from (usually a dozen) are staged in LDS first — their offsets relative to
+// plain gather (optionally subtracting a constant from every byte): 4 x 16 output bytes per lane.
+// The rows a workgroup's 16 KiB of output come from (usually ~50) are staged in LDS first — their offsets relative to
 // the block and their starts — with one coalesced load each: without that every lane walks a chain of six to eight
-// dependent global loads (binary search, row end, start, data) and the kernel runs at the rate of that latency
-// (0.7 TB/s); blocks with more rows than the table holds (rows of a few bytes) keep the direct path.
+// dependent global loads (binary search, row end, start, data) and the kernel runs at the rate of that latency.  What is
+// left of the chain (tile table -> offsets -> data) is paid once per 16 KiB: a lane finds the rows of its four chunks in
+// LDS, issues the four data loads together, and only then looks at them.  A chunk inside one row (19 in 20 for rows of
+// ~300 bytes) is ONE unaligned 16-byte load; the others are assembled from row segments.  Blocks with more rows than the
+// table holds (rows of a few bytes) keep the direct path.
 constexpr int GR_ROWS = 1024;
+#ifndef GR_CHUNKS_N
+#define GR_CHUNKS_N 4
+#endif
+constexpr int GR_PER = 16, GR_CHUNKS = GR_CHUNKS_N;
+constexpr int64_t GR_TILE = (int64_t)BNPK_BLOCK * GR_PER * GR_CHUNKS;
+
+__device__ __forceinline__ uint64_t gr_subtract(uint64_t x, uint64_t sub) {   // per-byte wrap-around subtraction, no borrows
+  return ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
+}
 
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
@@ -141,12 +153,18 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
   __shared__ int64_t st[GR_ROWS];                              // starts[rr0 + i]
   __shared__ int64_t first_off;                                // offsets[rr0] (rel[0] is clamped: the row may start gigabytes back)
   int64_t rr[2];
-  constexpr int PER = 16;
-  int64_t blk_first = (int64_t)blockIdx.x * BNPK_BLOCK * PER;
+  const int64_t blk_first = (int64_t)blockIdx.x * GR_TILE;
   if (blk_first >= total) return;
   tile_row_range(tile_rows, blockIdx.x, gridDim.x, n_rows, rr[0], rr[1]);
-  const int n_stage = (int)min(rr[1] - rr[0] + 1, (int64_t)GR_ROWS + 1);      // rows rr0 .. rr0 + n_stage - 1 (if they all fit)
-  const bool staged = rr[1] - rr[0] + 1 <= GR_ROWS;
+  // rows rr0 .. rr0 + n_stage - 1, if they all fit.  In 32-bit halves on purpose: hipcc 7.2 turns a wave-uniform SELECT on
+  // a 64-bit signed compare (`min(rr[1] - rr[0] + 1, GR_ROWS + 1)`, `diff < GR_ROWS ? diff + 1 : 0`) into V_CMP + S_CSELECT
+  // and loses the copy of VCC into SCC when the same compare also feeds a branch — the select then reads the carry of
+  // whatever scalar add came last (n_stage was 1025, or 0, whatever the tile held).  32-bit compares are S_CMPs.
+  const uint64_t row_span = (uint64_t)(rr[1] - rr[0]);
+  unsigned span_lo = (unsigned)row_span, span_hi = (unsigned)(row_span >> 32);
+  asm volatile("" : "+s"(span_lo), "+s"(span_hi));            // (or the optimiser fuses the halves into the 64-bit compare again)
+  const bool staged = span_hi == 0u && span_lo < (unsigned)GR_ROWS;
+  const int n_stage = staged ? (int)span_lo + 1 : 0;
   if (staged) {
     for (int i = threadIdx.x; i <= n_stage; i += BNPK_BLOCK) {
       const int64_t d = offsets[rr[0] + i] - blk_first;
@@ -156,43 +174,89 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
     }
     __syncthreads();
   }
-  int64_t pos = blk_first + (int64_t)threadIdx.x * PER;
-  if (pos >= total) return;
-  const int64_t end = min(pos + PER, total);
-  uint64_t v[3] = {0, 0, 0};
-  const int64_t p0 = pos;
   const uint64_t sub = (uint64_t)(subtract & 0xff) * REP01;
-  int j = 0;
+  auto store16 = [&](int64_t p0, const uint64_t (&v)[3]) {
+    if (p0 + GR_PER <= total && (((uintptr_t)(out + p0)) & 15) == 0) {
+      *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
+    } else {
+      for (int q = 0; p0 + q < total && q < GR_PER; ++q) out[p0 + q] = (uint8_t)(v[q >> 3] >> (8 * (q & 7)));
+    }
+  };
   if (staged) {
-    const int at = (int)(pos - blk_first);
-    int lo = 0, hi = n_stage - 1;                              // last i with rel[i] <= at (skips empty rows)
-    while (lo < hi) {
-      const int mid = lo + ((hi - lo + 1) >> 1);
-      if (rel[mid] <= at) lo = mid; else hi = mid - 1;
-    }
-    int row = lo, p = at;
-    const int e = (int)(end - blk_first);
-    int row_end = rel[row + 1];
-    const uint8_t* src = buf + st[row] + (row == 0 ? pos - first_off : (int64_t)(p - rel[row]));
-    while (p < e) {
-      while (p >= row_end) {
-        ++row;
-        row_end = rel[row + 1];
-        src = buf + st[row];
+#pragma unroll 1
+    for (int c = 0; c < GR_CHUNKS; ++c) {
+      const int at = (c * BNPK_BLOCK + (int)threadIdx.x) * GR_PER;
+      const int64_t pos = blk_first + at;
+      if (pos >= total) break;
+      int lo = 0, hi = n_stage - 1;                            // last i with rel[i] <= at (skips empty rows)
+      while (lo < hi) {
+        const int mid = lo + ((hi - lo + 1) >> 1);
+        if (rel[mid] <= at) lo = mid; else hi = mid - 1;
       }
-      int seg = min(row_end - p, e - p);
-      while (seg > 0) {
-        int m;
-        uint64_t x = load_upto8(src, seg, &m);
-        x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
-        if (m < 8) x &= (1ull << (8 * m)) - 1ull;
-        int sh = 8 * (j & 7);
-        v[j >> 3] |= x << sh;
-        if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
-        j += m; src += m; p += m; seg -= m;
+      int row = lo, p = at, j = 0;
+      const int e = (int)(min(pos + GR_PER, total) - blk_first);
+      int row_end = rel[row + 1];
+      const uint8_t* src = buf + st[row] + (row == 0 ? pos - first_off : (int64_t)(p - rel[row]));
+      uint64_t v[3] = {0, 0, 0};
+      if (row_end - p >= GR_PER && e - p == GR_PER) {
+        // the lane's 16 bytes lie in ONE row (19 lanes in 20 for rows of ~300 bytes): one unaligned 16-byte load instead
+        // of the byte-assembling walk over row segments below
+        uint64_t a[2];
+        __builtin_memcpy(a, src, 16);
+        v[0] = gr_subtract(a[0], sub);
+        v[1] = gr_subtract(a[1], sub);
+        p = e;
       }
+      if (p < e && e - p == GR_PER && row + 2 <= n_stage) {
+        // ONE row boundary inside the chunk, k bytes before it, and both rows at least 16 bytes long (every boundary
+        // chunk of FASTQ records): the 16 bytes that END row `row` and the 16 that START the next one, two independent
+        // loads, shifted together — instead of a walk of dependent loads of eight, then single bytes, that the other 63
+        // lanes of the wavefront wait for
+        const int k = row_end - p;
+        const int64_t start_r = row == 0 ? first_off - blk_first : (int64_t)rel[row];
+        if (k < GR_PER && row_end - start_r >= GR_PER && rel[row + 2] - row_end >= GR_PER) {
+          uint64_t a[2], b[2];
+          __builtin_memcpy(a, buf + st[row] + (row_end - start_r) - GR_PER, 16);
+          __builtin_memcpy(b, buf + st[row + 1], 16);
+          // out = (A >> 8 (16 - k)) | (B << 8 k) over 128 bits, 0 < k < 16
+          const int ra = 8 * (GR_PER - k), lb = 8 * k;
+          uint64_t lo = ra >= 64 ? (a[1] >> (ra - 64)) : ((a[0] >> ra) | (a[1] << (64 - ra)));
+          uint64_t hi = ra >= 64 ? 0ull : (a[1] >> ra);
+          lo |= lb >= 64 ? 0ull : (b[0] << lb);
+          hi |= lb >= 64 ? (b[0] << (lb - 64)) : ((b[1] << lb) | (b[0] >> (64 - lb)));
+          v[0] = gr_subtract(lo, sub);
+          v[1] = gr_subtract(hi, sub);
+          p = e;
+        }
+      }
+      while (p < e) {
+        while (p >= row_end) {
+          ++row;
+          row_end = rel[row + 1];
+          src = buf + st[row];
+        }
+        int seg = min(row_end - p, e - p);
+        while (seg > 0) {
+          int m;
+          uint64_t x = gr_subtract(load_upto8(src, seg, &m), sub);
+          if (m < 8) x &= (1ull << (8 * m)) - 1ull;
+          const int sh = 8 * (j & 7);
+          v[j >> 3] |= x << sh;
+          if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
+          j += m; src += m; p += m; seg -= m;
+        }
+      }
+      store16(pos, v);
     }
-  } else {
+    return;
+  }
+#pragma unroll 1
+  for (int c = 0; c < GR_CHUNKS; ++c) {
+    int64_t pos = blk_first + (int64_t)(c * BNPK_BLOCK + (int)threadIdx.x) * GR_PER;
+    if (pos >= total) continue;
+    const int64_t p0 = pos, end = min(pos + GR_PER, total);
+    uint64_t v[3] = {0, 0, 0};
+    int j = 0;
     int64_t row = find_row(offsets, rr[0], rr[1], pos);
     int64_t row_end = offsets[row + 1];
     const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
@@ -205,22 +269,15 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_rows_kernel(
       int seg = (int)min(row_end - pos, end - pos);
       while (seg > 0) {
         int m;
-        uint64_t x = load_upto8(src, seg, &m);
-        // per-byte wrap-around subtraction without borrows between bytes
-        x = ((x | REP80) - (sub & ~REP80)) ^ ((x ^ ~sub) & REP80);
+        uint64_t x = gr_subtract(load_upto8(src, seg, &m), sub);
         if (m < 8) x &= (1ull << (8 * m)) - 1ull;
-        int sh = 8 * (j & 7);
+        const int sh = 8 * (j & 7);
         v[j >> 3] |= x << sh;
         if (sh) v[(j >> 3) + 1] |= x >> (64 - sh);
         j += m; src += m; pos += m; seg -= m;
       }
     }
-  }
-  if (p0 + PER <= total && (((uintptr_t)(out + p0)) & 15) == 0) {
-    *reinterpret_cast<uint4*>(out + p0) =
-        make_uint4((uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
-  } else {
-    for (int q = 0; p0 + q < total; ++q) out[p0 + q] = (uint8_t)(v[q >> 3] >> (8 * (q & 7)));
+    store16(p0, v);
   }
 }
 
@@ -401,12 +458,12 @@ int bnpk_gather_rows(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_start
   if (total == 0) return BNPK_OK;
   if (!d_buf || !d_starts || !d_offsets || !d_out || n_rows == 0) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  int64_t blocks = ceil_div(total, (int64_t)BNPK_BLOCK * 16);
+  int64_t blocks = ceil_div(total, GR_TILE);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   void* table = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(blocks), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "gather_rows", s);
-  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 16, (int64_t*)table, s));
+  BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, GR_TILE, (int64_t*)table, s));
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_buf, d_starts, d_offsets,
                      n_rows, total, subtract, (const int64_t*)table, d_out);
   BNPK_HIP(ctx, hipGetLastError());

@@ -161,6 +161,63 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_generate_kernel(const uint64_t*
   for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = (int64_t)stage[i];
 }
 
+// Minimizers, PW k-mers per window known at compile time.  wf_generate_kernel rolls the PW hashes of every window anew
+// — PW rolls and PW comparisons per output, and at PW = 10 (BASELINE config 3) the kernel was bound by those instructions,
+// not by its 8 output bytes per window.  A lane's eight windows overlap: together they cover 8 + PW - 1 consecutive
+// k-mers.  These are rolled ONCE, and the eight window minima come from a doubling scheme over them —
+// a[i] = min(a[i], a[i + 2^j]) for j = 0 .. L - 1 turns a[i] into the minimum of 2^L hashes from i on (2^L <= PW), and
+// min(a[q], a[q + PW - 2^L]) is the window's: at PW = 10, 16 rolls and 48 comparisons per lane instead of 80 and 72.
+template <int PW>
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t* __restrict__ W, int64_t n_words,
+                                                                  const uint8_t* __restrict__ mask8, int64_t n_bases, int k,
+                                                                  const int64_t* __restrict__ tile_off,
+                                                                  int64_t* __restrict__ out) {
+  constexpr int H = WF_ITEMS + PW - 1;                       // k-mers under the lane's eight windows
+  constexpr int L = PW >= 16 ? 4 : PW >= 8 ? 3 : PW >= 4 ? 2 : 1;
+  static_assert(PW >= 2 && PW <= WF_MAX_PER_WINDOW && (1 << L) <= PW, "window of 2 .. 26 k-mers");
+  __shared__ uint64_t stage[WF_TILE];
+  __shared__ unsigned wsum[BNPK_BLOCK / 64];
+  const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+  const unsigned v = o < n_bases ? mask8[o >> 3] : 0u;
+  const unsigned cnt = __popc(v);
+  const unsigned inc = wave_inclusive_scan(cnt);
+  if (lane_id() == 63) wsum[wave_id()] = inc;
+  uint64_t a[H];
+  if (v) {
+    const int64_t wi = o >> 5;
+    const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0;
+    const int sh0 = 2 * (int)(o & 31), top = 2 * k - 2;
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;
+    a[0] = wf_window(w0, w1, w2, sh0) & kmask;              // k-mer at position o
+    const uint64_t next = wf_window(w0, w1, w2, sh0 + 2 * k);   // the bases that enter the k-mers at o+1, o+2, ... (2 (H - 1) <= 64 bits)
+#pragma unroll
+    for (int i = 1; i < H; ++i) a[i] = (a[i - 1] >> 2) | (((next >> (2 * (i - 1))) & 3ull) << top);
+    // (positions past a read's end enter hashes that no marked window uses: a window marked at o + q has PW k-mers of its
+    // read ahead, and only its own a[q .. q + PW - 1] reach its minimum)
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+#pragma unroll
+      for (int i = 0; i + (1 << j) < H; ++i) a[i] = a[i + (1 << j)] < a[i] ? a[i + (1 << j)] : a[i];
+    }
+  }
+  __syncthreads();
+  unsigned rank = inc - cnt;
+  for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
+  if (v) {
+#pragma unroll
+    for (int q = 0; q < WF_ITEMS; ++q) {
+      if ((v >> q) & 1u) {
+        const uint64_t x = a[q], y = a[q + PW - (1 << L)];
+        stage[rank++] = y < x ? y : x;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t base = tile_off[blockIdx.x];
+  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
+  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = (int64_t)stage[i];
+}
+
 // match_string (bionumpy/sequence/string_matcher.py:16-55): for every window of m symbols (marked in the start mask)
 // 1 if it equals the pattern, else 0, in the ragged-flat order of the windows.  Same skeleton as wf_generate.
 // PACKED: 2-bit symbols, the window is a k-mer hash compared with the pattern's; else bytes compared one by one.
@@ -356,9 +413,22 @@ int bnpk_windows_flat(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t* d
                      d_start_mask, n_mask_words, n_tiles, tile_off);
   BNPK_HIP(ctx, hipGetLastError());
   BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
-  hipLaunchKernelGGL(wf_generate_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases / 32 + 2,
-                     reinterpret_cast<const uint8_t*>(d_start_mask), n_bases, k, kmers_per_window,
-                     (const int64_t*)tile_off, d_out);
+  const uint8_t* mask8 = reinterpret_cast<const uint8_t*>(d_start_mask);
+#define WF_MIN_CASE(PW)                                                                                                    \
+  case PW:                                                                                                                 \
+    hipLaunchKernelGGL(wf_minimizer_kernel<PW>, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases / 32 + 2, \
+                       mask8, n_bases, k, (const int64_t*)tile_off, d_out);                                                \
+    break;
+  switch (kmers_per_window) {
+    WF_MIN_CASE(2) WF_MIN_CASE(3) WF_MIN_CASE(4) WF_MIN_CASE(5) WF_MIN_CASE(6) WF_MIN_CASE(7) WF_MIN_CASE(8) WF_MIN_CASE(9)
+    WF_MIN_CASE(10) WF_MIN_CASE(11) WF_MIN_CASE(12) WF_MIN_CASE(13) WF_MIN_CASE(14) WF_MIN_CASE(15) WF_MIN_CASE(16)
+    WF_MIN_CASE(17) WF_MIN_CASE(18) WF_MIN_CASE(19) WF_MIN_CASE(20) WF_MIN_CASE(21) WF_MIN_CASE(22) WF_MIN_CASE(23)
+    WF_MIN_CASE(24) WF_MIN_CASE(25) WF_MIN_CASE(26)
+    default:                                                   // one k-mer per window: the k-mers themselves
+      hipLaunchKernelGGL(wf_generate_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases / 32 + 2, mask8,
+                         n_bases, k, kmers_per_window, (const int64_t*)tile_off, d_out);
+  }
+#undef WF_MIN_CASE
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

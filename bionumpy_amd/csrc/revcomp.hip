@@ -14,7 +14,7 @@ namespace {
 
 constexpr int RC_TILE_WORDS = BNPK_BLOCK;            // one output word (32 bases) per lane
 constexpr int64_t RC_TILE_BASES = (int64_t)RC_TILE_WORDS * 32;
-constexpr int RC_BYTES_PER_LANE = 8;
+constexpr int RC_BYTES_PER_LANE = 16;
 constexpr int64_t RC_TILE_BYTES = (int64_t)BNPK_BLOCK * RC_BYTES_PER_LANE;
 
 // bases [pos, pos + n) of the packed stream, n <= 32, in the low 2n bits
@@ -72,6 +72,21 @@ __device__ __forceinline__ uint32_t ascii_complement(uint32_t b) {
   return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'N' ? 'N' : 0u;
 }
 
+// the same table on eight bytes at once: A (0x41) <-> T (0x54) differ by 0x15, C (0x43) <-> G (0x47) by 0x04, N stays;
+// a byte that is none of the five becomes 0.  Exact SWAR byte tests (no carries between bytes).
+__device__ __forceinline__ uint64_t swar_eq(uint64_t x, unsigned c) {          // 0xff in every byte of x that equals c
+  const uint64_t y = x ^ (0x0101010101010101ull * c);
+  const uint64_t t = ~(((y & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | y | 0x7f7f7f7f7f7f7f7full);   // 0x80 where y == 0
+  return (t >> 7) * 0xffull;
+}
+__device__ __forceinline__ uint64_t ascii_complement8(uint64_t x) {
+  const uint64_t at = swar_eq(x, 'A') | swar_eq(x, 'T'), cg = swar_eq(x, 'C') | swar_eq(x, 'G'), n = swar_eq(x, 'N');
+  return (x ^ (at & 0x1515151515151515ull) ^ (cg & 0x0404040404040404ull)) & (at | cg | n);
+}
+
+// 16 output bytes per lane.  A lane whose bytes all lie in one row (19 in 20 for reads of 150 bases) takes them with ONE
+// unaligned 16-byte load — the row read backwards is a contiguous run — reverses them with two byte swaps and complements
+// eight bytes at a time; the others walk their rows byte by byte as before.
 __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __restrict__ in,
                                                               const int64_t* __restrict__ off, int64_t n_rows,
                                                               int64_t total, const int64_t* __restrict__ tile_rows,
@@ -83,15 +98,22 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
   int64_t r = row_of(off, lo, hi, p0);
   const int64_t p1 = min(p0 + RC_BYTES_PER_LANE, total);
   int64_t s = off[r], e = off[r + 1];
-  uint64_t word = 0;                                          // the lane's eight output bytes, stored once
-  for (int64_t p = p0; p < p1; ++p) {
-    while (e <= p) { ++r; s = e; e = off[r + 1]; }
-    word |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)(p - p0));
-  }
-  if (p1 - p0 == RC_BYTES_PER_LANE) {
-    *reinterpret_cast<uint64_t*>(out + p0) = word;            // (p0 is a multiple of 8, the buffer 16-byte aligned)
+  uint64_t word[2] = {0, 0};                                  // the lane's sixteen output bytes, stored once
+  if (p0 + RC_BYTES_PER_LANE <= e) {                          // (then p1 == p0 + 16 too)
+    uint64_t a[2];
+    __builtin_memcpy(a, in + (s + e - RC_BYTES_PER_LANE - p0), 16);
+    word[0] = ascii_complement8(__builtin_bswap64(a[1]));
+    word[1] = ascii_complement8(__builtin_bswap64(a[0]));
   } else {
-    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word >> (8 * j));
+    for (int64_t p = p0; p < p1; ++p) {
+      while (e <= p) { ++r; s = e; e = off[r + 1]; }
+      word[(p - p0) >> 3] |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 7));
+    }
+  }
+  if (p1 - p0 == RC_BYTES_PER_LANE) {                         // (p0 is a multiple of 16, the buffer 16-byte aligned)
+    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)word[0], (uint32_t)(word[0] >> 32), (uint32_t)word[1], (uint32_t)(word[1] >> 32));
+  } else {
+    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
   }
 }
 
