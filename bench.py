@@ -337,13 +337,13 @@ def main():
         kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
                          "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the run, so they come from the committed
-    # rocprofv3 --pmc passes of this same command (scripts/profile_r02.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
+    # rocprofv3 --pmc passes of this same command (scripts/profile_r03.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
     # FETCH x2 as MI355X_MICROARCH.md prescribes) — and only if that profile was taken from THIS build (hash of the kernel
     # sources) on this workload; otherwise null
     traffic, traffic_source = None, None
     try:
         from bionumpy_amd.csrc.build import _source_hash
-        for cand in ("r02_pmc.json", "r01_pmc.json"):
+        for cand in (("r03_genome_pmc.json",) if args.mode == "genome" else ("r03_pmc.json",)) + ("r02_pmc.json", "r01_pmc.json"):
             path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -353,7 +353,7 @@ def main():
                 (args.reads, args.read_len, args.k, args.mode, bool(args.canonical)) and world == 1
             if not same_work or pmc.get("_source_hash") != _source_hash():
                 continue
-            names = {"finish_sorted": "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
+            names = {"finish_sorted": "finish_wave" if args.mode == "genome" else "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
                      "fastq_encode": "fq_encode_fast", "fastq_census": "fq_census_fast"}
             rec = pmc.get(names.get(dom, dom)) or pmc.get(dom)

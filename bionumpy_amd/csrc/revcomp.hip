@@ -105,9 +105,29 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
     word[0] = ascii_complement8(__builtin_bswap64(a[1]));
     word[1] = ascii_complement8(__builtin_bswap64(a[0]));
   } else {
-    for (int64_t p = p0; p < p1; ++p) {
-      while (e <= p) { ++r; s = e; e = off[r + 1]; }
-      word[(p - p0) >> 3] |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 7));
+    // ONE row boundary inside the chunk, k bytes before it, both rows at least 16 bytes long (every boundary chunk of
+    // 150-base reads): the first 16 bytes of this row and the last 16 of the next one, two independent loads, reversed
+    // and shifted together — instead of sixteen dependent single-byte loads that the other lanes of the wavefront wait for
+    const int64_t k = e - p0;
+    const int64_t e2 = (r + 2 <= n_rows && p1 - p0 == RC_BYTES_PER_LANE) ? off[r + 2] : e;
+    if (k > 0 && e - s >= RC_BYTES_PER_LANE && e2 - e >= RC_BYTES_PER_LANE) {
+      uint64_t a[2], b[2];
+      __builtin_memcpy(a, in + s, 16);
+      __builtin_memcpy(b, in + e2 - RC_BYTES_PER_LANE, 16);
+      const uint64_t ra[2] = {__builtin_bswap64(a[1]), __builtin_bswap64(a[0])};      // the 16 bytes reversed
+      const uint64_t rb[2] = {__builtin_bswap64(b[1]), __builtin_bswap64(b[0])};
+      const int sr = 8 * (int)(RC_BYTES_PER_LANE - k), sl = 8 * (int)k;                // out = (RA >> 8 (16 - k)) | (RB << 8 k)
+      uint64_t lo = sr >= 64 ? (ra[1] >> (sr - 64)) : ((ra[0] >> sr) | (ra[1] << (64 - sr)));
+      uint64_t hi = sr >= 64 ? 0ull : (ra[1] >> sr);
+      lo |= sl >= 64 ? 0ull : (rb[0] << sl);
+      hi |= sl >= 64 ? (rb[0] << (sl - 64)) : ((rb[1] << sl) | (rb[0] >> (64 - sl)));
+      word[0] = ascii_complement8(lo);
+      word[1] = ascii_complement8(hi);
+    } else {
+      for (int64_t p = p0; p < p1; ++p) {
+        while (e <= p) { ++r; s = e; e = off[r + 1]; }
+        word[(p - p0) >> 3] |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 7));
+      }
     }
   }
   if (p1 - p0 == RC_BYTES_PER_LANE) {                         // (p0 is a multiple of 16, the buffer 16-byte aligned)

@@ -301,7 +301,8 @@ namespace {
 
 constexpr int JL_MAX_LINES = 4;
 constexpr int JL_BYTES_PER_LANE = 16;
-constexpr int64_t JL_TILE = (int64_t)BNPK_BLOCK * JL_BYTES_PER_LANE;
+constexpr int JL_CHUNKS = 4;                            // chunks of 16 bytes per lane: the staging is paid once per 16 KiB
+constexpr int64_t JL_TILE = (int64_t)BNPK_BLOCK * JL_BYTES_PER_LANE * JL_CHUNKS;
 
 struct jl_line {
   const uint8_t* data;         // flat bytes of the field (nullptr: a one-byte constant line)
@@ -349,7 +350,9 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
   }
   auto EO = [&](int64_t r) -> int64_t { return staged ? s_ent[r - lo] : entry_off[r]; };
   auto FO = [&](int l, int64_t r) -> int64_t { return staged ? s_off[l][r - lo] : lines.l[l].off[r]; };
-  const int64_t p0 = blk0 + (int64_t)threadIdx.x * JL_BYTES_PER_LANE;
+#pragma unroll 1
+  for (int chunk = 0; chunk < JL_CHUNKS; ++chunk) {
+  const int64_t p0 = blk0 + ((int64_t)chunk * BNPK_BLOCK + threadIdx.x) * JL_BYTES_PER_LANE;
   if (p0 >= total) return;
   int64_t r;
   {
@@ -376,7 +379,28 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
     const uint64_t a = (uint64_t)(add & 0xff) * 0x0101010101010101ull;
     return ((x & 0x7f7f7f7f7f7f7f7full) + (a & 0x7f7f7f7f7f7f7f7full)) ^ ((x ^ a) & 0x8080808080808080ull);
   };
-  while (p < p1) {
+  // A lane whose sixteen bytes cross line boundaries (four lanes in ten for FASTQ records) first walks the lines WITHOUT
+  // touching the fields: constants (header byte, newline, fill byte) go straight into the word, and what has to come from
+  // a field is noted as a piece {source, place, length, add}.  Then the loads of all pieces are issued together — 16
+  // unaligned bytes each — and shifted into place.  The walk used to wait for every span's load before it looked at the
+  // next line: two to four dependent round trips that the other lanes of the wavefront waited for.
+  struct piece_t { const uint8_t* src; int j, m, add; bool wide; };
+  constexpr int MAX_PIECES = 3;
+  piece_t pieces[MAX_PIECES];
+  int n_pieces = 0;
+  auto place = [&](uint64_t lo, uint64_t hi, int j, int m) {   // bytes 0 .. m-1 of (lo, hi) to output positions j .. j+m-1
+    if (m < 8) { lo &= (1ull << (8 * m)) - 1ull; hi = 0; }
+    else if (m < 16) hi &= (1ull << (8 * (m - 8))) - 1ull;
+    const int sh = 8 * (j & 7);
+    if (j < 8) {
+      word[0] |= lo << sh;
+      word[1] |= (sh ? lo >> (64 - sh) : 0ull) | (hi << sh);
+    } else {
+      word[1] |= lo << sh;
+    }
+  };
+  bool overflow = false;
+  while (p < p1 && !overflow) {
     while (e1 <= p) { ++r; e0 = e1; e1 = EO(r + 1); }
     int64_t t = p - e0;                                        // offset inside entry r
     for (int i = 0; i < n_lines && p < p1; ++i) {
@@ -385,16 +409,57 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
       const int64_t flen = L.data ? FO(i, r + 1) - fs : 1;
       const int64_t line_len = L.prefix + flen + 1;
       if (t >= line_len) { t -= line_len; continue; }
-      if (L.data && p == p0 && p1 - p0 == JL_BYTES_PER_LANE && t >= L.prefix && t + JL_BYTES_PER_LANE <= L.prefix + flen) {
-        uint64_t a[2];                                         // all sixteen bytes inside this field
-        __builtin_memcpy(a, L.data + fs + (t - L.prefix), 16);
-        word[0] = L.add ? add_bytes(a[0], L.add) : a[0];
-        word[1] = L.add ? add_bytes(a[1], L.add) : a[1];
-        p = p1;
-        break;
+      if (t < L.prefix) { emit(header, 1); ++t; }
+      if (p < p1 && t < L.prefix + flen) {
+        const int m = (int)min((int64_t)L.prefix + flen - t, p1 - p);
+        if (!L.data) {
+          emit(L.fill, 1);                                     // (a line without a field is one constant byte)
+        } else {
+          if (n_pieces == MAX_PIECES) { overflow = true; break; }
+          const int64_t at = fs + (t - L.prefix);
+          const piece_t pc = {L.data + at, (int)(p - p0), m, L.add, at + 16 <= L.off[n_rows]};   // wide: 16 bytes can be read there
+#pragma unroll
+          for (int q = 0; q < MAX_PIECES; ++q)                 // (static indices: the pieces stay in registers)
+            if (q == n_pieces) pieces[q] = pc;
+          ++n_pieces;
+          p += m;
+        }
+        t += m;
       }
-      // the bytes of this line that belong to the lane: the header byte, a span of the field (one unaligned 8-byte load,
-      // the per-byte addition done on the whole word), the newline
+      if (p < p1 && t == L.prefix + flen) emit(10, 1);
+      t = 0;                                                   // the next line starts at its first byte
+    }
+  }
+  uint64_t got[MAX_PIECES][2];
+#pragma unroll
+  for (int q = 0; q < MAX_PIECES; ++q) {
+    got[q][0] = got[q][1] = 0;
+    if (q < n_pieces) {
+      if (pieces[q].wide) {
+        __builtin_memcpy(got[q], pieces[q].src, 16);
+      } else {
+        for (int b = 0; b < pieces[q].m; ++b) got[q][b >> 3] |= (uint64_t)pieces[q].src[b] << (8 * (b & 7));
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < MAX_PIECES; ++q) {
+    if (q < n_pieces) {
+      uint64_t lo = got[q][0], hi = got[q][1];
+      if (pieces[q].add) { lo = add_bytes(lo, pieces[q].add); hi = add_bytes(hi, pieces[q].add); }
+      place(lo, hi, pieces[q].j, pieces[q].m);
+    }
+  }
+  // (more than MAX_PIECES fields in sixteen bytes — fields of a byte or two: the rest of the lane's bytes the slow way)
+  while (p < p1) {
+    while (e1 <= p) { ++r; e0 = e1; e1 = EO(r + 1); }
+    int64_t t = p - e0;
+    for (int i = 0; i < n_lines && p < p1; ++i) {
+      const jl_line& L = lines.l[i];
+      const int64_t fs = L.data ? FO(i, r) : 0;
+      const int64_t flen = L.data ? FO(i, r + 1) - fs : 1;
+      const int64_t line_len = L.prefix + flen + 1;
+      if (t >= line_len) { t -= line_len; continue; }
       if (t < L.prefix) { emit(header, 1); ++t; }
       while (p < p1 && t < L.prefix + flen) {
         const int m = (int)min(min((int64_t)L.prefix + flen - t, p1 - p), (int64_t)8);
@@ -415,13 +480,14 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
         t += m;
       }
       if (p < p1 && t == L.prefix + flen) emit(10, 1);
-      t = 0;                                                   // the next line starts at its first byte
+      t = 0;
     }
   }
   if (p1 - p0 == JL_BYTES_PER_LANE) {                          // (p0 is a multiple of 16, the buffer 16-byte aligned)
     *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)word[0], (uint32_t)(word[0] >> 32), (uint32_t)word[1], (uint32_t)(word[1] >> 32));
   } else {
     for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
+  }
   }
 }
 

@@ -35,6 +35,9 @@ def _short(name):
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
         return "%s<%s>" % (kind, src)
+    for key in ("finish_wave_kernel", "finish_dup_kernel", "finish_compact", "fw_finalize", "wf_minimizer", "hist_weighted", "row_reduce_wide"):
+        if key in name:
+            return key.replace("_kernel", "") + ("<probe>" if key == "finish_wave_kernel" and name.rstrip(">").endswith("true") else "")
     for key in ("fq_census", "fq_encode", "fq_select", "fq_starts", "fq_detect_cr", "wf_generate", "wf_count",
                 "finish_fast", "finish_sorted", "finish_check", "finish_collect", "finish_fit", "copy_peak", "mg_tile", "mg_split", "kmer_start_mask", "byte_census", "byte_positions", "validate_entries", "field_table", "scan_reduce", "scan_apply",
                 "gather_encode", "kmer_kernel", "run_census", "run_heads", "run_sums", "synth_fastq", "fill_kernel",
