@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
   // own, and what they execute has to stay in the instruction cache
   auto consume = [&](const fw_item& it, const fw_v2 (&r)[2]) {
     const int nb = it.nb;
-    if (nb >= 2) {
+    if (nb >= 2 && !__any(gave_up)) {                      // (uniform; a bucket the table could not hold is not probed further)
       const unsigned long long key[4] = {r[0].x, r[0].y, r[1].x, r[1].y};
       const int i0 = it.c + 2 * lane, i1 = i0 + 128;
       const bool act[4] = {i0 + 1 < nb, i0 < nb, i1 + 1 < nb, i1 < nb};

@@ -18,6 +18,23 @@
 #include "kmer_gen.h"
 #include "scan.h"
 
+#ifndef RP_ABL
+#define RP_ABL 0            // experiment builds only: 1 no global stores, 2 no staging of the new keys, 4 no rank atomics, 8 no carry staging / readback, 16 all stores of a workgroup into one 128 KiB window
+#endif
+#ifndef RP_L1_LINE
+#define RP_L1_LINE 16       // flush granule (keys) of the fused first level
+#endif
+#ifndef RP_HELD
+#define RP_HELD 1           // the fused first level holds two store requests per lane back (see rp_scatter_kernel)
+#endif
+
+#ifdef RP_PHASES              // experiment builds only: cycles of wave RP_PHASES of every workgroup between the marks of the scatter kernel
+__device__ unsigned long long rp_phase_cycles[8];
+#define RP_MARK(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now__ = __builtin_readcyclecounter(); ph_t[i] += now__ - ph_last; ph_last = now__; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RP_MARK(i)
+#endif
+
 namespace {
 
 constexpr int RP_THREADS = 1024;
@@ -108,6 +125,7 @@ struct mem_source {
       if (i < hi) raw.v[q] = STREAM ? __builtin_nontemporal_load(&keys[i]) : keys[i];   // STREAM: last use of the keys
     }
   }
+  __device__ __forceinline__ static void landed(const raw_t&) {}
   __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[ITEMS]) const {
     unsigned vm = 0;
 #pragma unroll
@@ -167,21 +185,32 @@ struct kmer_source {
     const int s6 = sh & 63;
     return s6 ? (lo >> s6) | (hi << (64 - s6)) : lo;
   }
+  // Every lane waits for its loads HERE, whether or not it has k-mers in the tile: a wait that only some paths contain
+  // makes the compiler repeat it (as vmcnt(0), behind whatever stores were issued since) where the registers are reused.
+  __device__ __forceinline__ static void landed(const raw_t& raw) { asm volatile("" : : "v"(raw.v), "v"(raw.w2)); }
+  // The k-mer at the lane's position o + q is bits [2q, 2q + 2k) of the 96 bits of the stream that start at base o: three
+  // 32-bit words cut out of the lane's five with one V_ALIGNBIT each, then two V_ALIGNBITs by a constant and the mask
+  // per k-mer — nothing is rolled from one k-mer to the next.
   __device__ __forceinline__ unsigned finish(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t kk[ITEMS]) const {
+    static_assert(2 * (ITEMS - 1) + 62 <= 96, "the k-mers of a lane lie in 96 bits of the stream");
     const int64_t o = t0 + (int64_t)threadIdx.x * ITEMS;
     const int64_t end = min(t0 + (int64_t)items * RP_THREADS, hi);
     if (o >= end) return 0;
     unsigned valid = raw.v;
     if (end - o < ITEMS) valid &= (1u << (int)(end - o)) - 1u;
     if (valid == 0) return 0;
-    const int sh0 = 2 * (int)(o & 31);
+    const unsigned sb = 2u * (unsigned)(o & 31);
+    const bool up = sb >= 32u;
+    const unsigned d1 = (unsigned)(raw.w0 >> 32), d2 = (unsigned)raw.w1, d3 = (unsigned)(raw.w1 >> 32);
+    const unsigned e0 = up ? d1 : (unsigned)raw.w0, e1 = up ? d2 : d1, e2 = up ? d3 : d2, e3 = up ? (unsigned)raw.w2 : d3;
+    const unsigned x0 = __builtin_amdgcn_alignbit(e1, e0, sb & 31u), x1 = __builtin_amdgcn_alignbit(e2, e1, sb & 31u),
+                   x2 = __builtin_amdgcn_alignbit(e3, e2, sb & 31u);
     const uint64_t mask = (1ull << (2 * k)) - 1ull;
-    uint64_t h = window(raw, sh0) & mask;                      // k-mer at position o
-    const uint64_t next = window(raw, sh0 + 2 * k);            // the bases that enter at positions o+1 .. o+11 (2 * (ITEMS - 1) bits)
-    const int top = 2 * k - 2;
+    const unsigned mask_lo = (unsigned)mask, mask_hi = (unsigned)(mask >> 32);
 #pragma unroll
     for (int q = 0; q < ITEMS; ++q) {
-      if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
+      const unsigned lo = q ? __builtin_amdgcn_alignbit(x1, x0, 2 * q) : x0, hh = q ? __builtin_amdgcn_alignbit(x2, x1, 2 * q) : x1;
+      const uint64_t h = ((uint64_t)(hh & mask_hi) << 32) | (lo & mask_lo);
       kk[q] = CANON ? min(h, ~(reverse_2bit_groups(h) >> (64 - 2 * k)) & mask) : h;   // slots of invalid positions are never read
     }
     return valid;
@@ -368,10 +397,14 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
                                                                 const int64_t* __restrict__ offs,
                                                                 uint64_t* __restrict__ out) {
   using C = rp_cfg<LINE, MAXB>;
+  // Two schedules of a round (see the loop): the fused first level, which is bound by its rounds, takes the next tile's
+  // keys before it stores and has the loads of the tile after next in flight for a whole round; a level that reads its
+  // keys from memory is bound by HBM either way and keeps the shorter-lived registers of the plain order.
+  constexpr bool AHEAD = !std::is_same<Source, mem_source>::value;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
-  uint64_t* meta = reinterpret_cast<uint64_t*>(smem + C::OFF_META);   // {flush start:16 | nfl:16 | carry start:16 | rem:16}
-  unsigned* newcnt = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);
+  uint64_t* meta = reinterpret_cast<uint64_t*>(smem + C::OFF_META);   // {flush start:16 | nfl:16 | carry start - nfl:16}
+  unsigned* newcnt = reinterpret_cast<unsigned*>(smem + C::OFF_CNT);  // keys of the bucket in this round, the carried ones included
   unsigned* line = reinterpret_cast<unsigned*>(smem + C::OFF_LINE);   // write cursor of the bucket / LINE
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + C::OFF_WSUM);
   int64_t* sh = reinterpret_cast<int64_t*>(smem + C::OFF_SLAB);
@@ -400,7 +433,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       const int64_t c0 = offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
       cursor[b] = c0 & ~(int64_t)(LINE - 1);
       rem[b] = (unsigned)(c0 & (LINE - 1));
-      newcnt[d] = 0;
+      newcnt[d] = rem[b];
     }
     carried += rem[b];
 #pragma unroll
@@ -418,14 +451,42 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   unsigned T = tile_size(carried);
   typename Source::raw_t raw;                     // loads of the next tile, in flight while this one is staged + flushed
   src.template issue<true>(t0, sl.hi, raw);
-  uint64_t k[Source::ITEMS];
+  // A key's rank is its index among the bucket's keys of the round: the counter starts at the number of carried keys.
+  // Branch-free and back to back (a position where no key starts adds zero to some bucket), so the eight LDS round trips
+  // of a lane overlap.
+  uint64_t k[Source::ITEMS] = {};
   unsigned r[Source::ITEMS];
-  unsigned vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
+  unsigned vm;
+  auto digit = [&](uint64_t key) { return (unsigned)(key >> shift) & (unsigned)(B - 1); };
+  auto rank_tile = [&]() {
+    Source::landed(raw);
+    vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
 #pragma unroll
-  for (int q = 0; q < Source::ITEMS; ++q)
-    if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+    for (int q = 0; q < Source::ITEMS; ++q) r[q] = (RP_ABL & 4) ? (unsigned)(tid & 7) : atomicAdd(&newcnt[digit(k[q])], (vm >> q) & 1u);
+  };
+  rank_tile();
+  if (AHEAD) src.template issue<true>(t0 + T, sl.hi, raw);   // (one round ahead: consumed at the end of the first round)
   __syncthreads();
 
+  // A CU drains its stores at ~20 GB/s however many of the other CUs are storing (that times 256 is what HBM takes), and a
+  // round's 52 KB issued in one burst stall the wavefronts that issue them for 45 % of the round (measured with cycle
+  // counters: flush + the barrier behind it), with nothing else to run in this one-workgroup-per-CU kernel.  So the level
+  // that is bound by its rounds and not by HBM (the fused first one) holds two of a lane's pairs back in registers and
+  // issues them later: one after the carried keys are read back, one after the next round's carried keys are staged —
+  // but none in the phase before the wait for the next tile's loads, which would sit through the stores' round trip.
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  constexpr bool HELD = RP_HELD && AHEAD && MAXB == 1024;
+  uint64_t* held_dst[2] = {nullptr, nullptr};
+  u64x2 held_val[2];
+  auto emit_held = [&](int h) {
+    if (HELD && held_dst[h]) {
+      __builtin_nontemporal_store(held_val[h], reinterpret_cast<u64x2*>(held_dst[h]));
+      held_dst[h] = nullptr;
+    }
+  };
+#ifdef RP_PHASES
+  unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_last = __builtin_readcyclecounter();
+#endif
   while (true) {
     const bool last = t0 + T >= sl.hi;
     // layout of the round
@@ -434,21 +495,27 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     for (int b = 0; b < C::NBT; ++b) {
       const int d = tid + b * RP_THREADS;
       unsigned tot = 0;
-      if (d < B) { tot = rem[b] + newcnt[d]; newcnt[d] = 0; }
+      if (d < B) tot = newcnt[d];
       nfl[b] = last ? tot : (tot & ~(unsigned)(LINE - 1));     // whole lines only, except in the slab's last round
       nrem[b] = tot - nfl[b];
+      if (d < B) newcnt[d] = nrem[b];                           // where the next round's ranks start
       packed += nfl[b] | (nrem[b] << 16);
     }
     const unsigned inc = wave_inclusive_scan(packed);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    unsigned wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < RP_THREADS / 64; ++w) {
-      const unsigned x = wsum[w];
-      if (w < wave) wbase += x;
-      total += x;
-    }
+    RP_MARK(0)
+    // the sixteen wave totals: every row of sixteen lanes scans them (four DPP steps), the wave picks its own prefix
+    static_assert(RP_THREADS / 64 == 16, "one DPP row holds the wave totals");
+    unsigned ws = wsum[lane & 15];
+    ws += (unsigned)__builtin_amdgcn_update_dpp(0, (int)ws, 0x111, 0xf, 0xf, false);
+    ws += (unsigned)__builtin_amdgcn_update_dpp(0, (int)ws, 0x112, 0xf, 0xf, false);
+    ws += (unsigned)__builtin_amdgcn_update_dpp(0, (int)ws, 0x114, 0xf, 0xf, false);
+    ws += (unsigned)__builtin_amdgcn_update_dpp(0, (int)ws, 0x118, 0xf, 0xf, false);
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)ws, 15);
+    const unsigned wbase = wave_s ? (unsigned)__builtin_amdgcn_readlane((int)ws, wave_s - 1) : 0u;
+    const unsigned T_next = tile_size(total >> 16);           // the next tile's extent is known
     unsigned ex = wbase + inc - packed;
     const unsigned total_f = total & 0xffffu;
     unsigned cpos[C::NBT];
@@ -459,79 +526,46 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       cpos[b] = total_f + (ex >> 16);
       ex += nfl[b] | (nrem[b] << 16);
       if (d < B) {
-        meta[d] = (uint64_t)fpos | ((uint64_t)nfl[b] << 16) | ((uint64_t)cpos[b] << 32) | ((uint64_t)rem[b] << 48);
+        meta[d] = (uint64_t)(fpos | (nfl[b] << 16)) | ((uint64_t)(cpos[b] - nfl[b]) << 32);
         line[d] = (unsigned)(cursor[b] >> C::LOG_LINE);
-        // carried keys precede the new ones (rem < LINE <= nfl): in-bucket indices 0 .. rem-1
+        // carried keys precede the new ones (rem < LINE <= nfl): in-bucket indices 0 .. rem-1.  Index j goes to slot
+        // (j + rot) mod nfl of the flush slice — it wraps at most once, from index nfl - rot on — or, when the bucket
+        // flushes nothing this round, to slot j of its carry slice.
         const unsigned rot = last ? 0u : 2u * ((unsigned)d & (unsigned)(LINE / 2 - 1));
+        const unsigned p0 = nfl[b] ? fpos + rot : cpos[b];
+        const unsigned wrap = nfl[b] ? nfl[b] - rot : 0xffffu;
 #pragma unroll
-        for (int j = 0; j < C::CARRY; ++j) {
-          if (j < (int)rem[b]) {
-            unsigned m = j + rot;
-            if (m >= nfl[b]) m -= nfl[b];
-            stage[nfl[b] ? fpos + m : cpos[b] + j] = left[b][j];
-          }
-        }
+        for (int j = 0; j < C::CARRY; ++j)
+          if (!(RP_ABL & 8) && j < (int)rem[b]) stage[p0 + j - ((unsigned)j >= wrap ? nfl[b] : 0u)] = left[b][j];
+      }
+    }
+    emit_held(1);
+    __syncthreads();
+    RP_MARK(1)
+    if (!AHEAD && !last) src.template issue<true>(t0 + T, sl.hi, raw);   // plain order: the loads land while this tile is staged and flushed
+    // stage the new keys behind the carried ones, four at a time: the table reads first (one wait for the four of them),
+    // then the arithmetic, then the stores
+    constexpr int SG = MAXB > 1024 ? 2 : 4;                   // (two owned buckets per lane leave fewer registers)
+    const unsigned rot_mask = last ? 0u : (unsigned)(LINE / 2 - 1);
+#pragma unroll
+    for (int q0 = 0; q0 < Source::ITEMS; q0 += SG) {
+      uint64_t mq[SG];
+#pragma unroll
+      for (int u = 0; u < SG; ++u) mq[u] = meta[digit(k[q0 + u])];
+#pragma unroll
+      for (int u = 0; u < SG; ++u) {
+        const int q = q0 + u;
+        const unsigned lo = (unsigned)mq[u], hi = (unsigned)(mq[u] >> 32);
+        const unsigned j = r[q], f = lo >> 16;
+        unsigned jr = j + 2u * (digit(k[q]) & rot_mask);                                // slot inside the (rotated) flush slice:
+        jr = min(jr, jr - f);                                                           // (j + rot) mod f, j + rot < 2 f
+        const unsigned slot = j < f ? (lo & 0xffffu) + jr : hi + j;                     // hi = carry start - f
+        if (!(RP_ABL & 2) && ((vm >> q) & 1u)) stage[slot] = k[q];
       }
     }
     __syncthreads();
-    // the next tile's extent is known: start its loads now, they land while this tile is staged and flushed
-    const unsigned T_next = tile_size(total >> 16);
-    if (!last) src.template issue<true>(t0 + T, sl.hi, raw);
-    // stage the new keys behind the carried ones
-#pragma unroll
-    for (int q = 0; q < Source::ITEMS; ++q) {
-      if ((vm >> q) & 1u) {
-        const unsigned d = (unsigned)(k[q] >> shift) & (B - 1);
-        const uint64_t m = meta[d];
-        const unsigned j = (unsigned)(m >> 48) + r[q], f = (unsigned)(m >> 16) & 0xffffu;
-        unsigned jr = j + (last ? 0u : 2u * (d & (unsigned)(LINE / 2 - 1)));            // slot inside the (rotated) flush slice
-        if (jr >= f) jr -= f;
-        stage[j < f ? ((unsigned)m & 0xffffu) + jr : ((unsigned)(m >> 32) & 0xffffu) + j - f] = k[q];
-      }
-    }
-    __syncthreads();
-    // flush: whole lines, 16 bytes per lane; two independent LDS -> HBM chains per lane and iteration
-    if (!last) {
-      for (unsigned i0 = 2 * tid; i0 < total_f; i0 += 4 * RP_THREADS) {
-        ulonglong2 kk[2];
-        unsigned d[2], f[2], nf[2], ln[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned i = i0 + u * 2 * RP_THREADS;
-          if (i < total_f) kk[u] = *reinterpret_cast<const ulonglong2*>(stage + i);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned i = i0 + u * 2 * RP_THREADS;
-          if (i < total_f) {
-            d[u] = (unsigned)(kk[u].x >> shift) & (B - 1);
-            const unsigned m = (unsigned)meta[d[u]];
-            f[u] = m & 0xffffu;
-            nf[u] = m >> 16;
-            ln[u] = line[d[u]];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const unsigned i = i0 + u * 2 * RP_THREADS;
-          if (i < total_f) {
-            unsigned j = i - f[u], rot = 2u * (d[u] & (unsigned)(LINE / 2 - 1));      // undo the rotation of the slice
-            j = j >= rot ? j - rot : j + nf[u] - rot;
-            uint64_t* dst = out + (((int64_t)ln[u] << C::LOG_LINE) + j);
-            if (!((kk[u].x | kk[u].y) >> 63)) {
-              typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-              u64x2 pair;
-              pair.x = kk[u].x;
-              pair.y = kk[u].y;
-              __builtin_nontemporal_store(pair, reinterpret_cast<u64x2*>(dst));
-            } else {                                           // phantom slots before the bucket's first key
-              if (!(kk[u].x >> 63)) dst[0] = kk[u].x;
-              if (!(kk[u].y >> 63)) dst[1] = kk[u].y;
-            }
-          }
-        }
-      }
-    } else {
+    RP_MARK(2)
+    if (last) {
       for (unsigned i = tid; i < total_f; i += RP_THREADS) {
         const uint64_t key = stage[i];
         const unsigned d = (unsigned)(key >> shift) & (B - 1);
@@ -539,25 +573,101 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       }
       break;
     }
+    // The next tile's keys and ranks BEFORE this round's stores are issued.  Its loads are awaited with vmcnt(0) — the
+    // count is unknown at compile time, and the compiler repeats the wait where it reuses the registers for the loads of
+    // the tile after — and behind the stores such a wait sits through their whole round trip to HBM, once per round:
+    // 8 of the 19.7 ms of the fused level 1 (without its stores: 11.8 ms).  So: wait here, a whole round after the loads
+    // and the last stores were issued; start the loads of the tile after next; only then store.  The stores drain while
+    // the next round is laid out and staged.
+    if (AHEAD) {
+      t0 += T;
+      T = T_next;
+      rank_tile();
+      RP_MARK(3)
+      src.template issue<true>(t0 + T, sl.hi, raw);
+      RP_MARK(4)
+    }
+    // flush: whole lines, 16 bytes per lane; two independent LDS -> HBM chains per lane and call.  With HELD, the
+    // second and third pair of a lane (a round has ~3.2 per lane) only get as far as the lane's registers here.
+    auto flush2 = [&](unsigned i0, int hold0, int hold1) {
+      ulonglong2 kk[2];
+      unsigned d[2], f[2], nf[2], ln[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned i = i0 + u * 2 * RP_THREADS;
+        if (i < total_f) kk[u] = *reinterpret_cast<const ulonglong2*>(stage + i);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned i = i0 + u * 2 * RP_THREADS;
+        if (i < total_f) {
+          d[u] = (unsigned)(kk[u].x >> shift) & (B - 1);
+          const unsigned m = (unsigned)meta[d[u]];
+          f[u] = m & 0xffffu;
+          nf[u] = m >> 16;
+          ln[u] = line[d[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned i = i0 + u * 2 * RP_THREADS;
+        const int hold = u ? hold1 : hold0;
+        if (i < total_f) {
+          unsigned j = i - f[u] - 2u * (d[u] & (unsigned)(LINE / 2 - 1));              // undo the rotation of the slice:
+          j = min(j, j + nf[u]);                                                       // (slot - rot) mod nfl
+          uint64_t* dst = out + (((int64_t)ln[u] << C::LOG_LINE) + j);
+          if (RP_ABL & 16) dst = out + (size_t)blockIdx.x * 16384 + (i & 0x3ffeu);
+          if (RP_ABL & 1) {
+            if (dst == nullptr) dst[0] = kk[u].x;
+          } else if (!((kk[u].x | kk[u].y) >> 63)) {
+            u64x2 pair;
+            pair.x = kk[u].x;
+            pair.y = kk[u].y;
+            if (hold >= 0) {
+              held_dst[hold >= 0 ? hold : 0] = dst;
+              held_val[hold >= 0 ? hold : 0] = pair;
+            } else {
+              __builtin_nontemporal_store(pair, reinterpret_cast<u64x2*>(dst));
+            }
+          } else {                                             // phantom slots before the bucket's first key
+            if (!(kk[u].x >> 63)) dst[0] = kk[u].x;
+            if (!(kk[u].y >> 63)) dst[1] = kk[u].y;
+          }
+        }
+      }
+    };
+    if (HELD) {
+      if (2u * tid < total_f) flush2(2 * tid, -1, 0);
+      if (2u * tid + 4 * RP_THREADS < total_f) flush2(2 * tid + 4 * RP_THREADS, 1, -1);
+      for (unsigned i0 = 2 * tid + 8 * RP_THREADS; i0 < total_f; i0 += 4 * RP_THREADS) flush2(i0, -1, -1);
+    } else {
+      for (unsigned i0 = 2 * tid; i0 < total_f; i0 += 4 * RP_THREADS) flush2(i0, -1, -1);
+    }
+    RP_MARK(5)
 #pragma unroll
     for (int b = 0; b < C::NBT; ++b) {
       if (tid + b * RP_THREADS < B) {
+        // (64-byte granules: seven unconditional reads from one address — what lies behind the nrem carried keys is
+        // never staged — cost less than seven compares and branches)
 #pragma unroll
         for (int j = 0; j < C::CARRY; ++j)
-          if (j < (int)nrem[b]) left[b][j] = stage[cpos[b] + j];
+          if (!(RP_ABL & 8) && (LINE == 8 || j < (int)nrem[b])) left[b][j] = stage[cpos[b] + j];
         cursor[b] += nfl[b];
         rem[b] = nrem[b];
       }
     }
-    // next tile (its loads were issued before the staging): keys + ranks
-    t0 += T;
-    T = T_next;
-    vm = src.finish(t0, sl.hi, (int)(T / RP_THREADS), raw, k);
-#pragma unroll
-    for (int q = 0; q < Source::ITEMS; ++q)
-      if ((vm >> q) & 1u) r[q] = atomicAdd(&newcnt[(unsigned)(k[q] >> shift) & (B - 1)], 1u);
+    emit_held(0);
+    if (!AHEAD) {                                            // plain order: the next tile's keys and ranks after the stores
+      t0 += T;
+      T = T_next;
+      rank_tile();
+    }
     __syncthreads();
+    RP_MARK(6)
   }
+#ifdef RP_PHASES
+  if (tid == 64 * RP_PHASES) for (int i = 0; i < 8; ++i) atomicAdd(&rp_phase_cycles[i], ph_t[i]);
+#endif
 }
 
 // seg_slabs[p] = slabs before segment p (p <= n_seg); one workgroup, any n_seg
@@ -670,7 +780,7 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
   }
   bnpk_timer t(ctx, scatter_name, s);
   // (the granule: 16 keys for levels that read their keys from memory, 8 for the fused first level — see rp_cfg)
-  constexpr int line = std::is_same<Source, mem_source>::value ? 16 : 8;
+  constexpr int line = std::is_same<Source, mem_source>::value ? 16 : RP_L1_LINE;
   auto launch = [&](auto line_c, auto maxb_c) {
     constexpr int L_ = decltype(line_c)::value, M_ = decltype(maxb_c)::value;
     constexpr size_t lds = rp_cfg<L_, M_>::LDS;
@@ -773,6 +883,14 @@ __global__ __launch_bounds__(RS_THREADS) void rp_split_small_kernel(const uint64
 }  // namespace
 
 extern "C" {
+
+#ifdef RP_PHASES
+int bnpk_debug_radix_phases(unsigned long long* out8) {   // reads and clears the counters
+  unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(rp_phase_cycles), sizeof(zero)) != hipSuccess) return BNPK_ERR_HIP;
+  return hipMemcpyToSymbol(HIP_SYMBOL(rp_phase_cycles), zero, sizeof(zero)) == hipSuccess ? BNPK_OK : BNPK_ERR_HIP;
+}
+#endif
 
 int64_t bnpk_radix_max_bits(void) { return RP_MAXBITS; }
 
