@@ -399,7 +399,8 @@ def main():
                    "canonical": bool(args.canonical), "kmers_per_gpu": stats.n_kmers, "distinct_rank0": n_distinct,
                    "histogram": "dense" if args.k <= 13 else "sparse (sorted unique int64 keys + counts)",
                    "parallelism": "chunk-sharded x%d%s" % (world, ", key-range exchange of %s over %s" % (
-                       {"keys": "raw hashes", "counts": "(key, count) runs of the local histograms"}.get(merge["plan"], "dense bins"),
+                       {"keys": "raw hashes in %s steps overlapped with the counting" % merge.get("groups"),
+                        "counts": "(key, count) runs of the local histograms"}.get(merge["plan"], "dense bins"),
                        merge["collectives"]) if world > 1 else "")},
         "roofline": roofline,
         "kernels": kernels,

@@ -55,6 +55,7 @@ SIGNATURES = {
     "bnpk_allreduce_hist": (_int, [_p, _p, _p, _i64, _p]),
     "bnpk_exchange_counts": (_int, [_p, _p, _p, _int, _p, _p]),
     "bnpk_exchange_by_key_range": (_int, [_p, _p, _p, _p, _p, _p, _p]),
+    "bnpk_exchange_slices": (_int, [_p, _p, _p, _p, _p, _p, _p, _p]),
     "bnpk_prof_reset": (_int, [_p]),
     "bnpk_prof_count": (_int, [_p]),
     "bnpk_prof_get": (_int, [_p, _int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -7,7 +7,10 @@
 //                                much it will receive, bnpk_exchange_by_key_range moves every item to the rank that owns
 //                                its key range in ONE grouped ncclSend/ncclRecv step (each of a GPU's xGMI links carries
 //                                the slice of one peer, all of them at once) — raw 8-byte hashes before counting, or
-//                                (key, count) runs after a local histogram, whichever moves fewer bytes (parallel.py)
+//                                (key, count) runs after a local histogram, whichever moves fewer bytes (parallel.py);
+//                                bnpk_exchange_slices is the same step with the slice of every peer at an offset of its
+//                                own: one call per group of key ranges, on a stream of its own, while the group before
+//                                is counted
 //
 // RCCL is loaded on first use (dlopen of librccl.so.1 — the copy already in the process if the caller's framework brought
 // one — then librccl.so): a library that is only ever used on one GPU does not need it, and bnpk_comm_* report
@@ -169,6 +172,40 @@ int bnpk_exchange_counts(bnpk_ctx* ctx, void* comm, const int64_t* h_send_counts
   return BNPK_OK;
 }
 
+int bnpk_exchange_slices(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const int64_t* h_send_offsets, const int64_t* h_send_counts,
+                         int64_t* d_recv, const int64_t* h_recv_counts, void* stream) {
+  if (!ctx || !comm || !h_send_offsets || !h_send_counts || !h_recv_counts) return BNPK_ERR_ARG;
+  const rccl_api& a = rccl();
+  if (!a.ok) return BNPK_ERR_NODEVICE;
+  int world = 0, rank = 0;
+  BNPK_CHECK(comm_shape(a, (ncclComm_t)comm, world, rank));
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int64_t> recv_off(world + 1, 0);
+  int64_t sent = 0;
+  for (int p = 0; p < world; ++p) {
+    if (h_send_counts[p] < 0 || h_recv_counts[p] < 0 || h_send_offsets[p] < 0) return BNPK_ERR_ARG;
+    sent += h_send_counts[p];
+    recv_off[p + 1] = recv_off[p] + h_recv_counts[p];
+  }
+  if ((sent > 0 && !d_send) || (recv_off[world] > 0 && !d_recv)) return BNPK_ERR_ARG;
+  if (h_send_counts[rank] != h_recv_counts[rank]) return BNPK_ERR_ARG;
+  bnpk_timer t(ctx, "exchange_by_key_range", s);
+  // this rank's own slice never leaves the device; every other slice is one send and one receive, all in one group: the
+  // transfers to the N - 1 peers run concurrently, one per xGMI link
+  if (h_send_counts[rank] > 0)
+    BNPK_HIP(ctx, hipMemcpyAsync(d_recv + recv_off[rank], d_send + h_send_offsets[rank], (size_t)h_send_counts[rank] * 8,
+                                 hipMemcpyDeviceToDevice, s));
+  BNPK_RCCL(a, a.GroupStart());
+  for (int p = 0; p < world; ++p) {
+    if (p == rank) continue;
+    if (h_send_counts[p] > 0)
+      BNPK_RCCL(a, a.Send(d_send + h_send_offsets[p], (size_t)h_send_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
+    if (h_recv_counts[p] > 0) BNPK_RCCL(a, a.Recv(d_recv + recv_off[p], (size_t)h_recv_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
+  }
+  BNPK_RCCL(a, a.GroupEnd());
+  return BNPK_OK;
+}
+
 int bnpk_exchange_by_key_range(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const int64_t* h_send_counts, int64_t* d_recv,
                                const int64_t* h_recv_counts, void* stream) {
   if (!ctx || !comm || !h_send_counts || !h_recv_counts) return BNPK_ERR_ARG;
@@ -176,29 +213,12 @@ int bnpk_exchange_by_key_range(bnpk_ctx* ctx, void* comm, const int64_t* d_send,
   if (!a.ok) return BNPK_ERR_NODEVICE;
   int world = 0, rank = 0;
   BNPK_CHECK(comm_shape(a, (ncclComm_t)comm, world, rank));
-  hipStream_t s = (hipStream_t)stream;
-  std::vector<int64_t> send_off(world + 1, 0), recv_off(world + 1, 0);
-  for (int p = 0; p < world; ++p) {
-    if (h_send_counts[p] < 0 || h_recv_counts[p] < 0) return BNPK_ERR_ARG;
-    send_off[p + 1] = send_off[p] + h_send_counts[p];
-    recv_off[p + 1] = recv_off[p] + h_recv_counts[p];
+  std::vector<int64_t> send_off(world, 0);
+  for (int p = 1; p < world; ++p) {
+    if (h_send_counts[p - 1] < 0) return BNPK_ERR_ARG;
+    send_off[p] = send_off[p - 1] + h_send_counts[p - 1];
   }
-  if ((send_off[world] > 0 && !d_send) || (recv_off[world] > 0 && !d_recv)) return BNPK_ERR_ARG;
-  if (h_send_counts[rank] != h_recv_counts[rank]) return BNPK_ERR_ARG;
-  bnpk_timer t(ctx, "exchange_by_key_range", s);
-  // this rank's own slice never leaves the device; every other slice is one send and one receive, all in one group: the
-  // transfers to the N - 1 peers run concurrently, one per xGMI link
-  if (h_send_counts[rank] > 0)
-    BNPK_HIP(ctx, hipMemcpyAsync(d_recv + recv_off[rank], d_send + send_off[rank], (size_t)h_send_counts[rank] * 8,
-                                 hipMemcpyDeviceToDevice, s));
-  BNPK_RCCL(a, a.GroupStart());
-  for (int p = 0; p < world; ++p) {
-    if (p == rank) continue;
-    if (h_send_counts[p] > 0) BNPK_RCCL(a, a.Send(d_send + send_off[p], (size_t)h_send_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
-    if (h_recv_counts[p] > 0) BNPK_RCCL(a, a.Recv(d_recv + recv_off[p], (size_t)h_recv_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
-  }
-  BNPK_RCCL(a, a.GroupEnd());
-  return BNPK_OK;
+  return bnpk_exchange_slices(ctx, comm, d_send, send_off.data(), h_send_counts, d_recv, h_recv_counts, stream);
 }
 
 }  // extern "C"

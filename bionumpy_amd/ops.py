@@ -592,7 +592,7 @@ class HipOps:
                                            ptr(child), self._s()))
         return out, child
 
-    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0):
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0, dest=None):
         """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys).
 
         partition: (bucket_offsets, bits) if ``values`` is already grouped by its top ``bits`` bits
@@ -600,10 +600,18 @@ class HipOps:
         rank owns after the multi-GPU exchange) — the shared leading bits are then skipped by the partition.
         fast=False forces the fallback (rocPRIM sort + run kernels) that heavy-hitter buckets take.
         skew: densest / average density of the keys over their range, where it is known (canonical k-mers: 2) —
-        the levels are then planned for the densest part instead of discovering it from over-full buckets."""
+        the levels are then planned for the densest part instead of discovering it from over-full buckets.
+        dest: (keys HArray, counts HArray, pos) — the result is written to [pos, pos + distinct) of these device arrays,
+        which have room for pos + len(values) entries, and views of them are returned (the pieces of a histogram that is
+        counted key range by key range land next to each other without a copy)."""
         t = values.dev()
         n = t.numel()
+        if dest is not None:
+            out_keys, out_counts, pos = dest[0].dev(), dest[1].dev(), int(dest[2])
+            assert pos + n <= out_keys.numel() and pos + n <= out_counts.numel()
         if n == 0:
+            if dest is not None:
+                return HArray(dev=out_keys[pos:pos]), HArray(dev=out_counts[pos:pos])
             z = self._empty(0, np.int64)
             return HArray(dev=z), HArray(dev=z.clone())
         cur, owned = t, consume                          # owned: may ``cur`` be overwritten / handed out?
@@ -661,8 +669,11 @@ class HipOps:
             if fits:
                 # bnpk_finish_sorted uses the partitioned keys as workspace: never the caller's array
                 work = cur if owned else cur.clone()
-                keys_out = spare if spare is not None else self._empty(n, np.int64)
-                counts = self._empty(n, np.int64)
+                if dest is not None:
+                    keys_out, counts = out_keys[pos:pos + n], out_counts[pos:pos + n]
+                else:
+                    keys_out = spare if spare is not None else self._empty(n, np.int64)
+                    counts = self._empty(n, np.int64)
                 state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
                 n_unique, overflow = C.c_int64(0), C.c_int(0)
                 table, big_keys, big_counts = big if big is not None else (None, None, None)
@@ -675,6 +686,11 @@ class HipOps:
                 return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
             del spare, big
         keys_out, counts = self._count_by_sorting(cur if owned else cur.clone(), key_bits)
+        if dest is not None:
+            d = keys_out.numel()
+            out_keys[pos:pos + d].copy_(keys_out)
+            out_counts[pos:pos + d].copy_(counts)
+            keys_out, counts = out_keys[pos:pos + d], out_counts[pos:pos + d]
         return HArray(dev=keys_out), HArray(dev=counts)
 
     MAX_PRECOUNTED = 256          # buckets over the finishing kernel's capacity that are counted one by one
@@ -797,6 +813,10 @@ class HipOps:
         return HArray(dev=out)
 
     # -- misc --------------------------------------------------------------------------------------------------------
+    def empty_i64(self, n):
+        """uninitialised int64 array in HBM"""
+        return HArray(dev=self._empty(n, np.int64))
+
     def concat(self, arrays):
         return HArray(dev=self.device.torch_cat([a.dev() for a in arrays]))
 

@@ -14,7 +14,9 @@ ABI's communicator cannot be made (reported, never silent).
   - ``keys``   (nearly) duplicate-free k-mers: every rank generates its hashes already grouped by their top bits
     (bnpk_kmers_partition; the bucket boundaries are the send cuts), ONE exchange moves every raw 8-byte hash to the
     rank that owns its range (each of a GPU's 7 xGMI links carries 1/8 of its keys concurrently), and every rank
-    partitions + finishes only its own range;
+    partitions + finishes only its own range.  With ``groups`` > 1 the range of every rank is cut into that many parts and
+    the exchange into as many steps (bnpk_exchange_slices): step j + 1 runs on a stream of its own while the keys step j
+    delivered are counted, and the sorted pieces land next to each other in one pair of arrays;
   - ``counts`` duplicate-heavy k-mers (reads that cover a genome many times: S-genome holds every 31-mer ~60 times):
     every rank counts its OWN k-mers first — the single-GPU path, unchanged — cuts its sorted (key, count) list at the
     range boundaries, and the exchange moves 16 bytes per DISTINCT key instead of 8 per k-mer (S-genome: 1.6 GB
@@ -29,6 +31,7 @@ from .device import HArray
 from .ops import get_ops
 
 FINE_BITS = 8          # partition granularity: 256 fine buckets, contiguous groups of them per rank
+KEY_GROUPS = 4         # plan "keys": steps the exchange is cut into (the parts of a rank's key range), overlapped with the counting
 COUNTS_PLAN_MAX_RATIO = 0.25      # distinct / total below which 16 B per distinct key beats 8 B per k-mer (with room)
 PROBE_KEYS = 4 << 20              # keys of one fine bucket that a rank counts to estimate the ratio
 
@@ -87,6 +90,15 @@ class TorchCollectives:
         return _from_tensor(recv_t, ops)
 
 
+    def exchange_slices(self, send, send_offsets, send_counts, recv_counts):
+        """exchange() with the slice for rank p at send[send_offsets[p]:][:send_counts[p]]"""
+        import torch
+        ops = get_ops()
+        send_t = _as_tensor(send, ops)
+        packed = torch.cat([send_t[int(o):int(o) + int(c)] for o, c in zip(send_offsets, send_counts)])
+        return self.exchange(_from_tensor(packed, ops), send_counts, recv_counts)
+
+
 class AbiCollectives:
     """the same over the C-ABI (RCCL inside libbnpk.so): a communicator of its own, made from an id that rank 0 takes and
     torch.distributed broadcasts"""
@@ -143,8 +155,21 @@ class AbiCollectives:
         return HArray(dev=recv_t)
 
 
+    def exchange_slices(self, send, send_offsets, send_counts, recv_counts):
+        import torch
+        send_t = send.dev()
+        so = np.ascontiguousarray(send_offsets, dtype=np.int64)
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        recv_t = torch.empty(int(rc.sum()), dtype=torch.int64, device=send_t.device)
+        self._chk(self.lib.bnpk_exchange_slices(self.dev.ctx, self.comm, C.c_void_p(send_t.data_ptr()), so.ctypes.data_as(C.c_void_p),
+                                                sc.ctypes.data_as(C.c_void_p), C.c_void_p(recv_t.data_ptr()),
+                                                rc.ctypes.data_as(C.c_void_p), self.dev.stream()))
+        return HArray(dev=recv_t)
+
+
 _collectives = {}
-last = {"plan": None, "collectives": None}     # what the last sparse merge of this process did (bench.py reports it)
+last = {"plan": None, "collectives": None, "groups": None}     # what the last sparse merge of this process did (bench.py reports it)
 
 
 def collectives(group=None):
@@ -248,6 +273,77 @@ def exchange_by_key_range(hashes, key_bits, group=None, cuts=None):
     return coll.exchange(part, send_counts, recv_counts), key_range
 
 
+def key_groups(world, groups):
+    """first fine bucket of part j of rank q's range: bounds[q][j], j = 0 .. groups (the ranges of rank_of_bucket cut
+    into ``groups`` nearly equal runs of fine buckets; a rank with fewer buckets than groups has empty parts)"""
+    owner = rank_of_bucket(world)
+    bounds = np.zeros((world, groups + 1), dtype=np.int64)
+    for q in range(world):
+        mine = np.flatnonzero(owner == q)
+        lo, n = (int(mine[0]), mine.size) if mine.size else (0, 0)
+        bounds[q] = lo + (np.arange(groups + 1, dtype=np.int64) * n) // groups
+    return bounds
+
+
+class _SideStream:
+    """the stream the exchange steps run on (None on the CPU: the steps then run where they are called)"""
+
+    def __init__(self, ops):
+        self.torch = None
+        if not getattr(ops, "host_only", False):
+            import torch
+            self.torch = torch
+            self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(torch.cuda.current_stream())    # what is sent was produced on the caller's stream
+
+    def run(self, fn):
+        """fn() on the side stream -> (result, event or None)"""
+        if self.torch is None:
+            return fn(), None
+        with self.torch.cuda.stream(self.stream):
+            result = fn()
+            event = self.torch.cuda.Event()
+            event.record(self.stream)
+        return result, event
+
+    def ready(self, result, event):
+        """the caller's stream waits for the step that produced ``result``"""
+        if event is not None:
+            cur = self.torch.cuda.current_stream()
+            cur.wait_event(event)
+            result.dev().record_stream(cur)
+        return result
+
+
+def count_keys_in_groups(part, cuts, key_bits, groups, group=None):
+    """plan "keys" with the exchange cut into ``groups`` steps and overlapped with the counting.
+    part, cuts: this rank's hashes grouped by their top FINE_BITS bits and the bucket boundaries (bnpk_kmers_partition).
+    Returns (keys, counts): views of one pair of arrays holding the sorted pieces back to back."""
+    ops = get_ops()
+    coll = collectives(group)
+    world, rank = coll.world, coll.rank
+    cuts = np.asarray(cuts.host() if isinstance(cuts, HArray) else cuts, dtype=np.int64)
+    bounds = key_groups(world, groups)
+    send_off = cuts[bounds[:, :-1]]                                  # [peer][step]
+    send_cnt = cuts[bounds[:, 1:]] - send_off
+    recv_cnt = np.asarray(coll.exchange_counts(send_cnt.ravel()), dtype=np.int64).reshape(world, groups)   # [source][step]
+    total = int(recv_cnt.sum())
+    keys_all, counts_all = ops.empty_i64(total), ops.empty_i64(total)
+    side = _SideStream(ops)
+    step = lambda j: side.run(lambda: coll.exchange_slices(part, send_off[:, j], send_cnt[:, j], recv_cnt[:, j]))
+    pos, pending = 0, step(0)
+    for j in range(groups):
+        mine = side.ready(*pending)
+        pending = step(j + 1) if j + 1 < groups else None            # in flight while part j is counted
+        lo_b, hi_b = int(bounds[rank, j]), int(bounds[rank, j + 1])
+        if hi_b > lo_b:
+            key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
+            k, _ = ops.count_sparse(mine, key_bits=key_bits, consume=True, key_range=key_range, dest=(keys_all, counts_all, pos))
+            pos += k.size
+        del mine
+    return _slice(keys_all, 0, pos), _slice(counts_all, 0, pos)
+
+
 def exchange_counted(keys, counts, key_bits, group=None):
     """plan "counts": this rank's sorted (keys, counts) -> the global (keys, counts) of the key range it owns"""
     coll = collectives(group)
@@ -263,9 +359,10 @@ def exchange_counted(keys, counts, key_bits, group=None):
     return _merge_runs([(_slice(rk, int(off[q]), int(off[q + 1])), _slice(rc, int(off[q]), int(off[q + 1]))) for q in range(world)])
 
 
-def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto"):
+def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto", groups=None):
     """global sparse histogram, range-partitioned over the ranks: (keys, counts) of this rank's key range.
-    ``hashes`` grouped by their top FINE_BITS bits with bucket boundaries ``cuts`` (bnpk_kmers_partition), or raw."""
+    ``hashes`` grouped by their top FINE_BITS bits with bucket boundaries ``cuts`` (bnpk_kmers_partition), or raw.
+    groups: steps of the exchange of plan "keys" (default KEY_GROUPS; 1 = one exchange, then one count)."""
     ops = get_ops()
     if isinstance(hashes, list):              # [HArray]: the caller gave its only reference away
         held = hashes
@@ -283,12 +380,16 @@ def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto
         keys, counts = ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, FINE_BITS))
         del hashes
         return exchange_counted(keys, counts, key_bits, group)
+    groups = KEY_GROUPS if groups is None else int(groups)
+    last["groups"] = groups if coll.world > 1 else 1
+    if groups > 1 and coll.world > 1:
+        return count_keys_in_groups(hashes, cuts, key_bits, groups, group)
     mine, key_range = exchange_by_key_range(hashes, key_bits, group, cuts)
     del hashes
     return ops.count_sparse(mine, key_bits=key_bits, consume=True, key_range=key_range)
 
 
-def count_sparse_virtual(shards, key_bits, plan="auto"):
+def count_sparse_virtual(shards, key_bits, plan="auto", groups=None):
     """The N > 1 sparse path on ONE GPU: ``shards`` = [(hashes partitioned by their top FINE_BITS bits, cuts)] of N
     virtual ranks (what kmers_partitioned(FINE_BITS) leaves on every rank before the exchange).  The exchange is
     replaced by what it delivers — for destination r the slices of its range from source 0, 1, .. N-1, one after the
@@ -315,12 +416,20 @@ def count_sparse_virtual(shards, key_bits, plan="auto"):
             received.append(2 * sum(run[0].size for run in runs))
             out.append(_merge_runs(runs))
         return out, received, plan
+    groups = KEY_GROUPS if groups is None else int(groups)
+    bounds = key_groups(world, groups)
     for r in range(world):
-        mine = np.flatnonzero(owner == r)
-        lo_b, hi_b = int(mine[0]), int(mine[-1]) + 1
-        key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
-        pieces = [_slice(part, int(c[lo_b]), int(c[hi_b])) for (part, _), c in zip(shards, cuts)]
-        recv = ops.concat(pieces)                       # == the receive buffer of the exchange on rank r
-        received.append(recv.size)
-        out.append(ops.count_sparse(recv, key_bits=key_bits, consume=True, key_range=key_range))
+        # what count_keys_in_groups does on rank r: step j delivers part j of its range from source 0, 1, .. N-1
+        total = sum(int(c[bounds[r, groups]] - c[bounds[r, 0]]) for c in cuts)
+        keys_all, counts_all, pos = ops.empty_i64(total), ops.empty_i64(total), 0
+        for j in range(groups):
+            lo_b, hi_b = int(bounds[r, j]), int(bounds[r, j + 1])
+            if hi_b == lo_b:
+                continue
+            key_range = (lo_b << (key_bits - FINE_BITS), hi_b << (key_bits - FINE_BITS))
+            recv = ops.concat([_slice(part, int(c[lo_b]), int(c[hi_b])) for (part, _), c in zip(shards, cuts)])
+            k, _ = ops.count_sparse(recv, key_bits=key_bits, consume=True, key_range=key_range, dest=(keys_all, counts_all, pos))
+            pos += k.size
+        received.append(total)
+        out.append((_slice(keys_all, 0, pos), _slice(counts_all, 0, pos)))
     return out, received, plan

@@ -91,7 +91,8 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
 
 
-def fastq_kmer_histogram_virtual_ranks(texts, k, buffer_type=FastQBuffer, canonical=False, plan="auto", with_plan=False):
+def fastq_kmer_histogram_virtual_ranks(texts, k, buffer_type=FastQBuffer, canonical=False, plan="auto", with_plan=False,
+                                       groups=None):
     """The sparse N-GPU path with the N ranks played one after the other by a single GPU: texts[r] is rank
     r's shard of the reads.  Every virtual rank decodes its shard and generates its k-mer hashes grouped by the top
     parallel.FINE_BITS bits (the send cuts); parallel.count_sparse_virtual stands in for the exchange and counts every
@@ -109,7 +110,7 @@ def fastq_kmer_histogram_virtual_ranks(texts, k, buffer_type=FastQBuffer, canoni
         shards.append(ops.kmers_partitioned(packed, starts_mask, n_bases, n_kmers, k, parallel.FINE_BITS, canonical=canonical))
         stats.append(BatchStats(n, n_bases, n_kmers, text.size))
         del packed, starts_mask
-    hists, received, plan = parallel.count_sparse_virtual(shards, 2 * k, plan)
+    hists, received, plan = parallel.count_sparse_virtual(shards, 2 * k, plan, groups)
     return (hists, stats, received, plan) if with_plan else (hists, stats, received)
 
 

@@ -74,7 +74,11 @@ int         bnpk_device_info(bnpk_ctx* ctx, char* name64, int* compute_units, in
  *                               receives the slices of rank 0, 1, ... back to back (h_recv_counts[q] words, from
  *                               bnpk_exchange_counts).  One grouped ncclSend/ncclRecv step: the N - 1 transfers of a GPU
  *                               run concurrently, one per xGMI link; the rank's own slice is a device copy.  Asynchronous
- *                               on `stream`. */
+ *                               on `stream`.
+ *   bnpk_exchange_slices        the same step with the slice for rank p at d_send + h_send_offsets[p] (words): what a rank
+ *                               sends in ONE of several steps — the keys of the j-th part of every peer's range — lies
+ *                               scattered in its partitioned array.  A caller runs step j + 1 on a stream of its own while
+ *                               it counts what step j delivered (bionumpy_amd/parallel.py: plan "keys", groups > 1). */
 #define BNPK_COMM_ID_BYTES 128
 int bnpk_comm_unique_id(uint8_t* id128);
 int bnpk_comm_init(bnpk_ctx* ctx, const uint8_t* id128, int n_ranks, int rank, void** comm_out);
@@ -86,6 +90,8 @@ int bnpk_exchange_counts(bnpk_ctx* ctx, void* comm, const int64_t* h_send_counts
                          void* stream);
 int bnpk_exchange_by_key_range(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const int64_t* h_send_counts, int64_t* d_recv,
                                const int64_t* h_recv_counts, void* stream);
+int bnpk_exchange_slices(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const int64_t* h_send_offsets, const int64_t* h_send_counts,
+                         int64_t* d_recv, const int64_t* h_recv_counts, void* stream);
 
 /* per-kernel hipEvent timers (used by bench.py for the live roofline numbers) */
 int bnpk_prof_enable(bnpk_ctx* ctx, int on);

@@ -18,9 +18,10 @@ def parse(self, batch):
 parser.NumpyFileReader._fill, parser.NumpyFileReader._parse = fill, parse
 for rep in range(3):
     T["fill"] = T["parse"] = 0.0
-    t0 = time.perf_counter(); n = 0; tc = 0.0
+    t0 = time.perf_counter(); n = 0; tc = 0.0; tm = 0.0; total = None
     for ch in bnp.open(path).read_chunks(min_chunk_size=chunk):
         a = time.perf_counter(); c = bnp.sequence.count_kmers(ch.sequence, 31); torch.cuda.synchronize(); tc += time.perf_counter() - a; n += 1
+        a = time.perf_counter(); total = c if total is None else total + c; torch.cuda.synchronize(); tm += time.perf_counter() - a
     dt = time.perf_counter() - t0
-    print("total %.1f ms (%d chunks): file fill %.1f ms (background thread when read-ahead), parse (upload + scan) %.1f ms, count %.1f ms -> %.2f GB/s" % (dt * 1e3, n, T["fill"] * 1e3, T["parse"] * 1e3, tc * 1e3, os.path.getsize(path) / dt / 1e9), flush=True)
+    print("total %.1f ms (%d chunks): file fill %.1f ms (background thread when read-ahead), parse (upload + scan) %.1f ms, count %.1f ms, merge %.1f ms -> %.2f GB/s, %.2f Gbases/s" % (dt * 1e3, n, T["fill"] * 1e3, T["parse"] * 1e3, tc * 1e3, tm * 1e3, os.path.getsize(path) / dt / 1e9, n_file * 150 / dt / 1e9), flush=True)
 os.remove(path)

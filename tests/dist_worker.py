@@ -35,9 +35,11 @@ def main():
     res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
     codes = oracle.encode_dna(oracle.gather_rows(text, res.field_starts[:, 1], res.field_lens[:, 1]))
     mine, _ = oracle.get_kmers(codes, res.field_lens[:, 1], 31)
-    for plan in ("keys", "counts"):
-        keys, counts = parallel.count_sparse_distributed(HArray(host=mine.copy()), 62, plan=plan)
-        out[plan] = (keys.host().copy(), counts.host().copy())
+    # ("keys" with the exchange in one step, and cut into 3 and — the default — 4 steps that overlap with the counting)
+    for plan, groups in (("keys", None), ("counts", None), ("keys", 1), ("keys", 3)):
+        keys, counts = parallel.count_sparse_distributed(HArray(host=mine.copy()), 62, plan=plan, groups=groups)
+        assert parallel.last["plan"] == plan and (plan == "counts" or parallel.last["groups"] == (groups or parallel.KEY_GROUPS))
+        out[plan if groups is None else "keys/%d" % groups] = (keys.host().copy(), counts.host().copy())
     assert parallel.collectives().name == "torch.distributed"
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
@@ -60,7 +62,7 @@ def main():
                 for a, b in zip(bounds[:-1], bounds[1:]):
                     assert a.size == 0 or b.size == 0 or a[-1] < b[0], "rank ranges overlap"
                 if k == 31:
-                    for plan in ("keys", "counts"):
+                    for plan in ("keys", "counts", "keys/1", "keys/3"):
                         assert np.array_equal(np.concatenate([gathered[r][plan][0] for r in range(world)]), ek), plan
                         assert np.array_equal(np.concatenate([gathered[r][plan][1] for r in range(world)]), ec), plan
         print("DIST_OK")

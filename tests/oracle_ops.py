@@ -314,9 +314,17 @@ class OracleOps:
                                  minlength=n_bins).astype(w.dtype)
         return _h(out.reshape(-1))
 
-    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0):
+    def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0, dest=None):
         k, c = oracle.count_sparse(values.host())
+        if dest is not None:                             # (keys, counts, pos): written in place, views returned
+            ok, oc, pos = dest[0].host(), dest[1].host(), int(dest[2])
+            assert pos + values.size <= ok.size
+            ok[pos:pos + k.size], oc[pos:pos + k.size] = k, c
+            return _h(ok[pos:pos + k.size]), _h(oc[pos:pos + k.size])
         return _h(k), _h(c)
+
+    def empty_i64(self, n):
+        return _h(np.zeros(n, dtype=np.int64))
 
     def reduce_by_key(self, keys, weights, key_bits=62):
         if not isinstance(keys, (list, tuple)):

@@ -1,5 +1,5 @@
 """-m gpu: the multi-GPU entry points of the C-ABI (include/bnpk.h: bnpk_comm_*, bnpk_allreduce_hist, bnpk_exchange_counts,
-bnpk_exchange_by_key_range) on what one GPU can run — a communicator of ONE rank (RCCL is loaded, the communicator is
+bnpk_exchange_by_key_range, bnpk_exchange_slices) on what one GPU can run — a communicator of ONE rank (RCCL is loaded, the communicator is
 made, every collective goes through RCCL's grouped send/recv or all-reduce and comes back with this rank's own data) —
 and the two plans of the sparse merge played by one GPU for N ranks (parallel.count_sparse_virtual) against the
 unsharded histogram.  N > 1 processes: tests/test_parallel.py (gloo, CPU)."""
@@ -49,6 +49,14 @@ def test_one_rank_communicator_through_the_abi(env):
                                               recv_counts.ctypes.data_as(C.c_void_p), dev.stream()) == 0
         torch.cuda.synchronize()
         assert torch.equal(recv, keys)
+        # the same step with the slice at an offset of its own (one of several steps of the grouped exchange)
+        off = np.array([23_456], dtype=np.int64)
+        part_counts = np.array([50_001], dtype=np.int64)
+        recv.zero_()
+        assert lib.bnpk_exchange_slices(dev.ctx, comm, ptr(keys), off.ctypes.data_as(C.c_void_p), part_counts.ctypes.data_as(C.c_void_p),
+                                        ptr(recv), part_counts.ctypes.data_as(C.c_void_p), dev.stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(recv[:50_001], keys[23_456:23_456 + 50_001]) and not bool(recv[50_001:].any())
         # what cannot be right is refused before RCCL sees it
         bad = np.array([5], dtype=np.int64)
         assert lib.bnpk_exchange_by_key_range(dev.ctx, comm, ptr(keys), send_counts.ctypes.data_as(C.c_void_p), ptr(recv),
@@ -71,8 +79,9 @@ def test_both_plans_of_the_sparse_merge_on_virtual_ranks(mode, genome_len, expec
     texts = [ops.synth_fastq(per, read_len, seed, mode, genome_len, r * per) for r in range(world)]
     whole = ops.synth_fastq(world * per, read_len, seed, mode, genome_len, 0)
     (ek, ec), st = fastq_kmer_histogram(whole, k)
-    for plan in ("auto", "keys", "counts"):
-        hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True)
+    # ("keys": the exchange in one step, and cut into steps whose pieces land back to back in one pair of arrays)
+    for plan, groups in (("auto", None), ("keys", None), ("counts", None), ("keys", 1), ("keys", 7)):
+        hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True, groups=groups)
         assert chosen == (expect_plan if plan == "auto" else plan)
         keys = ops.concat([h[0] for h in hists])
         counts = ops.concat([h[1] for h in hists])

@@ -25,6 +25,22 @@ def test_bucket_ownership_is_contiguous_and_balanced():
         assert sizes.max() - sizes.min() <= 1
 
 
+def test_key_groups_cut_every_range_into_consecutive_parts():
+    import numpy as np
+    from bionumpy_amd import parallel
+    for world in (1, 2, 3, 8):
+        owner = parallel.rank_of_bucket(world)
+        for groups in (1, 3, 4, 7, 40):
+            b = parallel.key_groups(world, groups)
+            assert b.shape == (world, groups + 1) and np.all(np.diff(b, axis=1) >= 0)
+            for q in range(world):
+                mine = np.flatnonzero(owner == q)
+                assert b[q, 0] == mine[0] and b[q, -1] == mine[-1] + 1
+                sizes = np.diff(b[q])
+                assert sizes.max() - sizes.min() <= 1
+            assert np.all(b[1:, 0] == b[:-1, -1])                # the ranks' ranges follow each other
+
+
 def test_virtual_ranks_on_the_host_logic():
     """pipeline.fastq_kmer_histogram_virtual_ranks with the oracle-backed ops: shard -> partition by send cuts -> the
     exchange's result -> per-range counts == np.unique over all reads"""
@@ -43,8 +59,8 @@ def test_virtual_ranks_on_the_host_logic():
         codes = synth.read_codes(world * per, read_len, 9, 1, 7000, 0)
         h, _ = oracle.get_kmers(codes.reshape(-1), np.full(world * per, read_len, dtype=np.int64), k)
         ek, ec = oracle.count_sparse(h)
-        for plan in ("keys", "counts", "auto"):
-            hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True)
+        for plan, groups in (("keys", None), ("counts", None), ("keys", 1), ("keys", 5), ("auto", None)):
+            hists, stats, received, chosen = fastq_kmer_histogram_virtual_ranks(texts, k, plan=plan, with_plan=True, groups=groups)
             assert np.array_equal(np.concatenate([a.host() for a, _ in hists]), ek), plan
             assert np.array_equal(np.concatenate([c.host() for _, c in hists]), ec), plan
             if chosen == "keys":
