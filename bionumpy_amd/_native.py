@@ -63,6 +63,7 @@ SIGNATURES = {
     "bnpk_host_free": (_int, [_p]),
     "bnpk_copy_h2d_async": (_int, [_p, _p, C.c_size_t, _p]),
     "bnpk_copy_d2h_async": (_int, [_p, _p, C.c_size_t, _p]),
+    "bnpk_pread_parallel": (_int, [_p, _int, _i64, _p, _i64, _int, _i64, _p, _p, C.POINTER(_i64)]),
     "bnpk_stream_sync": (_int, [_p]),
     "bnpk_scan_tiles": (_i64, [_i64]),
     "bnpk_byte_census": (_int, [_p, _p, _i64, _u8, _p, _p]),

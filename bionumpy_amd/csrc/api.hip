@@ -1,4 +1,10 @@
 // Context, diagnostics, host staging and per-kernel timers of the bnpk C-ABI (include/bnpk.h).
+#include <errno.h>
+#include <unistd.h>
+
+#include <thread>
+#include <vector>
+
 #include "common.h"
 
 extern "C" {
@@ -143,6 +149,57 @@ int bnpk_copy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stre
   if (!d_dst || !h_src) return BNPK_ERR_ARG;
   if (hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
     return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+// A plain file (page cache or disk) into a page-locked buffer by `n_threads` threads, each with a slice of its own, and on
+// to the device piece by piece while the rest is still being read — the Python reader did this with a thread pool and spent
+// its time on the interpreter lock once the threads also had copies to start.
+int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst, int64_t bytes, int n_threads, int64_t piece_bytes,
+                        void* d_dst, void* stream, int64_t* h_read) {
+  if (fd < 0 || file_offset < 0 || bytes < 0 || n_threads < 1 || piece_bytes < 1 || !h_read || (bytes > 0 && !h_dst)) return BNPK_ERR_ARG;
+  if (d_dst && !ctx) return BNPK_ERR_ARG;
+  *h_read = 0;
+  if (bytes == 0) return BNPK_OK;
+  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, bytes / piece_bytes));
+  const int64_t step = ceil_div(ceil_div(bytes, (int64_t)n_threads), (int64_t)4096) * 4096;      // page-aligned slices
+  std::vector<int64_t> got(n_threads, 0);
+  std::vector<int> status(n_threads, BNPK_OK);
+  auto work = [&](int t) {
+    if (d_dst && hipSetDevice(ctx->device) != hipSuccess) { status[t] = BNPK_ERR_HIP; return; }
+    int64_t a = (int64_t)t * step;
+    const int64_t b = std::min(a + step, bytes);
+    while (a < b) {
+      const int64_t e = std::min(b, a + piece_bytes);
+      int64_t at = a;
+      while (at < e) {
+        const ssize_t n = pread(fd, (char*)h_dst + at, (size_t)(e - at), (off_t)(file_offset + at));
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) break;                                   // error, or the file ends here
+        at += n;
+      }
+      if (at > a && d_dst &&
+          hipMemcpyAsync((char*)d_dst + a, (const char*)h_dst + a, (size_t)(at - a), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        status[t] = BNPK_ERR_HIP;
+        return;
+      }
+      got[t] += at - a;
+      if (at < e) return;                                    // short: nothing behind it is read
+      a = e;
+    }
+  };
+  std::vector<std::thread> threads;
+  for (int t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+  work(0);
+  for (auto& th : threads) th.join();
+  // the bytes read are the contiguous prefix: a short slice ends the count
+  int64_t total = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    if (status[t] != BNPK_OK) return status[t];
+    total += got[t];
+    if (got[t] < std::min(step, bytes - (int64_t)t * step)) break;
+  }
+  *h_read = total;
   return BNPK_OK;
 }
 

@@ -3,6 +3,7 @@ import gzip
 from pathlib import PurePath
 
 from .buffers import FastQBuffer, MultiLineFastaBuffer, TwoLineFastaBuffer  # noqa: F401
+from .gzip_reading import open_gzip_for_reading
 from .npdataclassreader import NpDataclassReader
 from .parser import NumpyFileReader
 
@@ -41,7 +42,7 @@ def bnp_open(filename, mode=None, buffer_type=None, lazy=None):
         buffer_type = _get_buffer_type(suffix)
     if mode in ("w", "write", "wb", "a", "append", "ab"):
         return NpBufferedWriter(open_func(filename, "ab" if mode in ("a", "append", "ab") else "wb"), buffer_type)
-    file_reader = NumpyFileReader(open_func(filename, "rb"), buffer_type)
+    file_reader = NumpyFileReader(open_gzip_for_reading(filename) if is_gzip else open(filename, "rb"), buffer_type)
     if is_gzip:
         file_reader.set_prepend_mode()
     return NpDataclassReader(file_reader, lazy=lazy)
@@ -90,7 +91,7 @@ def count_entries(filename, buffer_type=None):
     open_func = gzip.open if is_gzip else open
     if buffer_type is None:
         buffer_type = _get_buffer_type(suffix)
-    file_reader = NumpyFileReader(open_func(filename, "rb"), buffer_type)
+    file_reader = NumpyFileReader(open_gzip_for_reading(filename) if is_gzip else open(filename, "rb"), buffer_type)
     if is_gzip:
         file_reader.set_prepend_mode()
     return sum(chunk.count_entries() for chunk in file_reader.read_chunks(min_chunk_size=500000))

@@ -1,0 +1,226 @@
+"""Reading ``.gz`` input without leaving the device idle behind one host thread of ``gzip`` (the reference prefers
+``isal.igzip`` where it is installed and falls back to ``gzip``: bionumpy/io/gzip_reading.py:1-4; neither isal nor a
+faster zlib is available here, so the time has to come from doing the inflate elsewhere than in the caller's thread).
+
+* **BGZF** (``bgzip``: a gzip file made of members of at most 64 KiB, each carrying its compressed size in a ``BC`` extra
+  field — what sequencing pipelines write): the members are cut apart by their headers and inflated by a pool of threads
+  (``zlib`` releases the interpreter lock), a few megabytes ahead of the reader, in order.
+* any other gzip stream (one member or several): one background thread inflates ahead of the reader, so the inflate of
+  the next batch runs while the caller uploads, scans and counts the current one.
+
+Both are file-like objects with ``readinto`` / ``read`` / ``close`` / ``name``; ``NumpyFileReader`` treats them as
+streams (``set_prepend_mode``), exactly like a ``gzip.GzipFile``.
+"""
+import collections
+import struct
+import threading
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+_GROUP_BYTES = 1 << 20          # compressed bytes of BGZF members handed to one pool task
+_AHEAD_TASKS = 48               # tasks in flight (~100-150 MB of text ahead of the reader at usual ratios)
+_STREAM_PIECE = 1 << 20         # compressed bytes fed to the single-stream inflater at a time
+_STREAM_AHEAD = 64              # inflated pieces the background thread may be ahead
+
+
+def _bgzf_block_size(header):
+    """total size of the BGZF member that starts with ``header`` (>= 18 bytes), or None if it is not a BGZF member"""
+    if len(header) < 18 or header[:4] != b"\x1f\x8b\x08\x04":
+        return None
+    xlen = struct.unpack_from("<H", header, 10)[0]
+    pos, end = 12, 12 + xlen
+    if end > len(header):
+        return None
+    while pos + 4 <= end:
+        si1, si2, slen = header[pos], header[pos + 1], struct.unpack_from("<H", header, pos + 2)[0]
+        if si1 == 66 and si2 == 67 and slen == 2:
+            return struct.unpack_from("<H", header, pos + 4)[0] + 1
+        pos += 4 + slen
+    return None
+
+
+def _inflate_members(blob):
+    """the text of whole BGZF members laid end to end in ``blob``"""
+    out, pos, n = [], 0, len(blob)
+    while pos < n:
+        size = _bgzf_block_size(blob[pos:pos + 64])
+        xlen = struct.unpack_from("<H", blob, pos + 10)[0]
+        out.append(zlib.decompress(blob[pos + 12 + xlen:pos + size - 8], wbits=-15))
+        pos += size
+    return b"".join(out)
+
+
+class _AheadReader:
+    """readinto/read over a sequence of byte strings produced ahead of the reader (``_next_piece`` -> bytes, b"" at the end)"""
+
+    def __init__(self, name):
+        self.name = name
+        self._cur, self._at = b"", 0
+        self._done = False
+
+    def readinto(self, target):
+        view = memoryview(target).cast("B")
+        got = 0
+        while got < len(view):
+            if self._at == len(self._cur):
+                if self._done:
+                    break
+                self._cur, self._at = self._next_piece(), 0
+                if not self._cur:
+                    self._done = True
+                    break
+            n = min(len(view) - got, len(self._cur) - self._at)
+            view[got:got + n] = self._cur[self._at:self._at + n]
+            got += n
+            self._at += n
+        return got
+
+    def read(self, n=-1):
+        if n is None or n < 0:
+            parts = [self._cur[self._at:]]
+            self._cur, self._at = b"", 0
+            while not self._done:
+                piece = self._next_piece()
+                if not piece:
+                    self._done = True
+                    break
+                parts.append(piece)
+            return b"".join(parts)
+        buf = bytearray(n)
+        return bytes(buf[:self.readinto(buf)])
+
+    def readable(self):
+        return True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *args):
+        self.close()
+
+
+class BgzfReader(_AheadReader):
+    """BGZF members inflated by a pool of threads, in order, a bounded number of tasks ahead of the reader"""
+
+    def __init__(self, raw, name, n_threads):
+        super().__init__(name)
+        self._raw = raw
+        self._pool = ThreadPoolExecutor(max_workers=max(1, n_threads), thread_name_prefix="bnpk-inflate")
+        self._tasks = collections.deque()
+        self._pending = b""
+        self._raw_done = False
+        self._fill_tasks()
+
+    def _fill_tasks(self):
+        while not self._raw_done and len(self._tasks) < _AHEAD_TASKS:
+            data = self._pending + self._raw.read(_GROUP_BYTES)
+            if not data:
+                self._raw_done = True
+                break
+            pos, n = 0, len(data)                           # whole members only; what is left over starts the next task
+            while pos + 18 <= n:
+                size = _bgzf_block_size(data[pos:pos + 64])
+                if size is None:
+                    raise OSError("%s: not a BGZF member at a member boundary (a plain gzip member inside a BGZF file?)" % self.name)
+                if pos + size > n:
+                    break
+                pos += size
+            if pos == 0:
+                more = self._raw.read(1 << 16)
+                if not more:
+                    raise EOFError("%s: truncated BGZF member at the end of the file" % self.name)
+                self._pending = data + more
+                continue
+            self._pending = data[pos:]
+            self._tasks.append(self._pool.submit(_inflate_members, data[:pos]))
+
+    def _next_piece(self):
+        while True:
+            if not self._tasks:
+                self._fill_tasks()
+                if not self._tasks:
+                    if self._pending:
+                        raise EOFError("%s: truncated BGZF member at the end of the file" % self.name)
+                    return b""
+            piece = self._tasks.popleft().result()
+            self._fill_tasks()
+            if piece:                                       # (the empty end-of-file member of bgzip inflates to nothing)
+                return piece
+
+    def close(self):
+        for t in self._tasks:
+            t.cancel()
+        self._pool.shutdown(wait=True)
+        self._raw.close()
+
+
+class AheadGzipReader(_AheadReader):
+    """a gzip stream (one member or several, any member size) inflated by ONE background thread ahead of the reader"""
+
+    def __init__(self, raw, name):
+        super().__init__(name)
+        self._raw = raw
+        self._queue = collections.deque()
+        self._cv = threading.Condition()
+        self._stop = False
+        self._thread = threading.Thread(target=self._work, name="bnpk-inflate", daemon=True)
+        self._thread.start()
+
+    def _put(self, item):
+        with self._cv:
+            while len(self._queue) >= _STREAM_AHEAD and not self._stop:
+                self._cv.wait()
+            self._queue.append(item)
+            self._cv.notify_all()
+
+    def _work(self):
+        try:
+            inflater = zlib.decompressobj(wbits=31)
+            started = False
+            while not self._stop:
+                data = self._raw.read(_STREAM_PIECE)
+                if not data:
+                    if started and not inflater.eof:
+                        raise EOFError("%s: compressed file ended before the end-of-stream marker was reached" % self.name)
+                    break
+                while data and not self._stop:
+                    if inflater.eof:                         # the next member of a multi-member file
+                        inflater = zlib.decompressobj(wbits=31)
+                    started = True
+                    text = inflater.decompress(data)
+                    data = inflater.unused_data if inflater.eof else b""
+                    if data and not data.strip(b"\x00"):    # (zero padding behind the last member, as gzip tolerates)
+                        data = b""
+                    if text:
+                        self._put(text)
+            self._put(b"")
+        except BaseException as e:                           # noqa: BLE001  (re-raised in the reader's thread)
+            self._put(e)
+
+    def _next_piece(self):
+        with self._cv:
+            while not self._queue:
+                self._cv.wait()
+            item = self._queue.popleft()
+            self._cv.notify_all()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._queue.clear()
+            self._cv.notify_all()
+        self._thread.join()
+        self._raw.close()
+
+
+def open_gzip_for_reading(filename, n_threads=8):
+    """``gzip.open(filename, "rb")`` for the chunk reader: BGZF -> thread pool, anything else -> one thread ahead"""
+    raw = open(filename, "rb")
+    head = raw.read(64)
+    raw.seek(0)
+    if _bgzf_block_size(head) is not None:
+        return BgzfReader(raw, filename, n_threads)
+    return AheadGzipReader(raw, filename)

@@ -15,6 +15,11 @@ gigabytes going to a device, not for 5 MB numpy chunks:
   bytes while the current batch is uploaded, scanned and worked on by the caller (they are read before the current
   batch's left-over is known, so such a batch is its left-over plus ``min_chunk_size`` new bytes; smaller batches keep
   the reference's window arithmetic exactly);
+* on the GPU that background thread also starts the upload: as soon as the new bytes are in their page-locked buffer they
+  go to a device staging buffer with ``hipMemcpyAsync`` on a copy stream, while the caller is still working on the batch
+  before (the copy of a 256 MB batch takes as long as counting its k-mers: one after the other they were half of a
+  file-to-histogram run).  When the caller takes the batch, the left-over in front of it and the end-of-file bytes behind
+  it are a few kilobytes more, and the batch is put together on the device;
 * nothing is ever seeked back or re-read, for plain files and gzip streams alike: the bytes behind the last complete
   entry (less than one entry) are carried over, by offset, to the front of the other staging buffer;
 * whether a batch holds a complete entry, and where its last one ends, is decided by the device scan of the buffer
@@ -24,7 +29,6 @@ gigabytes going to a device, not for 5 MB numpy chunks:
 import io
 import os
 import threading
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -36,6 +40,8 @@ _BIG = 32 << 20                    # batches from this size on: parallel file re
 _READ_THREADS = int(os.environ.get("BNPK_READ_THREADS", min(16, os.cpu_count() or 1)))    # 1 = the calling thread only
 _READ_AHEAD = os.environ.get("BNPK_READ_AHEAD", "1") != "0"
 _FRONT = 4 << 20                   # room kept in front of a read-ahead for the bytes left over by the batch before it
+_EARLY_UPLOAD = os.environ.get("BNPK_EARLY_UPLOAD", "1") != "0"     # the read-ahead thread starts the batch's upload too
+_PIECE = int(os.environ.get("BNPK_PIECE_MB", 16)) << 20                   # ... piece by piece, while the reading threads are still at work
 
 
 class _Staging:
@@ -59,6 +65,83 @@ class _Staging:
             self._pool.release()
 
 
+class _EarlyUpload:
+    """Device staging for the read-ahead: two HBM buffers that take turns, a copy stream, and the events that order the
+    background thread's ``hipMemcpyAsync`` into a buffer behind the caller's copy out of it two batches earlier."""
+
+    def __init__(self):
+        import torch
+        from ..device import Device
+        from .._native import lib, check
+        self.torch, self.dev, self.lib, self.check = torch, Device.get(), lib, check
+        self.stream = torch.cuda.Stream(self.dev.tdev)
+        self.buffers, self.free_events, self.turn = [None, None], [None, None], 0
+
+    def take(self, nbytes):
+        """(caller's thread) the next staging buffer in turn, at least nbytes large -> its index"""
+        i = self.turn
+        self.turn ^= 1
+        if self.buffers[i] is None or self.buffers[i].numel() < nbytes:
+            self.buffers[i] = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.dev.tdev)
+            ev = self.torch.cuda.Event()
+            ev.record(self.torch.cuda.current_stream(self.dev.tdev))     # (the allocation's stream)
+            self.free_events[i] = ev
+        return i
+
+    def begin(self, i):
+        """(background thread, before the first upload of a batch) the copy stream waits until the caller's copy out of
+        buffer i, two batches ago, is done"""
+        self.torch.cuda.set_device(self.dev.tdev)
+        if self.free_events[i] is not None:
+            self.stream.wait_event(self.free_events[i])
+
+    def target(self, i, offset):
+        """(device pointer of buffers[i][offset:], copy stream) for bnpk_pread_parallel"""
+        import ctypes as C
+        return C.c_void_p(self.buffers[i].data_ptr() + offset), C.c_void_p(self.stream.cuda_stream)
+
+    def upload(self, i, host, offset):
+        """(background thread) host[:] -> buffers[i][offset:], asynchronously on the copy stream"""
+        import ctypes as C
+        dst = C.c_void_p(self.buffers[i].data_ptr() + offset)
+        src = C.c_void_p(host.__array_interface__["data"][0])
+        self.check(self.lib.bnpk_copy_h2d_async(dst, src, host.size, C.c_void_p(self.stream.cuda_stream)))
+
+    def finish(self, i, owner):
+        """(background thread, after the last upload of a batch) -> the event behind the copies"""
+        import ctypes as C
+        if owner is not None:
+            owner.in_flight, owner.stream = True, C.c_void_p(self.stream.cuda_stream)
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def assemble(self, i, event, room, first, n, front, got):
+        """(caller's thread) the batch room[first:n] as one fresh device array: the new bytes room[front:front + got] are
+        in buffers[i] already, what lies in front of and behind them (left-over, end-of-file bytes) comes from the host"""
+        import ctypes as C
+        from ..device import HArray
+        from .pinned import owner_of
+        torch, lib = self.torch, self.lib
+        cur = torch.cuda.current_stream(self.dev.tdev)
+        t = torch.empty(n - first, dtype=torch.uint8, device=self.dev.tdev)
+        cur.wait_event(event)
+        head = front - first
+        t[head:head + got].copy_(self.buffers[i][front:front + got])
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.free_events[i] = ev
+        handle = C.c_void_p(cur.cuda_stream)
+        base = room.__array_interface__["data"][0]
+        for a, b in ((first, front), (front + got, n)):
+            if b > a:
+                self.check(lib.bnpk_copy_h2d_async(C.c_void_p(t.data_ptr() + (a - first)), C.c_void_p(base + a), b - a, handle))
+        owner = owner_of(room)
+        if owner is not None:
+            owner.in_flight, owner.stream = True, handle                # (the reader syncs this stream before it reuses the room)
+        return HArray(dev=t)
+
+
 class NumpyFileReader:
     def __init__(self, file_obj, buffer_type, has_header=False):
         self._file_obj = file_obj
@@ -72,6 +155,7 @@ class NumpyFileReader:
         self._stream_mode = False          # gzip: every batch takes min_chunk_size NEW bytes (parser.py:164-165)
         self._left_over = None             # bytes behind the last complete entry of the previous batch (a staging view)
         self._staging = None
+        self._early = None                 # device side of the read-ahead (_EarlyUpload)
         self._ahead_thread = None
         self.n_bytes_read = 0
         self.n_lines_read = 0
@@ -94,6 +178,9 @@ class NumpyFileReader:
             self._ahead_thread.join()
             self._ahead_thread = None
         self._file_obj.close()
+        if self._early is not None:                          # nothing may still be copying into its buffers when they go
+            self._early.stream.synchronize()
+            self._early = None
         if self._staging is not None:
             self._staging.release()
             self._staging = None
@@ -135,15 +222,35 @@ class NumpyFileReader:
         if self._staging is None:
             self._staging = _Staging()
 
+        early = None
+        if _EARLY_UPLOAD and not getattr(get_ops(), "host_only", False):
+            if self._early is None:
+                self._early = _EarlyUpload()
+            early = self._early
+
         def start():
             # the staging buffer is taken here, by the caller's thread: making sure that no copy out of it is in flight
             # means waiting for the stream, and the background thread would wait behind the upload of the current batch
             room = self._staging.room(_FRONT + min_chunk_size + 2)
+            slot = early.take(_FRONT + min_chunk_size + 2) if early is not None else None
             box = {}
 
             def work():
                 try:
-                    box["result"] = (room, self._fill(room[_FRONT:_FRONT + min_chunk_size]))
+                    new = room[_FRONT:_FRONT + min_chunk_size]
+                    if early is None:
+                        got = self._fill(new)
+                    else:
+                        early.begin(slot)
+                        got = self._fill(new, early.target(slot, _FRONT))
+                        if got < 0:                                          # the reading threads sent the pieces themselves
+                            got = -got
+                        elif got > 0:                                        # (a serial read: one copy behind it)
+                            early.upload(slot, new[:got], _FRONT)
+                        if got > 0:
+                            from .pinned import owner_of
+                            box["uploaded"] = (slot, early.finish(slot, owner_of(room)))
+                    box["result"] = (room, got)
                 except BaseException as e:                   # noqa: BLE001  (re-raised where the bytes are taken)
                     box["error"] = e
             box["thread"] = threading.Thread(target=work, name="bnpk-read-ahead", daemon=True)
@@ -164,6 +271,7 @@ class NumpyFileReader:
         try:
             while not self._is_finished:
                 room, got = take(ahead)
+                uploaded = ahead.get("uploaded")
                 ahead = None
                 self._is_finished = got < min_chunk_size
                 if got == 0 and held.size == 0:
@@ -178,7 +286,7 @@ class NumpyFileReader:
                     big = np.empty(held.size + got + 2, dtype=np.uint8)
                     big[:held.size] = held
                     big[held.size:held.size + got] = room[_FRONT:_FRONT + got]
-                    room, first, n = big, 0, held.size + got
+                    room, first, n, uploaded = big, 0, held.size + got, None
                 if self._is_finished:
                     n = self._terminate(room, n)
                 batch = room[first:n]
@@ -186,7 +294,9 @@ class NumpyFileReader:
                     ahead = start()                          # the next batch's bytes, while this one is parsed and used
                 if max_chunk_size is not None and batch.size > max_chunk_size:
                     raise Exception("No complete entry found")
-                buff = self._parse(batch)
+                on_device = early.assemble(uploaded[0], uploaded[1], room, first, n, _FRONT, got) if uploaded is not None else None
+                buff = self._parse(batch if on_device is None else on_device)
+                del on_device
                 if buff is None:                             # no complete entry yet: the whole batch is carried over
                     held = batch
                     continue
@@ -257,9 +367,11 @@ class NumpyFileReader:
             n = self._terminate(room, n)
         return room[:n], got
 
-    def _fill_parallel(self, target):
-        """a plain file on disk / in the page cache: ``os.preadv`` of disjoint slices from a few threads straight into the
-        (page-locked) target.  Returns None when this is not a big read of a plain seekable file (the serial path)."""
+    def _fill_parallel(self, target, upload=None):
+        """a plain file on disk / in the page cache: disjoint slices read by a few threads straight into the (page-locked)
+        target (bnpk_pread_parallel: native threads, no interpreter lock between them; with ``upload`` = (device pointer,
+        stream) every piece goes on to the device as soon as it is read).  Returns None when this is not a big read of a
+        plain seekable file (the serial path)."""
         if _READ_THREADS < 2 or target.size < _BIG or self._stream_mode or not self._plain_file():
             return None
         f = self._file_obj
@@ -267,27 +379,28 @@ class NumpyFileReader:
         want = min(target.size, os.fstat(fd).st_size - pos)
         if want <= 0:
             return 0
-        view = memoryview(target)
-        n_threads = max(1, min(_READ_THREADS, want // (_BIG // 4)))
-        step = -(-want // n_threads)
-
-        def read_slice(i):
-            a, b = i * step, min((i + 1) * step, want)
-            while a < b:
-                n = os.preadv(fd, [view[a:b]], pos + a)
-                if n <= 0:
-                    raise OSError("short read of %s" % self._f_name)
-                a += n
-        with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            list(pool.map(read_slice, range(n_threads)))
+        import ctypes as C
+        from .._native import lib, check
+        ctx = None
+        if upload is not None:
+            from ..device import Device
+            ctx = Device.get().ctx
+        got = C.c_int64(0)
+        d_dst, stream = upload if upload is not None else (None, None)
+        check(lib.bnpk_pread_parallel(ctx, fd, pos, C.c_void_p(target.__array_interface__["data"][0]), want,
+                                      _READ_THREADS, _PIECE, d_dst, stream, C.byref(got)))
+        if got.value < want:
+            raise OSError("short read of %s" % self._f_name)
         f.seek(pos + want)
         return want
 
-    def _fill(self, target):
-        """file.readinto(target) until it is full or the file ends (buffered / gzip readers return short reads)"""
-        got = self._fill_parallel(target)
+    def _fill(self, target, upload=None):
+        """file.readinto(target) until it is full or the file ends (buffered / gzip readers return short reads).
+        upload: (device pointer, stream) — a big read of a plain file sends its pieces there as they arrive and returns
+        -got instead of got (a negative count: "these bytes are on their way already")"""
+        got = self._fill_parallel(target, upload)
         if got is not None:
-            return got
+            return -got if upload is not None else got
         if not hasattr(self._file_obj, "readinto"):
             raw = self._file_obj.read(target.size)
             target[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)

@@ -124,6 +124,13 @@ int bnpk_host_alloc(size_t bytes, void** h_out);
 int bnpk_host_free(void* h_ptr);
 int bnpk_copy_h2d_async(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream);
+/* file.readinto(buffer) of a plain file for batches of hundreds of megabytes (bionumpy/io/parser.py:203-206): `bytes` bytes
+ * from `file_offset` of the open file `fd` into the page-locked h_dst by n_threads threads (pread of disjoint slices, in
+ * pieces of piece_bytes); with d_dst != NULL every piece also goes on to d_dst + its offset with hipMemcpyAsync on
+ * `stream` as soon as it is read, so the upload runs while the rest is still being read.  *h_read = bytes read (less than
+ * `bytes` only at the end of the file).  Synchronous for the reads, asynchronous for the copies. */
+int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst, int64_t bytes, int n_threads, int64_t piece_bytes,
+                        void* d_dst, void* stream, int64_t* h_read);
 int bnpk_stream_sync(void* stream);
 
 /* ---- A2: newline scan ------------------------------------------------------------------

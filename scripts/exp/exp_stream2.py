@@ -11,8 +11,8 @@ path = "/tmp/bnpk_stream_test.fq"
 synth.fastq_bytes(n_file, 150, 7, 1, 5_000_000).tofile(path)
 T = {"fill": 0.0, "parse": 0.0}
 orig_fill, orig_parse = parser.NumpyFileReader._fill, parser.NumpyFileReader._parse
-def fill(self, target):
-    t = time.perf_counter(); r = orig_fill(self, target); T["fill"] += time.perf_counter() - t; return r
+def fill(self, target, upload=None):
+    t = time.perf_counter(); r = orig_fill(self, target, upload); T["fill"] += time.perf_counter() - t; return r
 def parse(self, batch):
     t = time.perf_counter(); r = orig_parse(self, batch); torch.cuda.synchronize(); T["parse"] += time.perf_counter() - t; return r
 parser.NumpyFileReader._fill, parser.NumpyFileReader._parse = fill, parse
