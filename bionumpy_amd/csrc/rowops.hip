@@ -300,9 +300,7 @@ int bnpk_mask_fill(bnpk_ctx* ctx, uint8_t* d_mask, int64_t n, int64_t start, int
 namespace {
 
 constexpr int JL_MAX_LINES = 4;
-constexpr int JL_BYTES_PER_LANE = 16;
-constexpr int JL_CHUNKS = 4;                            // chunks of 16 bytes per lane: the staging is paid once per 16 KiB
-constexpr int64_t JL_TILE = (int64_t)BNPK_BLOCK * JL_BYTES_PER_LANE * JL_CHUNKS;
+constexpr int64_t JL_TILE = 16384;                      // output bytes a workgroup puts together in LDS
 
 struct jl_line {
   const uint8_t* data;         // flat bytes of the field (nullptr: a one-byte constant line)
@@ -321,173 +319,221 @@ __device__ __forceinline__ int64_t jl_row_of(const int64_t* __restrict__ off, in
   return lo;
 }
 
-// The entries a workgroup's 4 KiB of output come from (a dozen for FASTQ records) are staged in LDS first — their offsets
-// and, per line, the offsets of their field rows — with coalesced loads: without that every lane walks a chain of up to
-// ten dependent global loads (binary search, entry bounds, two offsets per line) before it touches a byte, and the kernel
-// runs at the rate of that latency.  A lane whose sixteen bytes lie inside one field (17 in 20 for 150-base reads) takes
-// them with ONE unaligned 16-byte load; the others assemble theirs from spans of up to eight bytes.
-constexpr int JL_ROWS = 256;
+// The text of a tile of the output is put together in LDS and leaves as aligned 16-byte stores.  The unit of work is a
+// 16-byte WORD OF A FIELD: a lane loads it where it lies (one unaligned 16-byte load) and stores it where it belongs in
+// the tile (one unaligned 16-byte LDS store — gfx950 takes them, at a quarter of the aligned rate, which is still 16 bytes
+// per clock and CU: scripts/exp/ubench/lds_unaligned.hip); the last word of a field goes in pieces of 8, 4, 2, 1 bytes.
+// Which field a word belongs to is found without a search: one thread per entry writes a descriptor per line (source,
+// place in the tile, bytes left, number of words that overlap the tile) and the constant bytes (header byte, fill byte,
+// newlines); a scan over the word counts numbers the words; every descriptor marks its first word in an array over the
+// words, and a running maximum carries the mark to the words behind it.  Then all 256 lanes copy words, independently.
+// Rounds 1-2 worked the other way round — every lane owned sixteen OUTPUT bytes, found its entry by a binary search and
+// walked the lines to see where its bytes came from: ~1200 lane cycles per sixteen bytes, 31 ms for 50 M FASTQ records,
+// whatever was done to the loads; half a wavefront per entry (the first version of this kernel) was no faster: the
+// entries of a group went through their loads one after the other.
+constexpr int JL_RECS = 128;                            // entries described per pass (a FASTQ tile holds ~52)
+constexpr int JL_DESC = JL_RECS * JL_MAX_LINES;
+constexpr int JL_WORDS = 2048;                          // words numbered per pass (a FASTQ tile: ~1150)
+constexpr int JL_PER_LANE = JL_WORDS / BNPK_BLOCK;
 
 __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, int n_lines, uint8_t header,
                                                                 const int64_t* __restrict__ entry_off, int64_t n_rows,
                                                                 int64_t total, const int64_t* __restrict__ tile_rows,
                                                                 uint8_t* __restrict__ out) {
-  __shared__ int64_t s_ent[JL_ROWS + 1];
-  __shared__ int64_t s_off[JL_MAX_LINES][JL_ROWS + 1];
+  __shared__ __attribute__((aligned(16))) uint8_t tile[JL_TILE];
+  __shared__ int64_t d_src[JL_DESC];                           // first byte of the field's first word inside the tile
+  __shared__ int d_q[JL_DESC];                                 // where that word goes (may be up to 15 bytes before the tile)
+  __shared__ int d_left[JL_DESC];                              // bytes of the field from that word on (capped)
+  __shared__ int d_first[JL_DESC + 1];                         // words before the descriptor's first one
+  __shared__ unsigned short owner[JL_WORDS];
+  __shared__ int s_scan[BNPK_BLOCK / 64 + 1];
   const int64_t blk0 = (int64_t)blockIdx.x * JL_TILE;
   if (blk0 >= total) return;
+  const int tile_n = (int)min(JL_TILE, total - blk0);
   const int64_t lo = tile_rows[blockIdx.x];
   const int64_t hi = (blk0 + JL_TILE < total) ? tile_rows[blockIdx.x + 1] : n_rows - 1;
-  const bool staged = hi - lo + 1 <= JL_ROWS;
-  if (staged) {
-    const int n_stage = (int)(hi - lo + 1);
-    for (int i = threadIdx.x; i <= n_stage; i += BNPK_BLOCK) {
-      s_ent[i] = entry_off[lo + i];
-      for (int l = 0; l < n_lines; ++l)
-        if (lines.l[l].data) s_off[l][i] = lines.l[l].off[lo + i];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t field_end[JL_MAX_LINES];                             // sixteen bytes can be read at `at` iff at + 16 <= field_end
+#pragma unroll
+  for (int l = 0; l < JL_MAX_LINES; ++l) field_end[l] = (l < n_lines && lines.l[l].data) ? lines.l[l].off[n_rows] : 0;
+  const unsigned tile_base = (unsigned)(size_t)tile;           // (LDS addresses are 32-bit)
+  auto put = [&](int64_t q, uint8_t v) { if (q >= 0 && q < tile_n) tile[q] = v; };
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+  for (int64_t r0 = lo; r0 <= hi; r0 += JL_RECS) {
+    const int n_rec = (int)min((int64_t)JL_RECS, hi - r0 + 1);
+    const int n_desc = n_rec * n_lines;
+    // ---- one thread per entry: its constant bytes, a descriptor per line
+    int words_mine = 0;                                        // (of the descriptors this thread writes: summed below)
+    if (tid < n_rec) {
+      const int64_t r = r0 + tid;
+      int64_t o = entry_off[r] - blk0;                         // where the entry starts, relative to the tile (may lie before it)
+      for (int i = 0; i < n_lines; ++i) {
+        const jl_line& L = lines.l[i];
+        const int d = tid * n_lines + i;
+        if (L.prefix) { put(o, header); ++o; }
+        int64_t flen = 1;
+        int nw = 0;
+        if (!L.data) {
+          put(o, L.fill);
+        } else {
+          const int64_t fs = L.off[r];
+          flen = L.off[r + 1] - fs;
+          // the 16-byte words of the field that overlap the tile
+          const int64_t w_lo = o < 0 ? (-o) >> 4 : 0;
+          const int64_t w_hi = min((flen + 15) >> 4, ((int64_t)tile_n - o + 15) >> 4);
+          if (w_hi > w_lo) {
+            nw = (int)(w_hi - w_lo);
+            d_src[d] = fs + 16 * w_lo;
+            d_q[d] = (int)(o + 16 * w_lo);
+            d_left[d] = (int)min(flen - 16 * w_lo, (int64_t)1 << 30);
+          }
+        }
+        d_first[d] = nw;
+        words_mine += nw;
+        o += flen;
+        put(o, 10);
+        ++o;
+      }
+    }
+    __syncthreads();
+    // ---- number the words: exclusive scan of the counts (a thread scans the lines of its entry)
+    int before;
+    {
+      const int inc = (int)wave_inclusive_scan((unsigned)words_mine);
+      if (lane == 63) s_scan[wave] = inc;
+      __syncthreads();
+      int base = 0, all = 0;
+      for (int w = 0; w < BNPK_BLOCK / 64; ++w) { if (w < wave) base += s_scan[w]; all += s_scan[w]; }
+      before = base + inc - words_mine;
+      if (tid == 0) s_scan[BNPK_BLOCK / 64] = all;
+    }
+    if (tid < n_rec) {
+      for (int i = 0; i < n_lines; ++i) {
+        const int d = tid * n_lines + i, nw = d_first[d];
+        d_first[d] = before;
+        before += nw;
+      }
+    }
+    __syncthreads();
+    const int n_words = s_scan[BNPK_BLOCK / 64];
+    if (tid == 0) d_first[n_desc] = n_words;
+    // ---- the words, JL_WORDS at a time
+    for (int base = 0; base < n_words; base += JL_WORDS) {
+      for (int t = tid; t < JL_WORDS; t += BNPK_BLOCK) owner[t] = 0;
+      __syncthreads();
+      for (int d = tid; d < n_desc; d += BNPK_BLOCK) {           // a descriptor marks its first word of this pass
+        const int f = d_first[d], e = d_first[d + 1];
+        if (e > f && e > base && f < base + JL_WORDS) owner[max(f, base) - base] = (unsigned short)(d + 1);
+      }
+      __syncthreads();
+      // running maximum over the marks: a lane takes JL_PER_LANE consecutive words
+      unsigned mark[JL_PER_LANE], top = 0;
+#pragma unroll
+      for (int j = 0; j < JL_PER_LANE; ++j) { top = max(top, (unsigned)owner[tid * JL_PER_LANE + j]); mark[j] = top; }
+      unsigned run = top;                                      // inclusive maximum over the lanes of the wave ..
+#pragma unroll
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const unsigned other = (unsigned)__shfl_up((int)run, sh, 64);
+        if (lane >= sh) run = max(run, other);
+      }
+      if (lane == 63) s_scan[wave] = (int)run;
+      __syncthreads();
+      unsigned carry = (unsigned)__shfl_up((int)run, 1, 64);
+      if (lane == 0) carry = 0;
+      for (int w = 0; w < wave; ++w) carry = max(carry, (unsigned)s_scan[w]);   // .. and over the waves before
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JL_PER_LANE; ++j) owner[tid * JL_PER_LANE + j] = (unsigned short)max(mark[j], carry);
+      __syncthreads();
+      // every lane copies words: t = tid, tid + 256, ... (consecutive lanes, consecutive words of a field: coalesced)
+      const int n_here = min(JL_WORDS, n_words - base);
+      for (int t0 = 0; t0 < n_here; t0 += BNPK_BLOCK * 2) {
+        int dsc[2], m[2];
+        int64_t q[2];
+        uint64_t x[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                          // two independent words per lane in flight
+          const int t = t0 + u * BNPK_BLOCK + tid;
+          dsc[u] = -1;
+          if (t < n_here) {
+            const int d = (int)owner[t] - 1;
+            const int w = base + t - d_first[d];
+            const int64_t at = d_src[d] + 16 * (int64_t)w;
+            dsc[u] = d % n_lines;
+            m[u] = min(16, d_left[d] - 16 * w);
+            q[u] = (int64_t)d_q[d] + 16 * (int64_t)w;
+            const jl_line& L = lines.l[0];
+            (void)L;
+            const uint8_t* src = nullptr;
+            int64_t end = 0;
+#pragma unroll
+            for (int l = 0; l < JL_MAX_LINES; ++l)
+              if (l == dsc[u]) { src = lines.l[l].data; end = field_end[l]; }
+            x[u][0] = x[u][1] = 0;
+            if (at + 16 <= end) {
+              __builtin_memcpy(x[u], src + at, 16);
+            } else {
+              uint64_t x0 = 0, x1 = 0;                         // (no dynamic index: the words stay in registers)
+              for (int b = 0; b < m[u]; ++b) {
+                const uint64_t v = (uint64_t)src[at + b] << (8 * (b & 7));
+                if (b < 8) x0 |= v; else x1 |= v;
+              }
+              x[u][0] = x0;
+              x[u][1] = x1;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (dsc[u] < 0) continue;
+          int add = 0;
+#pragma unroll
+          for (int l = 0; l < JL_MAX_LINES; ++l)
+            if (l == dsc[u]) add = lines.l[l].add;
+          if (add) {                                           // per-byte wrap-around addition without carries between bytes
+            const uint64_t a = (uint64_t)(add & 0xff) * 0x0101010101010101ull;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              x[u][h] = ((x[u][h] & 0x7f7f7f7f7f7f7f7full) + (a & 0x7f7f7f7f7f7f7f7full)) ^ ((x[u][h] ^ a) & 0x8080808080808080ull);
+          }
+          if (q[u] >= 0 && q[u] + 16 <= tile_n) {
+            const unsigned addr = tile_base + (unsigned)q[u];
+            if (m[u] == 16) {
+              const u32x4 v = {(unsigned)x[u][0], (unsigned)(x[u][0] >> 32), (unsigned)x[u][1], (unsigned)(x[u][1] >> 32)};
+              asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+            } else {                                           // in pieces of 8, 4, 2, 1 bytes (unaligned, like the whole)
+              uint64_t rest = x[u][0];
+              unsigned at = addr;
+              if (m[u] & 8) { asm volatile("ds_write_b64 %0, %1" : : "v"(at), "v"(rest) : "memory"); rest = x[u][1]; at += 8; }
+              if (m[u] & 4) { asm volatile("ds_write_b32 %0, %1" : : "v"(at), "v"((unsigned)rest) : "memory"); rest >>= 32; at += 4; }
+              if (m[u] & 2) { asm volatile("ds_write_b16 %0, %1" : : "v"(at), "v"((unsigned)rest) : "memory"); rest >>= 16; at += 2; }
+              if (m[u] & 1) { asm volatile("ds_write_b8 %0, %1" : : "v"(at), "v"((unsigned)rest) : "memory"); }
+            }
+          } else {                                             // what sticks out of the tile: byte by byte
+            const uint64_t x0 = x[u][0], x1 = x[u][1];
+            for (int b = 0; b < m[u]; ++b) put(q[u] + b, (uint8_t)((b < 8 ? x0 : x1) >> (8 * (b & 7))));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (the asm stores are the compiler's blind spot)
+      __syncthreads();
     }
     __syncthreads();
   }
-  auto EO = [&](int64_t r) -> int64_t { return staged ? s_ent[r - lo] : entry_off[r]; };
-  auto FO = [&](int l, int64_t r) -> int64_t { return staged ? s_off[l][r - lo] : lines.l[l].off[r]; };
-#pragma unroll 1
-  for (int chunk = 0; chunk < JL_CHUNKS; ++chunk) {
-  const int64_t p0 = blk0 + ((int64_t)chunk * BNPK_BLOCK + threadIdx.x) * JL_BYTES_PER_LANE;
-  if (p0 >= total) return;
-  int64_t r;
-  {
-    int64_t a = lo, b = hi;                                    // last row with EO(row) <= p0
-    while (a < b) {
-      const int64_t mid = a + ((b - a + 1) >> 1);
-      if (EO(mid) <= p0) a = mid; else b = mid - 1;
-    }
-    r = a;
-  }
-  const int64_t p1 = min(p0 + JL_BYTES_PER_LANE, total);
-  int64_t e0 = EO(r), e1 = EO(r + 1);
-  int64_t p = p0;
-  uint64_t word[3] = {0, 0, 0};                                // the lane's sixteen output bytes, stored once
-  // m (1..8) bytes, the low bytes of x, go to the lane's next output positions
-  auto emit = [&](uint64_t x, int m) {
-    if (m < 8) x &= (1ull << (8 * m)) - 1ull;
-    const int j = (int)(p - p0), sh = 8 * (j & 7);
-    word[j >> 3] |= x << sh;
-    if (sh) word[(j >> 3) + 1] |= x >> (64 - sh);
-    p += m;
-  };
-  auto add_bytes = [&](uint64_t x, int add) -> uint64_t {     // per-byte wrap-around addition without carries between bytes
-    const uint64_t a = (uint64_t)(add & 0xff) * 0x0101010101010101ull;
-    return ((x & 0x7f7f7f7f7f7f7f7full) + (a & 0x7f7f7f7f7f7f7f7full)) ^ ((x ^ a) & 0x8080808080808080ull);
-  };
-  // A lane whose sixteen bytes cross line boundaries (four lanes in ten for FASTQ records) first walks the lines WITHOUT
-  // touching the fields: constants (header byte, newline, fill byte) go straight into the word, and what has to come from
-  // a field is noted as a piece {source, place, length, add}.  Then the loads of all pieces are issued together — 16
-  // unaligned bytes each — and shifted into place.  The walk used to wait for every span's load before it looked at the
-  // next line: two to four dependent round trips that the other lanes of the wavefront waited for.
-  struct piece_t { const uint8_t* src; int j, m, add; bool wide; };
-  constexpr int MAX_PIECES = 3;
-  piece_t pieces[MAX_PIECES];
-  int n_pieces = 0;
-  auto place = [&](uint64_t lo, uint64_t hi, int j, int m) {   // bytes 0 .. m-1 of (lo, hi) to output positions j .. j+m-1
-    if (m < 8) { lo &= (1ull << (8 * m)) - 1ull; hi = 0; }
-    else if (m < 16) hi &= (1ull << (8 * (m - 8))) - 1ull;
-    const int sh = 8 * (j & 7);
-    if (j < 8) {
-      word[0] |= lo << sh;
-      word[1] |= (sh ? lo >> (64 - sh) : 0ull) | (hi << sh);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = tid * 16; t < tile_n; t += BNPK_BLOCK * 16) {
+    if (t + 16 <= tile_n) {
+      const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(tile + t);
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 pair;
+      pair.x = v.x;
+      pair.y = v.y;
+      __builtin_nontemporal_store(pair, reinterpret_cast<u64x2*>(out + blk0 + t));
     } else {
-      word[1] |= lo << sh;
+      for (int b = t; b < tile_n; ++b) out[blk0 + b] = tile[b];
     }
-  };
-  bool overflow = false;
-  while (p < p1 && !overflow) {
-    while (e1 <= p) { ++r; e0 = e1; e1 = EO(r + 1); }
-    int64_t t = p - e0;                                        // offset inside entry r
-    for (int i = 0; i < n_lines && p < p1; ++i) {
-      const jl_line& L = lines.l[i];
-      const int64_t fs = L.data ? FO(i, r) : 0;
-      const int64_t flen = L.data ? FO(i, r + 1) - fs : 1;
-      const int64_t line_len = L.prefix + flen + 1;
-      if (t >= line_len) { t -= line_len; continue; }
-      if (t < L.prefix) { emit(header, 1); ++t; }
-      if (p < p1 && t < L.prefix + flen) {
-        const int m = (int)min((int64_t)L.prefix + flen - t, p1 - p);
-        if (!L.data) {
-          emit(L.fill, 1);                                     // (a line without a field is one constant byte)
-        } else {
-          if (n_pieces == MAX_PIECES) { overflow = true; break; }
-          const int64_t at = fs + (t - L.prefix);
-          const piece_t pc = {L.data + at, (int)(p - p0), m, L.add, at + 16 <= L.off[n_rows]};   // wide: 16 bytes can be read there
-#pragma unroll
-          for (int q = 0; q < MAX_PIECES; ++q)                 // (static indices: the pieces stay in registers)
-            if (q == n_pieces) pieces[q] = pc;
-          ++n_pieces;
-          p += m;
-        }
-        t += m;
-      }
-      if (p < p1 && t == L.prefix + flen) emit(10, 1);
-      t = 0;                                                   // the next line starts at its first byte
-    }
-  }
-  uint64_t got[MAX_PIECES][2];
-#pragma unroll
-  for (int q = 0; q < MAX_PIECES; ++q) {
-    got[q][0] = got[q][1] = 0;
-    if (q < n_pieces) {
-      if (pieces[q].wide) {
-        __builtin_memcpy(got[q], pieces[q].src, 16);
-      } else {
-        for (int b = 0; b < pieces[q].m; ++b) got[q][b >> 3] |= (uint64_t)pieces[q].src[b] << (8 * (b & 7));
-      }
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < MAX_PIECES; ++q) {
-    if (q < n_pieces) {
-      uint64_t lo = got[q][0], hi = got[q][1];
-      if (pieces[q].add) { lo = add_bytes(lo, pieces[q].add); hi = add_bytes(hi, pieces[q].add); }
-      place(lo, hi, pieces[q].j, pieces[q].m);
-    }
-  }
-  // (more than MAX_PIECES fields in sixteen bytes — fields of a byte or two: the rest of the lane's bytes the slow way)
-  while (p < p1) {
-    while (e1 <= p) { ++r; e0 = e1; e1 = EO(r + 1); }
-    int64_t t = p - e0;
-    for (int i = 0; i < n_lines && p < p1; ++i) {
-      const jl_line& L = lines.l[i];
-      const int64_t fs = L.data ? FO(i, r) : 0;
-      const int64_t flen = L.data ? FO(i, r + 1) - fs : 1;
-      const int64_t line_len = L.prefix + flen + 1;
-      if (t >= line_len) { t -= line_len; continue; }
-      if (t < L.prefix) { emit(header, 1); ++t; }
-      while (p < p1 && t < L.prefix + flen) {
-        const int m = (int)min(min((int64_t)L.prefix + flen - t, p1 - p), (int64_t)8);
-        uint64_t x;
-        if (!L.data) {
-          x = L.fill;
-        } else {
-          const uint8_t* src = L.data + fs + (t - L.prefix);
-          if (fs + (t - L.prefix) + 8 <= L.off[n_rows]) {
-            __builtin_memcpy(&x, src, 8);
-          } else {                                             // the last bytes of the field's buffer
-            x = 0;
-            for (int q = 0; q < m; ++q) x |= (uint64_t)src[q] << (8 * q);
-          }
-          if (L.add) x = add_bytes(x, L.add);
-        }
-        emit(x, m);
-        t += m;
-      }
-      if (p < p1 && t == L.prefix + flen) emit(10, 1);
-      t = 0;
-    }
-  }
-  if (p1 - p0 == JL_BYTES_PER_LANE) {                          // (p0 is a multiple of 16, the buffer 16-byte aligned)
-    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)word[0], (uint32_t)(word[0] >> 32), (uint32_t)word[1], (uint32_t)(word[1] >> 32));
-  } else {
-    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
-  }
   }
 }
 
