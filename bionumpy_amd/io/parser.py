@@ -65,6 +65,9 @@ class _Staging:
             self._pool.release()
 
 
+_early_cache = []                  # _EarlyUpload objects of closed readers
+
+
 class _EarlyUpload:
     """Device staging for the read-ahead: two HBM buffers that take turns, a copy stream, and the events that order the
     background thread's ``hipMemcpyAsync`` into a buffer behind the caller's copy out of it two batches earlier."""
@@ -178,13 +181,18 @@ class NumpyFileReader:
             self._ahead_thread.join()
             self._ahead_thread = None
         self._file_obj.close()
-        if self._early is not None:                          # nothing may still be copying into its buffers when they go
-            self._early.stream.synchronize()
-            self._early = None
+        if self._early is not None:
+            self._release_early()
         if self._staging is not None:
             self._staging.release()
             self._staging = None
         self._left_over = None
+
+    def _release_early(self):
+        self._early.stream.synchronize()                     # nothing may still be copying into its buffers when they change hands
+        if len(_early_cache) < 2:
+            _early_cache.append(self._early)
+        self._early = None
 
     def read(self):
         """the whole file as one buffer (parser.py:89-94)"""
@@ -224,8 +232,8 @@ class NumpyFileReader:
 
         early = None
         if _EARLY_UPLOAD and not getattr(get_ops(), "host_only", False):
-            if self._early is None:
-                self._early = _EarlyUpload()
+            if self._early is None:                          # (a finished reader's staging — stream, two HBM buffers — is kept for the next)
+                self._early = _early_cache.pop() if _early_cache else _EarlyUpload()
             early = self._early
 
         def start():
@@ -314,6 +322,8 @@ class NumpyFileReader:
             self._left_over = held if held.size and not self._is_finished else None
             if self._is_finished and held.size:              # (a finished file's tail without a complete entry is dropped)
                 self._left_over = None
+            if self._is_finished and self._early is not None:    # the file is through: its device staging goes to the next reader
+                self._release_early()
 
     def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
         """the next buffer of complete entries, or None at the end of the file (parser.py:96-171)"""
