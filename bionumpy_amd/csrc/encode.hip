@@ -59,57 +59,146 @@ __device__ __forceinline__ uint64_t load_upto8(const uint8_t* __restrict__ src, 
   return x;
 }
 
+// 32 source bytes -> the packed word of their codes, a bit per invalid byte, and (optionally) the byte codes
+__device__ __forceinline__ void encode32(const uint64_t (&x)[4], uint64_t& word, unsigned& bad32, uint64_t (&cw)[4]) {
+  word = 0;
+  bad32 = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint64_t badm;
+    const uint64_t c = dna_codes8(x[q], ~0ull, &badm);
+    cw[q] = c;
+    word |= compress_codes8(c) << (16 * q);
+    bad32 |= (unsigned)((((badm >> 7) * 0x0102040810204080ull) >> 56) & 0xffull) << (8 * q);
+  }
+}
+
+constexpr int GE_ROWS = 512;                                   // rows of a tile (8192 bases) staged in LDS
+
+// The rows a workgroup's 8192 bases come from (~55 reads) are staged in LDS — offsets relative to the tile, starts —
+// with one coalesced load each; a lane finds the row of its 32 bases there.  Four lanes in five have all 32 inside one
+// row: two unaligned 16-byte loads, issued together.  Most of the others straddle ONE row boundary with at least 32
+// bases on either side: the 32 bytes that END the first row and the 32 that START the next are encoded separately and
+// joined in the 2-bit domain by two 64-bit shifts (likewise their invalid-byte masks).  Only lanes over short rows walk
+// row segments with 8-byte loads as rounds 1-2 did for every lane — after a binary search over the offsets in GLOBAL
+// memory: 12.7 ms per 50 M reads, a chain of ten dependent loads per lane, 0.09 of the HBM peak.
 template <bool WRITE_CODES, bool WRITE_PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
     int64_t n_rows, int64_t total, const int64_t* __restrict__ tile_rows, int64_t n_tiles,
     uint8_t* __restrict__ codes, uint64_t* __restrict__ packed, unsigned long long* __restrict__ err) {
+  __shared__ int rel[GE_ROWS + 1];                             // offsets[rr0 + i] - first base of the tile (clamped below)
+  __shared__ int64_t st[GE_ROWS];
+  __shared__ int64_t first_off;
   int64_t rr[2];
-  int64_t n_words = (total + BASES_PER_WORD - 1) / BASES_PER_WORD;
-  int64_t w0 = (int64_t)blockIdx.x * BNPK_BLOCK;
-  int64_t w = w0 + threadIdx.x;
+  const int64_t n_words = (total + BASES_PER_WORD - 1) / BASES_PER_WORD;
+  const int64_t w0 = (int64_t)blockIdx.x * BNPK_BLOCK;
+  const int64_t w = w0 + threadIdx.x;
   if (w0 >= n_words) {                          // pad word(s) read by the k-mer kernel
     if (WRITE_PACKED && w <= n_words) packed[w] = 0;
     return;
   }
   tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, rr[0], rr[1]);
+  const int64_t blk_first = w0 * BASES_PER_WORD;
+  // (32-bit halves: see gather_rows_kernel for the compiler bug a 64-bit uniform select runs into here)
+  const uint64_t row_span = (uint64_t)(rr[1] - rr[0]);
+  unsigned span_lo = (unsigned)row_span, span_hi = (unsigned)(row_span >> 32);
+  asm volatile("" : "+s"(span_lo), "+s"(span_hi));
+  const bool staged = span_hi == 0u && span_lo < (unsigned)GE_ROWS;
+  const int n_stage = staged ? (int)span_lo + 1 : 0;
+  if (staged) {
+    for (int i = threadIdx.x; i <= n_stage; i += BNPK_BLOCK) {
+      const int64_t d = offsets[rr[0] + i] - blk_first;
+      rel[i] = (int)max(d, (int64_t)-(1 << 30));
+      if (i < n_stage) st[i] = starts[rr[0] + i];
+      if (i == 0) first_off = offsets[rr[0]];
+    }
+    __syncthreads();
+  }
   if (w >= n_words) {
     if (WRITE_PACKED && w == n_words) packed[w] = 0;
     return;
   }
   int64_t pos = w * BASES_PER_WORD;
   const int64_t end = min(pos + BASES_PER_WORD, total);
-  int64_t row = find_row(offsets, rr[0], rr[1], pos);
-  int64_t row_end = offsets[row + 1];
-  const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
   uint64_t word = 0;
   uint64_t cw[5] = {0, 0, 0, 0, 0};
   unsigned long long bad = (unsigned long long)BNPK_NONE;
-  int j = 0;                                    // bases produced so far
-  while (pos < end) {
-    while (pos >= row_end) {                    // next non-empty row
-      ++row;
-      row_end = offsets[row + 1];
-      src = buf + starts[row];
+  bool done = false;
+  int64_t row;
+  if (staged) {
+    const int at = (int)(pos - blk_first);
+    int lo = 0, hi = n_stage - 1;                              // last i with rel[i] <= at (skips empty rows)
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo + 1) >> 1);
+      if (rel[mid] <= at) lo = mid; else hi = mid - 1;
     }
-    int seg = (int)min(row_end - pos, end - pos);
-    while (seg > 0) {
-      int m;
-      uint64_t x = load_upto8(src, seg, &m);
-      uint64_t lanes = (m == 8) ? ~0ull : ((1ull << (8 * m)) - 1ull);
-      uint64_t badm;
-      uint64_t c = dna_codes8(x, lanes, &badm);
-      if (badm) {
-        unsigned long long at = (unsigned long long)(pos + ((__ffsll((long long)badm) - 1) >> 3));
-        if (at < bad) bad = at;
+    row = rr[0] + lo;
+    const int row_end = rel[lo + 1];
+    const int64_t start_r = lo == 0 ? first_off - blk_first : (int64_t)rel[lo];      // (tile-relative; may lie far before the tile)
+    if (end - pos == BASES_PER_WORD) {
+      uint64_t x[4], c4[4];
+      unsigned bad32 = 0;
+      if (row_end - at >= BASES_PER_WORD) {                    // all 32 bases inside the row
+        const uint8_t* src = buf + st[lo] + ((int64_t)at - start_r);
+        __builtin_memcpy(x, src, 16);
+        __builtin_memcpy(x + 2, src + 16, 16);
+        encode32(x, word, bad32, c4);
+        done = true;
+      } else if (!WRITE_CODES && lo + 2 <= n_stage && (int64_t)row_end - start_r >= BASES_PER_WORD &&
+                 rel[lo + 2] - row_end >= BASES_PER_WORD) {    // one boundary, k bases before it
+        const int k = row_end - at;                            // 1 .. 31
+        uint64_t y[4], c5[4], wa, wb;
+        unsigned bad_a, bad_b;
+        const uint8_t* tail = buf + st[lo] + ((int64_t)row_end - start_r) - BASES_PER_WORD;
+        const uint8_t* head = buf + st[lo + 1];
+        __builtin_memcpy(x, tail, 16);
+        __builtin_memcpy(x + 2, tail + 16, 16);
+        __builtin_memcpy(y, head, 16);
+        __builtin_memcpy(y + 2, head + 16, 16);
+        encode32(x, wa, bad_a, c4);
+        encode32(y, wb, bad_b, c5);
+        word = (wa >> (2 * (BASES_PER_WORD - k))) | (wb << (2 * k));
+        bad32 = (bad_a >> (BASES_PER_WORD - k)) | (bad_b << k);
+        done = true;
       }
-      if (WRITE_CODES) {
-        int sh = 8 * (j & 7);
-        cw[j >> 3] |= c << sh;
-        if (sh) cw[(j >> 3) + 1] |= c >> (64 - sh);
+      if (done) {
+        if (bad32) bad = (unsigned long long)(pos + (__ffs((int)bad32) - 1));
+        if (WRITE_CODES) { cw[0] = c4[0]; cw[1] = c4[1]; cw[2] = c4[2]; cw[3] = c4[3]; }
       }
-      word |= compress_codes8(c) << (2 * j);
-      j += m; src += m; pos += m; seg -= m;
+    }
+  } else {
+    row = find_row(offsets, rr[0], rr[1], pos);
+  }
+  if (!done) {
+    int64_t row_end = offsets[row + 1];
+    const uint8_t* src = buf + starts[row] + (pos - offsets[row]);
+    int j = 0;                                  // bases produced so far
+    while (pos < end) {
+      while (pos >= row_end) {                  // next non-empty row
+        ++row;
+        row_end = offsets[row + 1];
+        src = buf + starts[row];
+      }
+      int seg = (int)min(row_end - pos, end - pos);
+      while (seg > 0) {
+        int m;
+        uint64_t x = load_upto8(src, seg, &m);
+        uint64_t lanes = (m == 8) ? ~0ull : ((1ull << (8 * m)) - 1ull);
+        uint64_t badm;
+        uint64_t c = dna_codes8(x, lanes, &badm);
+        if (badm) {
+          unsigned long long at = (unsigned long long)(pos + ((__ffsll((long long)badm) - 1) >> 3));
+          if (at < bad) bad = at;
+        }
+        if (WRITE_CODES) {
+          int sh = 8 * (j & 7);
+          cw[j >> 3] |= c << sh;
+          if (sh) cw[(j >> 3) + 1] |= c >> (64 - sh);
+        }
+        word |= compress_codes8(c) << (2 * j);
+        j += m; src += m; pos += m; seg -= m;
+      }
     }
   }
   if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
