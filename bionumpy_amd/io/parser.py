@@ -8,10 +8,10 @@ new bytes on top of what was left over), the newline (and '>' for multi-line FAS
 ``FormatException.line_number`` that counts from the start of the file — but the mechanism is built for batches of
 gigabytes going to a device, not for 5 MB numpy chunks:
 
-* the bytes are read straight into page-locked staging buffers, two of them: a plain file by ``os.preadv`` of disjoint
+* the bytes are read straight into page-locked staging buffers, three of them: a plain file by ``os.preadv`` of disjoint
   slices from a few threads (one thread copies out of the page cache at ~10 GB/s), anything else by ``readinto``; the
   end-of-file newline / marker is written in place behind the data;
-* under ``read_chunks`` with batches of 32 MB and more of a plain file, a background thread reads the next batch's new
+* under ``read_chunks`` with batches of 32 MB and more of a plain file, background threads read the next two batches' new
   bytes while the current batch is uploaded, scanned and worked on by the caller (they are read before the current
   batch's left-over is known, so such a batch is its left-over plus ``min_chunk_size`` new bytes; smaller batches keep
   the reference's window arithmetic exactly);
@@ -26,6 +26,7 @@ gigabytes going to a device, not for 5 MB numpy chunks:
   class (``from_raw_buffer``) on the uploaded bytes — the host never looks at them (the reference counts the
   newlines of every chunk with numpy before it parses it).
 """
+import collections
 import io
 import os
 import threading
@@ -41,19 +42,20 @@ _READ_THREADS = int(os.environ.get("BNPK_READ_THREADS", min(16, os.cpu_count() o
 _READ_AHEAD = os.environ.get("BNPK_READ_AHEAD", "1") != "0"
 _FRONT = 4 << 20                   # room kept in front of a read-ahead for the bytes left over by the batch before it
 _EARLY_UPLOAD = os.environ.get("BNPK_EARLY_UPLOAD", "1") != "0"     # the read-ahead thread starts the batch's upload too
+_READ_DEPTH = int(os.environ.get("BNPK_READ_DEPTH", 2))          # batches read ahead under read_chunks (1 or 2)
 _PIECE = int(os.environ.get("BNPK_PIECE_MB", 16)) << 20                   # ... piece by piece, while the reading threads are still at work
 
 
 class _Staging:
     """where the bytes of a batch are gathered: page-locked buffers on the GPU path (io/pinned.py), plain numpy arrays
     under the host-only test backend.  ``room(n)`` returns a writable uint8 array of at least n bytes that does not
-    alias the array returned by the previous call."""
+    alias the arrays returned by the two calls before it."""
 
     def __init__(self):
         self._pool = None
         if not getattr(get_ops(), "host_only", False):
             from .pinned import PinnedPool
-            self._pool = PinnedPool(2)
+            self._pool = PinnedPool(3)                       # the batch in use and two being read ahead
 
     def room(self, n):
         if self._pool is not None:
@@ -69,8 +71,8 @@ _early_cache = []                  # _EarlyUpload objects of closed readers
 
 
 class _EarlyUpload:
-    """Device staging for the read-ahead: two HBM buffers that take turns, a copy stream, and the events that order the
-    background thread's ``hipMemcpyAsync`` into a buffer behind the caller's copy out of it two batches earlier."""
+    """Device staging for the read-ahead: three HBM buffers that take turns, a copy stream, and the events that order the
+    background thread's ``hipMemcpyAsync`` into a buffer behind the caller's copy out of it three batches earlier."""
 
     def __init__(self):
         import torch
@@ -78,12 +80,12 @@ class _EarlyUpload:
         from .._native import lib, check
         self.torch, self.dev, self.lib, self.check = torch, Device.get(), lib, check
         self.stream = torch.cuda.Stream(self.dev.tdev)
-        self.buffers, self.free_events, self.turn = [None, None], [None, None], 0
+        self.buffers, self.free_events, self.turn = [None] * 3, [None] * 3, 0
 
     def take(self, nbytes):
         """(caller's thread) the next staging buffer in turn, at least nbytes large -> its index"""
         i = self.turn
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.buffers)
         if self.buffers[i] is None or self.buffers[i].numel() < nbytes:
             self.buffers[i] = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.dev.tdev)
             ev = self.torch.cuda.Event()
@@ -159,7 +161,7 @@ class NumpyFileReader:
         self._left_over = None             # bytes behind the last complete entry of the previous batch (a staging view)
         self._staging = None
         self._early = None                 # device side of the read-ahead (_EarlyUpload)
-        self._ahead_thread = None
+        self._ahead_threads = []
         self.n_bytes_read = 0
         self.n_lines_read = 0
 
@@ -177,9 +179,9 @@ class NumpyFileReader:
         self._stream_mode = True
 
     def close(self):
-        if self._ahead_thread is not None:                   # a read-ahead still writing into a staging buffer
-            self._ahead_thread.join()
-            self._ahead_thread = None
+        for t in list(self._ahead_threads):                  # read-aheads still writing into staging buffers
+            t.join()
+        self._ahead_threads = []
         self._file_obj.close()
         if self._early is not None:
             self._release_early()
@@ -236,51 +238,67 @@ class NumpyFileReader:
                 self._early = _early_cache.pop() if _early_cache else _EarlyUpload()
             early = self._early
 
+        # Two batches are read ahead where the reads can be given their places in the file beforehand (a plain file read by
+        # bnpk_pread_parallel): while the caller works on batch i, batch i + 1 is (usually) in HBM already and batch i + 2 is
+        # being read and copied — the copy engine is busy without a gap.  One batch ahead otherwise.
+        placed = _READ_THREADS >= 2
+        depth = min(2, _READ_DEPTH) if placed else 1
+        f = self._file_obj
+        next_pos = f.tell()
+        file_size = os.fstat(f.fileno()).st_size if placed else 0
+
         def start():
             # the staging buffer is taken here, by the caller's thread: making sure that no copy out of it is in flight
             # means waiting for the stream, and the background thread would wait behind the upload of the current batch
+            nonlocal next_pos
             room = self._staging.room(_FRONT + min_chunk_size + 2)
             slot = early.take(_FRONT + min_chunk_size + 2) if early is not None else None
             box = {}
+            if placed:
+                pos, want = next_pos, max(0, min(min_chunk_size, file_size - next_pos))
+                next_pos += want
 
             def work():
                 try:
-                    new = room[_FRONT:_FRONT + min_chunk_size]
-                    if early is None:
-                        got = self._fill(new)
-                    else:
+                    new = room[_FRONT:_FRONT + (want if placed else min_chunk_size)]
+                    target = early.target(slot, _FRONT) if early is not None else None
+                    if early is not None:
                         early.begin(slot)
-                        got = self._fill(new, early.target(slot, _FRONT))
-                        if got < 0:                                          # the reading threads sent the pieces themselves
-                            got = -got
-                        elif got > 0:                                        # (a serial read: one copy behind it)
+                    if placed:
+                        got = self._fill_at(new, pos, target) if want else 0
+                        sent = True
+                    else:
+                        got = self._fill(new, target)
+                        sent = got < 0                                       # the reading threads sent the pieces themselves
+                        got = abs(got)
+                    if early is not None and got > 0:
+                        if not sent:                                         # (a serial read: one copy behind it)
                             early.upload(slot, new[:got], _FRONT)
-                        if got > 0:
-                            from .pinned import owner_of
-                            box["uploaded"] = (slot, early.finish(slot, owner_of(room)))
+                        from .pinned import owner_of
+                        box["uploaded"] = (slot, early.finish(slot, owner_of(room)))
                     box["result"] = (room, got)
                 except BaseException as e:                   # noqa: BLE001  (re-raised where the bytes are taken)
                     box["error"] = e
             box["thread"] = threading.Thread(target=work, name="bnpk-read-ahead", daemon=True)
             box["thread"].start()
-            self._ahead_thread = box["thread"]               # (close() waits for it before the staging buffers go back)
+            self._ahead_threads.append(box["thread"])        # (close() waits for them before the staging buffers go back)
             return box
 
         def take(box):
             box["thread"].join()
-            self._ahead_thread = None
+            self._ahead_threads.remove(box["thread"])
             if "error" in box:
                 raise box["error"]
             return box["result"]
 
         held = self._left_over if self._left_over is not None else np.zeros(0, dtype=np.uint8)
         self._left_over = None
-        ahead = start()
+        pending = collections.deque([start()])
         try:
             while not self._is_finished:
+                ahead = pending.popleft()
                 room, got = take(ahead)
                 uploaded = ahead.get("uploaded")
-                ahead = None
                 self._is_finished = got < min_chunk_size
                 if got == 0 and held.size == 0:
                     break
@@ -298,8 +316,8 @@ class NumpyFileReader:
                 if self._is_finished:
                     n = self._terminate(room, n)
                 batch = room[first:n]
-                if not self._is_finished:
-                    ahead = start()                          # the next batch's bytes, while this one is parsed and used
+                while not self._is_finished and len(pending) < depth:
+                    pending.append(start())                  # the next batches' bytes, while this one is parsed and used
                 if max_chunk_size is not None and batch.size > max_chunk_size:
                     raise Exception("No complete entry found")
                 on_device = early.assemble(uploaded[0], uploaded[1], room, first, n, _FRONT, got) if uploaded is not None else None
@@ -313,12 +331,16 @@ class NumpyFileReader:
                 self.n_lines_read += buff.n_lines
                 yield buff
         finally:
-            if ahead is not None:                            # abandoned mid-file: what was read stays available
-                room, got = take(ahead)
+            while pending:                                   # abandoned mid-file: what was read stays available
+                room, got = take(pending.popleft())
+                if self._is_finished:                        # (a read started behind the end of the file: nothing)
+                    continue
                 rest = np.empty(held.size + got, dtype=np.uint8)
                 rest[:held.size] = held
                 rest[held.size:] = room[_FRONT:_FRONT + got]
                 held, self._is_finished = rest, got < min_chunk_size
+            if placed:
+                f.seek(next_pos)                             # (the reads were placed by hand: the file object follows)
             self._left_over = held if held.size and not self._is_finished else None
             if self._is_finished and held.size:              # (a finished file's tail without a complete entry is dropped)
                 self._left_over = None
@@ -403,6 +425,23 @@ class NumpyFileReader:
             raise OSError("short read of %s" % self._f_name)
         f.seek(pos + want)
         return want
+
+    def _fill_at(self, target, pos, upload=None):
+        """target.size bytes of the (plain) file from byte ``pos`` on, whatever the file object's position is: reads that
+        run side by side take their places in the file when they are started"""
+        import ctypes as C
+        from .._native import lib, check
+        ctx = None
+        if upload is not None:
+            from ..device import Device
+            ctx = Device.get().ctx
+        got = C.c_int64(0)
+        d_dst, stream = upload if upload is not None else (None, None)
+        check(lib.bnpk_pread_parallel(ctx, self._file_obj.fileno(), pos, C.c_void_p(target.__array_interface__["data"][0]),
+                                      target.size, _READ_THREADS, _PIECE, d_dst, stream, C.byref(got)))
+        if got.value < target.size:
+            raise OSError("short read of %s" % self._f_name)
+        return target.size
 
     def _fill(self, target, upload=None):
         """file.readinto(target) until it is full or the file ends (buffered / gzip readers return short reads).

@@ -162,7 +162,7 @@ out["config5_kmer_index"] = {"genome_rows": len(genome), "genome_bases": int(seq
                              "lookup_s": round(t_lookup, 5), "queries_with_hit": hits}
 
 # ---- streamed file -> 31-mer histogram (host file read + pinned H2D included) ----------------------------------------
-n_file = min(reads, 4_000_000)
+n_file = min(reads, 16_000_000)
 path = "/tmp/bnpk_stream_test.fq"
 synth.fastq_bytes(n_file, 150, 7, 1, 5_000_000).tofile(path)
 def stream_count():
