@@ -93,6 +93,7 @@ SIGNATURES = {
     "bnpk_minimizers_generic": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _int, _p, _p]),
     "bnpk_lut_bytes": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
     "bnpk_kmer_start_mask": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
+    "bnpk_row_end_mask": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "bnpk_join_lines": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _u8, _p, _i64, _p, _p]),
     "bnpk_col_sums_u8": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "bnpk_row_reduce_u8": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),

@@ -569,6 +569,20 @@ class HipOps:
 
     def kmer_start_mask(self, offsets, n_rows, total, k):
         """one bit per base, set where a k-mer starts (bnpk_kmer_start_mask)"""
+        # the rows' end bits (one atomic per row), then the bit-parallel windowed OR the fused decode uses: a third of the
+        # time of bnpk_kmer_start_mask, which walks the words of every row
+        mask = self._empty(total // 64 + 2, np.int64)
+        if k > 64:                                       # (windows longer than the windowed OR looks ahead)
+            self._chk(lib.bnpk_kmer_start_mask(self.ctx, ptr(offsets.dev()), n_rows, total, k, ptr(mask), self._s()))
+            return HArray(dev=mask)
+        ends = self._empty(total // 64 + 2, np.int64)
+        count = self._empty(1, np.int64)
+        self._chk(lib.bnpk_row_end_mask(self.ctx, ptr(offsets.dev()), n_rows, total, ptr(ends), self._s()))
+        self._chk(lib.bnpk_kmer_starts_from_ends(self.ctx, ptr(ends), total, k, ptr(mask), ptr(count), self._s()))
+        return HArray(dev=mask)
+
+    def kmer_start_mask_by_rows(self, offsets, n_rows, total, k):
+        """bnpk_kmer_start_mask itself (a thread walks the words of its row): any k, kept as the reference form"""
         mask = self._empty(total // 64 + 2, np.int64)
         self._chk(lib.bnpk_kmer_start_mask(self.ctx, ptr(offsets.dev()), n_rows, total, k, ptr(mask), self._s()))
         return HArray(dev=mask)

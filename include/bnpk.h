@@ -355,6 +355,9 @@ int bnpk_canonical_kmers(bnpk_ctx* ctx, int64_t* d_hashes, int64_t n, int k, voi
  * (bionumpy/sequence/kmers.py:100) as a mask, so that the fused generator below needs no row lookup. */
 int bnpk_kmer_start_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t total, int k,
                          uint64_t* d_mask, void* stream);
+/* the read-end mask of rows given by their offsets (bit i set on the last element of every non-empty row; total / 64 + 2
+ * words, zeroed here): with bnpk_kmer_starts_from_ends the faster way to the mask bnpk_kmer_start_mask writes. */
+int bnpk_row_end_mask(bnpk_ctx* ctx, const int64_t* d_offsets, int64_t n_rows, int64_t total, uint64_t* d_ends, void* stream);
 
 /* Row-lookup-free form of bnpk_kmers (kmers_per_window = 1) and bnpk_minimizers (kmers_per_window =
  * window_size - k + 1 <= 26): d_start_mask marks the flat positions at which a window starts

@@ -478,8 +478,16 @@ def test_fused_fastq_encode_matches_the_unfused_path(ops, encoder, seed, n_reads
     offsets, _ = ops.row_offsets(_h(lens), 1)
     for k in (1, 2, 5, 31):
         mask, n_kmers = ops.kmer_starts_from_ends(ends, n_bases, k)
-        ref = ops.kmer_start_mask(offsets, n_records, n_bases, k)
-        assert np.array_equal(mask.host(), ref.host())
+        bits = np.zeros((n_bases // 64 + 2) * 64, dtype=np.uint8)          # numpy: a k-mer starts at the first len - k + 1 bases of a row
+        first = np.cumsum(lens) - lens
+        for s0, ln in zip(first, lens):
+            if ln >= k:
+                bits[s0:s0 + ln - k + 1] = 1
+        want = np.packbits(bits, bitorder="little").view(np.int64)
+        assert np.array_equal(mask.host(), want)
+        # the same mask from row offsets: through the rows' end bits (ops.kmer_start_mask) and by walking the rows
+        assert np.array_equal(ops.kmer_start_mask(offsets, n_records, n_bases, k).host(), want)
+        assert np.array_equal(ops.kmer_start_mask_by_rows(offsets, n_records, n_bases, k).host(), want)
         assert n_kmers == int(np.maximum(lens - k + 1, 0).sum())
 
 
