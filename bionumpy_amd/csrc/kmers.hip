@@ -335,9 +335,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_pwm_kernel(const uint64_t* __re
     }
   }
   __syncthreads();
-  const int64_t base = tile_off[blockIdx.x];
-  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
-  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = stage[i];
+  wf_store_run(reinterpret_cast<const uint64_t*>(stage), tile_off[blockIdx.x], tile_off[blockIdx.x + 1],
+               reinterpret_cast<int64_t*>(out));
 }
 
 // bits [off[r], off[r+1] - (k-1)) of the mask for every row r with at least k bases: the positions of the flat
