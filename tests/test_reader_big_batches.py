@@ -22,12 +22,17 @@ def _fastq(rng, n, max_len, final_newline=True):
     return text if final_newline else text[:-1]
 
 
-@pytest.fixture
-def small_thresholds(monkeypatch):
+@pytest.fixture(params=[(4, 2), (4, 1), (1, 2)], ids=["two-ahead", "one-ahead", "serial-reads"])
+def small_thresholds(monkeypatch, request):
+    """the big-batch machinery at test sizes: two batches read ahead by placed native reads (the default), one batch ahead,
+    and reads through the file object (one thread: no places in the file can be handed out beforehand)"""
     from bionumpy_amd.io import parser
+    threads, depth = request.param
     monkeypatch.setattr(parser, "_BIG", 1 << 12)
     monkeypatch.setattr(parser, "_FRONT", 1 << 9)
-    monkeypatch.setattr(parser, "_READ_THREADS", 4)
+    monkeypatch.setattr(parser, "_READ_THREADS", threads)
+    monkeypatch.setattr(parser, "_READ_DEPTH", depth)
+    monkeypatch.setattr(parser, "_PIECE", 1 << 11)
     return parser
 
 
@@ -95,6 +100,8 @@ def test_parallel_fill_reads_what_readinto_reads(small_thresholds, tmp_path):
     r._stream_mode = False
     r._f_name = str(path)
     out = np.zeros(50_000, dtype=np.uint8)
+    if parser._READ_THREADS < 2:
+        assert r._fill_parallel(out) is None                 # (one thread: the serial path)
     assert r._fill(out) == 50_000 and np.array_equal(out, data[:50_000])
     out2 = np.zeros(50_000, dtype=np.uint8)
     assert r._fill(out2) == 20_001 and np.array_equal(out2[:20_001], data[50_000:])
