@@ -151,7 +151,9 @@ def count_kmers(sequence, k, axis=None, canonical=False):
     For the flattened sparse histogram the hashes are never laid out row by row: they are generated straight
     into the first radix level of the counting sort (bnpk_kmers_partition), as in pipeline.py."""
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
-    if axis is None and 8 < k <= _DENSE_MAX_K and not canonical and _as_four_letter(sequence).encoding.alphabet_size == 4:
+    if axis is None and k > 8:
+        sequence = _as_four_letter(sequence)                 # (once: on base-encoded input this is the gather + 2-bit encode)
+    if axis is None and 8 < k <= _DENSE_MAX_K and not canonical and sequence.encoding.alphabet_size == 4:
         # 4^k bins still fit the device (as in pipeline.py): one dense counting pass and a compaction of the non-zero bins
         # give the same sorted (key, count) pairs as the radix path, which would spend its levels on a 2k <= 26 bit key
         kmers = get_kmers(sequence, k)
@@ -161,9 +163,8 @@ def count_kmers(sequence, k, axis=None, canonical=False):
             ops = get_ops()
             keys, counts = ops.dense_to_sparse(ops.count_dense(kmers._flat_data(), 4 ** k))
             return SparseKmerCounts(kmers.encoding, keys, counts)
-    if axis is None and k > 8 and _as_four_letter(sequence).encoding.alphabet_size == 4:
+    if axis is None and k > 8 and sequence.encoding.alphabet_size == 4:
         from .count_encoded import SparseKmerCounts
-        sequence = _as_four_letter(sequence)
         if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":
             raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
         ops = get_ops()
