@@ -92,7 +92,7 @@ def sampled_reads_check(ops, keys, counts, n_reads, read_len, k, seed, mode, gen
         assert bool((pos < n_distinct).all().item()), "a sampled k-mer lies beyond the last key"
         assert bool((kd[pos] == torch.from_numpy(ek).to(kd.device)).all().item()), "a sampled k-mer is missing"
         got = cd[pos].cpu().numpy()
-        if mode == 0:
+        if mode == 0 and 2 * k >= 56:                    # (random reads: a k-mer of >= 28 bases occurs once in the whole batch)
             assert np.array_equal(got, ec), "count of a sampled k-mer differs (reads %d..%d)" % (f, f + m)
         else:
             assert np.all(got >= ec), "count of a sampled k-mer is too small (reads %d..%d)" % (f, f + m)
