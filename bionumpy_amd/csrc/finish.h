@@ -9,7 +9,7 @@
 // start at word FS_FAST.
 constexpr int FS_FLAGS = 0, FS_TICKET = 1, FS_UNIQUE = 2, FS_REDO = 3, FS_NLOG = 4, FS_MISFIT = 5, FS_TODO = 6, FS_LOG = 8;
 // (the duplicate-aware path does not use the fast kernel's log: its words hold the probe's counters)
-constexpr int FS_PROBE_BAD = 8, FS_PROBE_DISTINCT = 9, FS_PROBE_KEYS = 10;
+constexpr int FS_PROBE_BAD = 8, FS_PROBE_DISTINCT = 9, FS_PROBE_KEYS = 10, FS_PROBE_GIVEUP = 11;   // [11] keys the sampled buckets that did not fit had shown when that became clear
 constexpr int FS_FTICKET = 96, FS_FAST = 112;
 
 // most keys a bucket may hold (the general kernel and the duplicate-aware kernel; the fast kernel takes 7680)

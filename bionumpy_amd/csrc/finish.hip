@@ -1136,6 +1136,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
   const bool can_wave = n >= 2;
   bool use_general = mode == 1, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
   bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
+  bool nearly_distinct = false;
   if (!use_general) BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
@@ -1147,13 +1148,17 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       if (mode == 0 && can_wave)
         BNPK_CHECK(bnpk_finish_wave_launch(ctx, true, probe_buckets, part, n, d_bucket_offsets, n_buckets, low_bits, state, Dv,
                                            todo_ids, d_keys_out, d_big_table, n_big, big_keys, d_big_counts, s));
-      int64_t probe[3] = {0, 0, 0};
+      int64_t probe[4] = {0, 0, 0, 0};
       BNPK_HIP(ctx, hipMemcpyAsync(probe, d_state + FS_PROBE_BAD, sizeof(probe), hipMemcpyDeviceToHost, s));
       BNPK_CHECK(read_header());
       if (host[FS_MISFIT] != 0) try_fast = false;
       if (mode == 0 && can_wave && probe[2] > 0) {
         const int64_t stride = std::max<int64_t>(1, n_buckets / probe_buckets), sampled = ceil_div(n_buckets, stride);
         if (probe[0] * 16 <= sampled) { use_wave = true; try_fast = false; }
+        // the sampled buckets overflowed the 704-slot table within ~1100 keys: (nearly) every key is new — if the fast
+        // kernel refuses such keys for the repeats among them, the workgroup table would overflow too, and the general
+        // kernel is the one left (random 21-mers: 125 instead of 188 ms by way of the cascade)
+        nearly_distinct = probe[0] > 0 && probe[3] < 1100 * probe[0];
       }
     }
     if (try_fast) {
@@ -1189,7 +1194,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       else if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
     }
     if (!try_fast && !use_general && !use_dup && !use_wave) {
-      if (mode == 2) use_general = true; else use_dup = true;
+      if (mode == 2 || (mode == 0 && nearly_distinct)) use_general = true; else use_dup = true;
     }
     if (use_wave) BNPK_CHECK(duplicate_aware(true));
     else if (use_dup) BNPK_CHECK(duplicate_aware(false));

@@ -118,6 +118,7 @@ __device__ __noinline__ void fw_finalize(uint64_t* A, int64_t b, int64_t lo, int
       if (lane < FW_BM_WORDS) BM[lane] = 0;
       if (lane == 0) {
         sh[0] = 0;
+        if (bad && !gave_up) atomicAdd(&header[FS_PROBE_GIVEUP], (unsigned long long)nb);   // (more distinct keys than the list holds)
         atomicAdd(&header[FS_PROBE_KEYS], (unsigned long long)nb);
         atomicAdd(&header[bad ? FS_PROBE_BAD : FS_PROBE_DISTINCT], bad ? 1ull : (unsigned long long)D);
       }
@@ -335,6 +336,10 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
       const int i0 = it.c + 2 * lane, i1 = i0 + 128;
       const bool act[4] = {i0 + 1 < nb, i0 < nb, i1 + 1 < nb, i1 < nb};
       insert4(key, act);
+      // (the probe notes how many keys of the bucket it took to overflow the table: ~700 when they are all distinct, the
+      // more the more they repeat — what tells the caller which kernel such buckets belong to)
+      if (PROBE && __any(gave_up) && lane == 0)
+        atomicAdd(&header[FS_PROBE_GIVEUP], (unsigned long long)min(it.c + FW_ITEM, nb));
     }
     FW_MARK(3)
     if (it.c + FW_ITEM < nb) return;                     // (uniform) more requests of this bucket follow
