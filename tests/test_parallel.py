@@ -6,10 +6,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_histogram_merge_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("ranks,port", [(2, 29731), (3, 29733)])
+def test_histogram_merge_over_gloo(ranks, port):
+    """2 ranks, and 3 (256 fine buckets do not divide evenly; the steps of the exchange get parts of unequal size)"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29731", os.path.join(ROOT, "tests", "dist_worker.py")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_OK" in r.stdout
