@@ -12,6 +12,7 @@ Both are file-like objects with ``readinto`` / ``read`` / ``close`` / ``name``; 
 streams (``set_prepend_mode``), exactly like a ``gzip.GzipFile``.
 """
 import collections
+import os
 import struct
 import threading
 import zlib
@@ -216,8 +217,10 @@ class AheadGzipReader(_AheadReader):
         self._raw.close()
 
 
-def open_gzip_for_reading(filename, n_threads=8):
+def open_gzip_for_reading(filename, n_threads=None):
     """``gzip.open(filename, "rb")`` for the chunk reader: BGZF -> thread pool, anything else -> one thread ahead"""
+    if n_threads is None:
+        n_threads = int(os.environ.get("BNPK_INFLATE_THREADS", min(16, os.cpu_count() or 1)))
     raw = open(filename, "rb")
     head = raw.read(64)
     raw.seek(0)
