@@ -44,6 +44,8 @@ struct bnpk_ctx {
   int finish_dup_grid = 0;
   bool finish_wave_ready = false;   // finish_wave.hip
   int finish_wave_grid = 0;
+  bool finish_multi_ready = false;  // finish_multi.hip
+  int finish_multi_grid = 0;
   int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
 };
 

@@ -35,3 +35,13 @@ int bnpk_finish_wave_launch(bnpk_ctx* ctx, bool probe, int64_t probe_buckets, ui
                             int64_t n_buckets, int low_bits, unsigned long long* header, int64_t* Dv, unsigned* todo_ids,
                             int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
                             const int64_t* big_counts, hipStream_t s);
+
+// The fast kernel's ranking with multiplicities, run-length emission from the sorted stage and exact output positions
+// (finish_multi.hip): nearly-distinct keys with a repeat in most buckets.  status: n_buckets zeroed 32-bit words; the
+// header's first FS_FAST words zeroed.  Buckets it leaves to finish_sorted_kernel<REDO> (a bin of more than 64 keys) are
+// listed in redo_ids / redo_bases (header[FS_REDO]); header[FS_UNIQUE] = distinct keys; flag 2 = a wait gave up (the
+// output is incomplete: the caller takes another kernel).  Buckets over 7680 keys must be pre-counted (big_table).
+int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
+                             unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
+                             const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
+                             unsigned* redo_ids, int64_t* redo_bases, hipStream_t s);

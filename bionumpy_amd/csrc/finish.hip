@@ -1132,15 +1132,28 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
   // a bucket per workgroup when keys repeat after all; then the cascade without its first stage.
   // 1 = general kernel only; 2 = fast kernel + redo list, general kernel if it gives up; 3 = the workgroup kernel of the
   // cascade (+ general kernel); 4 = the whole cascade.
+  // The multiplicity-counting fast kernel (finish_multi.hip): exact positions, every bucket emitted once; what it leaves
+  // (a bin of more than 64 keys) is redone by the general kernel at the position the list carries.
+  auto multi = [&]() -> int {
+    BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+    BNPK_HIP(ctx, hipMemsetAsync(meta, 0, (size_t)n_buckets * 4, s));
+    BNPK_CHECK(bnpk_finish_multi_launch(ctx, part, d_bucket_offsets, n_buckets, low_bits, state, meta, keys_out, d_counts_out,
+                                        d_big_table, n_big, big_keys, d_big_counts, redo_ids, redo_bases, s));
+    BNPK_CHECK(read_header());
+    if (host[FS_FLAGS] & 2) return BNPK_OK;               // (a wait gave up: the caller takes the general kernel)
+    if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
+    return BNPK_OK;
+  };
   const int mode = ctx->finish_mode;
   const bool can_wave = n >= 2;
   bool use_general = mode == 1, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
   bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
+  bool use_multi = mode == 5;
   bool nearly_distinct = false;
   if (!use_general) BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
-    if (mode == 0 || try_fast) {
+    if (mode == 0 || try_fast || use_multi) {
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
                          d_bucket_offsets, n_buckets, state);
@@ -1151,7 +1164,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       int64_t probe[4] = {0, 0, 0, 0};
       BNPK_HIP(ctx, hipMemcpyAsync(probe, d_state + FS_PROBE_BAD, sizeof(probe), hipMemcpyDeviceToHost, s));
       BNPK_CHECK(read_header());
-      if (host[FS_MISFIT] != 0) try_fast = false;
+      if (host[FS_MISFIT] != 0) { try_fast = false; if (use_multi) { use_multi = false; use_general = true; } }
       if (mode == 0 && can_wave && probe[2] > 0) {
         const int64_t stride = std::max<int64_t>(1, n_buckets / probe_buckets), sampled = ceil_div(n_buckets, stride);
         if (probe[0] * 16 <= sampled) { use_wave = true; try_fast = false; }
@@ -1193,8 +1206,15 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       if (host[FS_FLAGS] & 4) try_fast = false;           // duplicate-heavy keys: everything again, with another kernel
       else if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
     }
-    if (!try_fast && !use_general && !use_dup && !use_wave) {
-      if (mode == 2 || (mode == 0 && nearly_distinct)) use_general = true; else use_dup = true;
+    if (!try_fast && !use_general && !use_dup && !use_wave && !use_multi) {
+      // the fast kernel refused (repeats in more than FF_LOG buckets) or could not be tried
+      if (mode == 2) use_general = true;
+      else if (mode == 0 && nearly_distinct && host[FS_MISFIT] == 0) use_multi = true;
+      else use_dup = true;
+    }
+    if (use_multi) {
+      BNPK_CHECK(multi());
+      if (host[FS_FLAGS] & 2) use_general = true;
     }
     if (use_wave) BNPK_CHECK(duplicate_aware(true));
     else if (use_dup) BNPK_CHECK(duplicate_aware(false));

@@ -1,0 +1,546 @@
+// Finishing kernel of the sparse k-mer histogram (A9 for k > 13) for keys that are NEARLY all distinct but repeat often
+// enough that most buckets hold a repeat: random 21-mers (0.07 % repeats, ~4 per bucket), reads at a coverage near 1x,
+// metagenomes.  np.unique(return_counts=True) semantics (bionumpy/sequence/count_encoded.py:150-188 extended to k > 8).
+//
+// The fast kernel (finish.hip) ranks such a bucket at full speed but cannot emit it: it knows THAT a key repeats, not
+// how often, and its output positions ("bucket_off[b] minus the duplicates announced so far") only hold while buckets
+// with repeats are rare.  The duplicate-aware tables (finish_wave.hip, finish_dup.hip) overflow on ~5.7 K distinct keys.
+// What was left was the general kernel at 0.13 of the HBM peak.  This kernel is the fast kernel's counting sort and
+// slot-owner ranking with three changes:
+//   * multiplicities.  A slot owner counts, next to the smaller keys on either side, the EQUAL keys on its left: its
+//     place among the bucket's keys with repeats is  s - min(t, s) + smaller + equal-left  (unique per key; equal keys
+//     end up adjacent, first occurrence first).  An owner keeps only the places (two per register); after the barrier
+//     that ends the neighbour reads it takes its keys from their slots again, and after one more barrier it writes
+//     them back at their places: the stage then holds the bucket sorted.  (Keys AND places held across the walk
+//     spilled a hundred registers; so did keeping the keys until the next bucket's barrier behind its rank atomics.)
+//   * run-length emission from the sorted stage, one iteration LATER (while the next bucket takes its ranks and its
+//     bin offsets are scanned — phases that do not touch the stage): position p is a first occurrence iff
+//     stage[p - 1] != stage[p], its count the length of the run behind it (one more LDS read where there is none,
+//     which is nearly everywhere), its output slot the number of first occurrences before it: the owners counted the
+//     repeats per 960-position range (rare LDS atomics) so a wavefront knows where its range starts without another
+//     barrier, and ballots do the rest.  The stores are contiguous runs (the fast kernel's were permuted inside bins).
+//   * exact output positions: every bucket publishes its distinct count (status[b] = D + 1) as soon as it is known,
+//     and the prefix a bucket needs — the distinct keys of ALL earlier buckets — is summed by wavefront 0 from the
+//     status words themselves, chain-free: the workgroup remembers the prefix of its previous bucket and reads the
+//     ~G words in between with up to eight loads per lane in flight while the ranks of the next bucket are taken.
+//     The deferral is what makes that affordable: the fast kernel's experiments with a look-back of the same kind
+//      stalled every round on its slowest workgroup because the sum was needed at once; here it is
+//     needed most of a phase later, and two workgroups share a CU.
+// Buckets are handed out by a ticket counter only (never by blockIdx), so a bucket is always owned by a RUNNING
+// workgroup and the waits cannot deadlock whatever the grid size or whoever else occupies CUs.
+// A bucket with a bin of more than 64 keys (a key repeated that often, or skewed low bits) is not sorted here: its
+// duplicates are counted exactly, it takes its place in the output and goes to finish_sorted_kernel<REDO> by a list.
+#include <algorithm>
+
+#include "finish.h"
+
+namespace {
+
+constexpr int FM_THREADS = 512;
+constexpr int FM_WAVES = FM_THREADS / 64;
+constexpr int FM_ITEMS = 15;
+constexpr int FM_CAP = FM_THREADS * FM_ITEMS;            // 7680 keys
+constexpr int FM_SLICE = 64 * FM_ITEMS;                  // slots owned (and sorted positions emitted) by one wavefront
+constexpr int FM_MAXBITS = 13;
+constexpr int FM_MAXBINS = 1 << FM_MAXBITS;
+constexpr int FM_SCAN_DW = FM_MAXBINS / 2 / FM_THREADS;  // packed bin words scanned by one lane (8)
+constexpr int FM_NEAR = 64;                              // guard slots around the stage
+constexpr int FM_WG = 3;                                 // chunks of 64 slots whose neighbour walks advance together
+constexpr int FM_USUAL = 12;                             // items the usual bucket fills
+#ifndef FM_UNROLL
+#define FM_UNROLL 4
+#endif
+#ifndef FM_EMIT_UNROLL
+#define FM_EMIT_UNROLL 1
+#endif
+#ifndef FM_LB
+#define FM_LB 2                                          // status words per lane in flight: a poll covers 64 * 8 * FM_LB buckets
+#endif
+constexpr unsigned FM_SPIN_LIMIT = 1u << 22;
+static_assert(FM_ITEMS % FM_WG == 0 && FM_USUAL % FM_WG == 0, "whole groups");
+constexpr size_t FM_OFF_STAGE = (size_t)FM_NEAR * 8;
+constexpr size_t FM_OFF_P = FM_OFF_STAGE + (size_t)(FM_CAP + 2 * FM_NEAR) * 8;       // (the run walks read up to 128 slots past a bucket)
+constexpr size_t FM_OFF_WSUM = FM_OFF_P + (((size_t)(FM_MAXBINS + 2) * 2 + 15) & ~(size_t)15);
+constexpr size_t FM_OFF_DUPC = FM_OFF_WSUM + 3 * FM_WAVES * 4;                        // repeats per range of sorted positions
+constexpr size_t FM_OFF_LBS = FM_OFF_DUPC + FM_WAVES * 4;                             // per polled chunk of 64 status words: 0 = incomplete, else sum + 1
+constexpr size_t FM_OFF_SH = FM_OFF_LBS + (size_t)FM_WAVES * FM_LB * 4;
+constexpr size_t FM_LDS = FM_OFF_SH + 8 * 8;
+static_assert(2 * FM_LDS <= 160 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ int64_t fm_uniform(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+  return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int fm_fresh(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+// status[b]: 0 until bucket b's number of distinct keys D is known, then D + 1 (zeroed by the caller).
+// header: [FS_FLAGS] 1 = over-capacity bucket without a pre-counted entry, 2 = a wait gave up; [FS_UNIQUE] distinct keys;
+// [FS_REDO] length of the redo list (ids, output bases); [FS_FTICKET] the ticket counter (a 128-byte line of its own).
+__global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
+    const uint64_t* __restrict__ A, const int64_t* __restrict__ bucket_off, int64_t n_buckets, int sshift, int sbits,
+    unsigned long long* __restrict__ header, unsigned* __restrict__ status, uint64_t* __restrict__ keys_out,
+    int64_t* __restrict__ counts_out, const int64_t* __restrict__ big_table, int n_big,
+    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, unsigned* __restrict__ redo_ids,
+    int64_t* __restrict__ redo_bases) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* stage = reinterpret_cast<uint64_t*>(smem + FM_OFF_STAGE);
+  unsigned* P32 = reinterpret_cast<unsigned*>(smem + FM_OFF_P);
+  const unsigned short* P16 = reinterpret_cast<const unsigned short*>(smem + FM_OFF_P);
+  unsigned* wsum = reinterpret_cast<unsigned*>(smem + FM_OFF_WSUM);             // [0..7] scan, [8..15] repeats, [16..23] longest bins
+  unsigned* dupc = reinterpret_cast<unsigned*>(smem + FM_OFF_DUPC);
+  unsigned* lbs = reinterpret_cast<unsigned*>(smem + FM_OFF_LBS);
+  long long* sh = reinterpret_cast<long long*>(smem + FM_OFF_SH);               // [1] abort, [2] next ticket, [3] prefix of the distinct counts, [7] ... up to which bucket
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned SB = 1u << sbits;
+  const unsigned n_dw = SB > 1 ? SB >> 1 : 1u;
+  const unsigned dwl = n_dw >= FM_THREADS ? n_dw / FM_THREADS : 1u;
+
+  for (unsigned i = tid; i <= n_dw; i += FM_THREADS) P32[i] = 0;
+  if (tid < FM_NEAR) stage[tid - FM_NEAR] = ~0ull;       // guard keys in front of slot 0 (keys are < 2^63)
+  if (tid < FM_WAVES) dupc[tid] = 0;
+  if (tid == 0) sh[1] = 0;
+
+  uint64_t k[FM_ITEMS];
+  struct bucket_t { int64_t lo; int nb; int64_t size; };
+  const int nbk = (int)n_buckets;                        // (< 2^30: the launcher checks)
+  auto fetch_offsets = [&](int bb, int64_t& o0, int64_t& o1) {
+    o0 = 0; o1 = 0;
+    if (bb < nbk) { o0 = bucket_off[bb]; o1 = bucket_off[bb + 1]; }
+  };
+  auto open_bucket = [&](int64_t o0, int64_t o1) {
+    bucket_t x;
+    x.lo = fm_uniform(o0);
+    x.size = fm_uniform(o1) - x.lo;
+    x.nb = x.size > FM_CAP ? 0 : (int)x.size;
+    return x;
+  };
+  auto load_keys = [&](const bucket_t& x) {
+    const uint64_t* Ab = A + x.lo;
+    const int t = fm_fresh(tid);
+    if (x.nb > 0) {
+#pragma unroll
+      for (int q = 0; q < FM_USUAL; ++q) k[q] = __builtin_nontemporal_load(&Ab[(unsigned)min(t + q * FM_THREADS, x.nb - 1)]);
+      if (x.nb > FM_USUAL * FM_THREADS) {
+#pragma unroll
+        for (int q = FM_USUAL; q < FM_ITEMS; ++q) k[q] = __builtin_nontemporal_load(&Ab[(unsigned)min(t + q * FM_THREADS, x.nb - 1)]);
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < FM_ITEMS; ++q) k[q] = 0;
+
+  // ---- tickets: three in flight (ticket -> offsets -> keys -> sort) -------------------------------------------------------
+  if (tid == 0) {
+    sh[4] = (long long)min(atomicAdd(&header[FS_FTICKET], 1ull), (unsigned long long)n_buckets);     // (ids past the end: all "n_buckets")
+    sh[5] = (long long)min(atomicAdd(&header[FS_FTICKET], 1ull), (unsigned long long)n_buckets);
+    sh[6] = (long long)min(atomicAdd(&header[FS_FTICKET], 1ull), (unsigned long long)n_buckets);
+  }
+  __syncthreads();
+  int b = (int)fm_uniform(sh[4]), b_nxt = (int)fm_uniform(sh[5]), b_n2 = (int)fm_uniform(sh[6]);
+  int64_t f0, f1;
+  fetch_offsets(b, f0, f1);
+  bucket_t cur = open_bucket(f0, f1);
+  load_keys(cur);
+  fetch_offsets(b_nxt, f0, f1);
+
+  // ---- the bucket whose emission is pending (sorted in the stage since the last iteration) ---------------------------
+  int prv_kind = 0;                                      // 0 nothing, 1 sorted in the stage, 2 pre-counted, 3 left to the general kernel
+  int prv_b = 0;
+  int64_t prv_src = 0;
+  int prv_nb = 0;
+  unsigned prv_D = 0;
+  unsigned PLp[(FM_ITEMS + 1) / 2];                      // its keys' places in sorted order, two per word (slot order: 64 q + lane of the slice)
+#pragma unroll
+  for (int i = 0; i < (FM_ITEMS + 1) / 2; ++i) PLp[i] = 0;
+  // the pending bucket's keys: from their slots (before a barrier) to their sorted places (behind it)
+  auto take_keys = [&](uint64_t (&X)[FM_ITEMS]) {
+    const uint64_t* mine = stage + wave * FM_SLICE + fm_fresh(lane);
+#pragma unroll
+    for (int q = 0; q < FM_ITEMS; ++q) X[q] = mine[64 * q];
+  };
+  auto put_keys = [&](const uint64_t (&X)[FM_ITEMS]) {
+    const int s0 = wave * FM_SLICE + fm_fresh(lane);
+#pragma unroll
+    for (int q = 0; q < FM_ITEMS; ++q)
+      if (s0 + 64 * q < prv_nb) stage[(PLp[q >> 1] >> ((q & 1) * 16)) & 0xffffu] = X[q];
+  };
+
+  // ---- the prefix of the distinct counts ------------------------------------------------------------------------------
+  // Status words [0, pref_b) are summed up in pref_v (every wavefront keeps the same copy).  A poll covers the next
+  // 64 * FM_WAVES * FM_LB words: wavefront w loads chunks w * FM_LB ... of 64 words (FM_LB registers per lane, in flight
+  // while the ranks are taken), reports per chunk "all there, and their sum" through LDS, and wavefront 0 adds up the
+  // leading chunks that are complete.  What is still missing then — a predecessor that is late, or a workgroup that fell
+  // more than a poll behind — wavefront 0 fetches chunk by chunk on its own.
+  int pref_b = 0;                                        // (32-bit on purpose: hipcc 7.2 drops the VCC -> SCC copy of a uniform 64-bit
+  long long pref_v = 0;                                  //  select whose compare also feeds a branch — scripts/check_scc.py)
+  unsigned lbv[FM_LB];
+#pragma unroll
+  for (int i = 0; i < FM_LB; ++i) lbv[i] = 1u;
+  auto lb_issue = [&](int target) {                  // every wavefront
+    const unsigned* first = status + pref_b + wave * (FM_LB * 64);
+    const int l = fm_fresh(lane);
+#pragma unroll
+    for (int i = 0; i < FM_LB; ++i)
+      lbv[i] = pref_b + wave * (FM_LB * 64) + 64 * i + l < target
+                   ? __hip_atomic_load(first + (l + 64 * i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+  };
+  auto lb_report = [&]() {                               // every wavefront, before a barrier
+#pragma unroll
+    for (int i = 0; i < FM_LB; ++i) {
+      const bool there = __all(lbv[i] != 0u);
+      const unsigned sum = wave_sum(lbv[i] - 1u);
+      if (lane == 0) lbs[wave * FM_LB + i] = there ? sum + 1u : 0u;
+    }
+  };
+  auto lb_finish = [&](int target) -> bool {         // wavefront 0, behind that barrier; false: gave up
+    for (int c = 0; c < FM_WAVES * FM_LB && pref_b < target; ++c) {
+      const unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)lbs[c]);
+      if (v == 0u) break;
+      pref_v += (long long)(v - 1u);
+      pref_b = min(pref_b + 64, target);
+    }
+    unsigned spins = 0;
+    while (pref_b < target) {
+      const unsigned v = pref_b + lane < target ? __hip_atomic_load(status + pref_b + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+      if (__all(v != 0u)) {
+        pref_v += (long long)wave_sum(v - 1u);
+        pref_b = min(pref_b + 64, target);
+      } else {
+        if (++spins > FM_SPIN_LIMIT) return false;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    return true;
+  };
+  // wavefront 0 hands the result to the others (sh[3] base, sh[7] how far the prefix reaches), who take it behind a barrier
+  auto lb_share = [&](bool ok) {
+    if (tid == 0) {
+      sh[3] = pref_v;
+      sh[7] = (long long)pref_b;
+      if (!ok) { sh[1] = 1; atomicOr(&header[FS_FLAGS], 2ull); }
+    }
+  };
+  auto lb_take = [&]() {
+    pref_v = fm_uniform(sh[3]);
+    pref_b = (int)fm_uniform(sh[7]);
+  };
+
+  // ---- emission of the pending bucket at its final place ------------------------------------------------------------
+  auto emit = [&](int64_t base) {
+    if (prv_kind == 1) {
+      const int nbp = prv_nb;
+      unsigned r0 = 0;                                   // first occurrences in the ranges of the wavefronts before this one
+#pragma unroll
+      for (int w = 0; w < FM_WAVES; ++w) {
+        const int in_range = max(0, min(FM_SLICE, nbp - w * FM_SLICE));
+        r0 += w < wave ? (unsigned)in_range - dupc[w] : 0u;
+      }
+      r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)r0);
+      uint64_t* ko = keys_out + base;
+      int64_t* co = counts_out + base;
+      const int l0 = fm_fresh(lane);
+      const uint64_t* mid = stage + wave * FM_SLICE + l0;
+#pragma unroll FM_EMIT_UNROLL
+      for (int c = 0; c < FM_ITEMS; ++c) {
+        if (wave * FM_SLICE + c * 64 >= nbp) break;      // (uniform)
+        const int p = wave * FM_SLICE + c * 64 + l0;
+        const uint64_t key = mid[64 * c], before = mid[64 * c - 1], after = mid[64 * c + 1];
+        const bool first = p < nbp && key != before;
+        unsigned cnt = 1;
+        bool alive = first && after == key;
+        if (__any(alive)) {                              // a repeat in these 64 positions: walk the runs
+          cnt += alive ? 1u : 0u;
+          for (int d = 2; d <= FM_NEAR; ++d) {
+            alive = alive && mid[64 * c + d] == key;
+            if (!__any(alive)) break;
+            cnt += alive ? 1u : 0u;
+          }
+        }
+        const unsigned long long m = __ballot(first);
+        const unsigned r = r0 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (first) {
+          __builtin_nontemporal_store(key, &ko[r]);
+          __builtin_nontemporal_store((int64_t)cnt, &co[r]);
+        }
+        r0 += (unsigned)__popcll(m);
+      }
+    } else if (prv_kind == 2) {
+      uint64_t* ko = keys_out + base;
+      int64_t* co = counts_out + base;
+      for (unsigned i = (unsigned)fm_fresh(tid); i < prv_D; i += FM_THREADS) {
+        ko[i] = big_keys[prv_src + i];
+        co[i] = big_counts[prv_src + i];
+      }
+    } else if (prv_kind == 3) {
+      if (tid == 0) {
+        const unsigned long long at = atomicAdd(&header[FS_REDO], 1ull);
+        redo_ids[at] = (unsigned)prv_b;
+        redo_bases[at] = base;
+      }
+    }
+    if (prv_kind != 0 && prv_b == nbk - 1 && tid == 0) header[FS_UNIQUE] = (unsigned long long)(base + (int64_t)prv_D);
+  };
+  auto publish = [&](int bb, unsigned D) {           // one lane
+    __hip_atomic_store(status + bb, D + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
+  __syncthreads();
+  for (; b < nbk;) {
+    const bucket_t nxt = open_bucket(f0, f1);            // bucket b_nxt (offsets fetched an iteration ago)
+    fetch_offsets(b_n2, f0, f1);
+    unsigned long long tk = 0;
+    if (tid == 0) tk = atomicAdd(&header[FS_FTICKET], 1ull);
+    int b_n3 = 0;
+    const int nb = cur.nb;
+    if (prv_kind != 0) lb_issue(prv_b);                  // (uniform) in flight until the ranks are taken
+    if (nb == 0) {
+      // ---- an empty bucket, or a heavy-hitter bucket the caller counted beforehand: nothing to sort ------------------
+      unsigned D = 0;
+      int64_t src = 0;
+      int kind = 0;
+      if (cur.size > 0) {
+        int lo_i = 0, hi_i = n_big;
+        while (lo_i < hi_i) {
+          const int mid_i = (lo_i + hi_i) >> 1;
+          if (big_table[3 * mid_i] < b) lo_i = mid_i + 1; else hi_i = mid_i;
+        }
+        if (lo_i < n_big && big_table[3 * lo_i] == b) {
+          D = (unsigned)fm_uniform(big_table[3 * lo_i + 1]);
+          src = fm_uniform(big_table[3 * lo_i + 2]);
+          kind = 2;
+        } else if (tid == 0) {
+          atomicOr(&header[FS_FLAGS], 1ull);
+        }
+      }
+      if (tid == 0) publish(b, D);
+      if (prv_kind != 0) lb_report();
+      if (tid == 0) sh[2] = (long long)min(tk, (unsigned long long)n_buckets);
+      __syncthreads();
+      if (wave == 0) lb_share(prv_kind == 0 || lb_finish(prv_b));
+      __syncthreads();
+      b_n3 = (int)fm_uniform(sh[2]);
+      if (fm_uniform(sh[1])) return;
+      lb_take();
+      emit(pref_v);
+      __syncthreads();                                   // the stage and the repeat counters are free
+      if (tid < FM_WAVES) dupc[tid] = 0;
+      prv_kind = (kind == 2 || b == nbk - 1) ? (kind == 2 ? 2 : 4) : 0;   // (4: nothing to write, but the last bucket reports the total)
+      prv_b = b; prv_D = D; prv_src = src; prv_nb = 0;
+      load_keys(nxt);
+      __syncthreads();
+    } else {
+      // ---- counting sort on the next sbits bits (as in finish_fast_kernel) ------------------------------------------------
+      unsigned rb[FM_ITEMS];
+      const bool large = nb > FM_USUAL * FM_THREADS;
+      {
+        const int t0 = fm_fresh(tid);
+        unsigned old[FM_ITEMS];
+#pragma unroll
+        for (int q = 0; q < FM_USUAL; ++q) {
+          const unsigned bin = (unsigned)(k[q] >> sshift) & (SB - 1);
+          rb[q] = bin;
+          old[q] = atomicAdd(&P32[bin >> 1], (t0 + q * FM_THREADS < nb ? 1u : 0u) << ((bin & 1u) * 16u));
+        }
+        if (large) {
+#pragma unroll
+          for (int q = FM_USUAL; q < FM_ITEMS; ++q) {
+            const unsigned bin = (unsigned)(k[q] >> sshift) & (SB - 1);
+            rb[q] = bin;
+            old[q] = atomicAdd(&P32[bin >> 1], (t0 + q * FM_THREADS < nb ? 1u : 0u) << ((bin & 1u) * 16u));
+          }
+        } else {
+#pragma unroll
+          for (int q = FM_USUAL; q < FM_ITEMS; ++q) { rb[q] = 0; old[q] = 0; }
+        }
+#pragma unroll
+        for (int q = 0; q < FM_ITEMS; ++q) rb[q] |= __builtin_amdgcn_ubfe(old[q], (rb[q] & 1u) * 16u, 16u) << 13;
+      }
+      if (prv_kind != 0) lb_report();                    // (uniform)
+      __syncthreads();                                   // (1) every rank is taken
+      bool short_bins;
+      int t_walk;
+      {
+        unsigned c[FM_SCAN_DW], sum = 0, longest = 0;
+        const unsigned t1 = (unsigned)fm_fresh(tid);
+#pragma unroll
+        for (int j = 0; j < FM_SCAN_DW; ++j) {
+          const unsigned w = t1 * dwl + j;
+          c[j] = ((unsigned)j < dwl && w < n_dw) ? P32[w] : 0u;
+          sum += (c[j] & 0xffffu) + (c[j] >> 16);
+          longest = max(longest, max(c[j] & 0xffffu, c[j] >> 16));
+        }
+        const unsigned inc = wave_inclusive_scan(sum);
+        longest = wave_max(longest);
+        if (lane == 63) { wsum[wave] = inc; wsum[2 * FM_WAVES + wave] = longest; }
+        // wavefront 0: the output base of the pending bucket
+        if (wave == 0) lb_share(prv_kind == 0 || lb_finish(prv_b));
+        __syncthreads();                                 // (2)
+        unsigned run = inc - sum, longs = 0;
+#pragma unroll
+        for (int w = 0; w < FM_WAVES; ++w) {
+          run += w < wave ? wsum[w] : 0u;
+          longs = max(longs, wsum[2 * FM_WAVES + w]);
+        }
+        t_walk = __builtin_amdgcn_readfirstlane((int)longs) - 1;
+        short_bins = t_walk < FM_NEAR;
+#pragma unroll
+        for (int j = 0; j < FM_SCAN_DW; ++j) {
+          const unsigned w = t1 * dwl + j;
+          if ((unsigned)j < dwl && w < n_dw) {
+            const unsigned c0 = c[j] & 0xffffu;
+            P32[w] = run | ((run + c0) << 16);
+            run += c0 + (c[j] >> 16);
+          }
+        }
+        if (tid == 0) reinterpret_cast<unsigned short*>(P32)[SB] = (unsigned short)nb;
+      }
+      if (fm_uniform(sh[1])) return;                     // (uniform) a wait gave up: the caller falls back
+      lb_take();
+      emit(pref_v);                                      // the previous bucket leaves the stage
+      __syncthreads();                                   // (3) the bin offsets are in place, the stage is free
+      {
+        const int t2 = fm_fresh(tid);
+        unsigned slot[FM_ITEMS];
+#pragma unroll
+        for (int q = 0; q < FM_USUAL; ++q) slot[q] = P16[rb[q] & 0x1fffu] + (rb[q] >> 13);
+#pragma unroll
+        for (int q = 0; q < FM_USUAL; ++q)
+          if (t2 + q * FM_THREADS < nb) stage[slot[q]] = k[q];
+        if (large) {
+#pragma unroll
+          for (int q = FM_USUAL; q < FM_ITEMS; ++q) slot[q] = P16[rb[q] & 0x1fffu] + (rb[q] >> 13);
+#pragma unroll
+          for (int q = FM_USUAL; q < FM_ITEMS; ++q)
+            if (t2 + q * FM_THREADS < nb) stage[slot[q]] = k[q];
+        }
+      }
+      if (wave >= FM_WAVES - 2) stage[nb + (wave - (FM_WAVES - 2)) * 64 + fm_fresh(lane)] = ~0ull;   // guard keys behind the bucket
+      if (tid < FM_WAVES) dupc[tid] = 0;
+      if (tid == 0) sh[2] = (long long)min(tk, (unsigned long long)n_buckets);
+      load_keys(nxt);
+      __syncthreads();                                   // (4) the keys are grouped by bin
+      b_n3 = (int)fm_uniform(sh[2]);
+      // ---- slot owners: place = s - min(t, s) + smaller keys within t on either side + equal keys within t on the left
+      unsigned ndup = 0;
+      const int l3 = fm_fresh(lane);
+      const int slice0 = wave * FM_SLICE;
+      int kind = 1;
+      if (short_bins) {
+        for (unsigned i = (unsigned)fm_fresh(tid); i <= n_dw; i += FM_THREADS) P32[i] = 0;
+#pragma unroll
+        for (int i = 0; i < (FM_ITEMS + 1) / 2; ++i) PLp[i] = 0;
+#pragma unroll
+        for (int c0 = 0; c0 < FM_ITEMS; c0 += FM_WG) {
+          if (slice0 + c0 * 64 < nb) {
+            uint64_t x[FM_WG];
+            unsigned cnt[FM_WG], eq[FM_WG];
+            const int sl0 = slice0 + c0 * 64 + l3;
+            const uint64_t* mid = stage + sl0;
+#pragma unroll
+            for (int u = 0; u < FM_WG; ++u) { x[u] = mid[64 * u]; cnt[u] = 0; eq[u] = 0; }
+#pragma unroll FM_UNROLL
+            for (int d = 1; d <= t_walk; ++d) {
+              uint64_t y[FM_WG], z[FM_WG];
+#pragma unroll
+              for (int u = 0; u < FM_WG; ++u) { y[u] = mid[64 * u - d]; z[u] = mid[64 * u + d]; }
+#pragma unroll
+              for (int u = 0; u < FM_WG; ++u) {
+                cnt[u] += (y[u] < x[u] ? 1u : 0u) + (z[u] < x[u] ? 1u : 0u);
+                eq[u] += y[u] == x[u] ? 1u : 0u;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < FM_WG; ++u) {
+              const int s = sl0 + 64 * u;
+              const unsigned place = (unsigned)(s - min(t_walk, s)) + cnt[u] + eq[u];
+              PLp[(c0 + u) >> 1] |= (place & 0xffffu) << (((c0 + u) & 1) * 16);
+              const bool rep = eq[u] != 0 && s < nb;
+              ndup += rep ? 1u : 0u;
+              if (rep) atomicAdd(&dupc[place / FM_SLICE], 1u);
+            }
+          }
+        }
+      } else {
+        // a bin longer than a chunk: only the exact number of repeats is taken here; the general kernel sorts the bucket
+        kind = 3;
+#pragma unroll 1
+        for (int c = 0; c < FM_ITEMS; ++c) {
+          const int s = slice0 + c * 64 + l3;
+          if (slice0 + c * 64 >= nb) break;
+          unsigned a = 0;
+          uint64_t xv = 0;
+          if (s < nb) {
+            xv = stage[s];
+            a = (unsigned)s - P16[(unsigned)(xv >> sshift) & (SB - 1)];
+          }
+          bool is_dup = false;
+          for (unsigned d = 1; __any(d <= a && !is_dup); ++d)
+            if (d <= a && !is_dup && stage[s - (int)d] == xv) is_dup = true;
+          ndup += is_dup ? 1u : 0u;
+        }
+      }
+      ndup = wave_sum(ndup);
+      if (lane == 0) wsum[FM_WAVES + wave] = ndup;
+      __syncthreads();                                   // (5) every neighbour has been read
+      unsigned dups = 0;
+#pragma unroll
+      for (int w = 0; w < FM_WAVES; ++w) dups += wsum[FM_WAVES + w];
+      dups = (unsigned)__builtin_amdgcn_readfirstlane((int)dups);
+      const unsigned D = (unsigned)nb - dups;
+      if (tid == 0) publish(b, D);
+      prv_kind = kind; prv_b = b; prv_D = D; prv_nb = nb; prv_src = 0;
+      if (short_bins) {
+        // the bucket into sorted order: every owner takes its keys from their slots again (nobody holds them: keys and
+        // places kept across the walk spilled a hundred registers) and, behind a barrier, writes them at their places
+        uint64_t X[FM_ITEMS];
+        take_keys(X);
+        __syncthreads();                                 // (6)
+        put_keys(X);
+      } else {
+        for (unsigned i = (unsigned)fm_fresh(tid); i <= n_dw; i += FM_THREADS) P32[i] = 0;
+        __syncthreads();
+      }
+    }
+    cur = nxt;
+    b = b_nxt;
+    b_nxt = b_n2;
+    b_n2 = b_n3;
+  }
+  // ---- the last pending bucket ------------------------------------------------------------------------------------------
+  if (prv_kind != 0) {
+    lb_issue(prv_b);
+    lb_report();
+    __syncthreads();
+    if (wave == 0) lb_share(lb_finish(prv_b));
+    __syncthreads();
+    if (fm_uniform(sh[1])) return;
+    lb_take();
+    emit(pref_v);
+  }
+}
+
+}  // namespace
+
+int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
+                             unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
+                             const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
+                             unsigned* redo_ids, int64_t* redo_bases, hipStream_t s) {
+  if (n_buckets >= (1ll << 30)) return BNPK_ERR_RANGE;
+  if (!ctx->finish_multi_ready) {
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS));
+    int per_cu = 0;
+    BNPK_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)finish_multi_kernel, FM_THREADS, FM_LDS));
+    ctx->finish_multi_grid = ctx->compute_units * std::max(1, per_cu);
+    ctx->finish_multi_ready = true;
+  }
+  const int sbits = std::min(low_bits, FM_MAXBITS), sshift = low_bits - sbits;
+  const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->finish_multi_grid);
+  hipLaunchKernelGGL(finish_multi_kernel, dim3(grid), dim3(FM_THREADS), FM_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
+                     header, status, keys_out, counts_out, big_table, n_big, big_keys, big_counts, redo_ids, redo_bases);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}

@@ -111,7 +111,9 @@ int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes,
  *                hold), other keys the fast kernel and, if it gives up, the cascade without its first stage;
  *                1 = the general kernel only; 2 = the fast kernel + redo list (general kernel if it gives up);
  *                3 = the workgroup-per-bucket duplicate-aware kernel (+ general kernel for what it hands back);
- *                4 = the whole cascade.  Same results in every mode.
+ *                4 = the whole cascade; 5 = the fast kernel's ranking with multiplicities and exact output positions
+ *                (finish_multi.hip; what mode 0 takes when the fast kernel refuses keys that are nearly all distinct),
+ *                + general kernel for buckets with a bin of more than 64 keys.  Same results in every mode.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
  * Unknown names and values out of range return BNPK_ERR_ARG. */

@@ -10,7 +10,7 @@ k = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 reads = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
 ops = get_ops(); dev = Device.get()
 text = ops.synth_fastq(reads, 150, 20260925, 0, 0, 0)
-for mode in (0, 1, 2, 3, 4):
+for mode in [int(m) for m in (sys.argv[3].split(',') if len(sys.argv) > 3 else '0,1,2,3,4,5'.split(','))]:
     assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
     (keys, counts), st = fastq_kmer_histogram(text, k); del keys, counts
     dev.prof_enable(True); dev.prof_reset()

@@ -14,7 +14,7 @@ from bionumpy_amd.device import HArray
 pytestmark = pytest.mark.gpu
 
 M62 = (1 << 62) - 1
-MODES = (1, 2, 3, 4, 0)         # general / fast + redo / workgroup-per-bucket duplicate-aware / whole cascade / chosen per call
+MODES = (1, 2, 3, 4, 5, 0)      # general / fast + redo / workgroup-per-bucket duplicate-aware / whole cascade / fast with multiplicities / chosen per call
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +48,12 @@ def _cases():
     yield "every key ~6 times", _genome_like(rng, n, 6)
     yield "every key ~2 times", _genome_like(rng, n, 2)
     yield "distinct", rng.integers(0, 1 << 62, size=n, dtype=np.int64)
+    # nearly distinct, but every bucket holds a few repeats (random 21-mers, reads at ~1x coverage): the multiplicity-counting
+    # fast kernel's regime — pairs, triples and a few longer runs on top of distinct keys
+    d = rng.integers(0, 1 << 62, size=n, dtype=np.int64)
+    yield "a few repeats per bucket", rng.permutation(np.concatenate([d, d[:4000], d[:1500], d[:300], d[:300], np.repeat(d[5000:5040], 20)]))
+    yield "every key 1-3 times", rng.permutation(np.concatenate([d[:n // 2], d[:n // 4], d[:n // 8]]))
+    yield "runs of 2..70 copies", rng.permutation(np.repeat(d[:30000], rng.integers(2, 71, size=30000)))
     yield "read errors", np.concatenate([_genome_like(rng, 3 * n // 4, 60), rng.integers(0, 1 << 62, size=n // 4, dtype=np.int64)])
     yield "low bits", (rng.integers(0, 1 << 12, size=n, dtype=np.int64) << 50) | rng.integers(0, 3000, size=n, dtype=np.int64)
     yield "clusters", (rng.integers(0, 1 << 12, size=n, dtype=np.int64) << 50) | (rng.integers(0, 8, size=n, dtype=np.int64) << 44) \
