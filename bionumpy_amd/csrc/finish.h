@@ -41,6 +41,9 @@ int bnpk_finish_wave_launch(bnpk_ctx* ctx, bool probe, int64_t probe_buckets, ui
 // header's first FS_FAST words zeroed.  Buckets it leaves to finish_sorted_kernel<REDO> (a bin of more than 64 keys) are
 // listed in redo_ids / redo_bases (header[FS_REDO]); header[FS_UNIQUE] = distinct keys; flag 2 = a wait gave up (the
 // output is incomplete: the caller takes another kernel).  Buckets over 7680 keys must be pre-counted (big_table).
+// bytes of the parking ring for `grid` workgroups: taken from the ctx's scratch arena by the launcher (a caller that holds a
+// pointer into the arena asks for at least this much beforehand, so that the arena does not move under it)
+int64_t bnpk_finish_multi_park_bytes(int grid);
 int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                              unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
                              const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,

@@ -1150,7 +1150,11 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
   bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
   bool use_multi = mode == 5;
   bool nearly_distinct = false;
-  if (!use_general) BNPK_CHECK(bnpk_scratch(ctx, bnpk_scan_scratch_bytes(n_buckets), &scan_scratch, (hipStream_t)stream));
+  // (one arena: the scan partials of the fast / duplicate-aware paths, or the parking ring of the multiplicity kernel —
+  // never both at a time; asked for together so that the arena does not move between them)
+  if (!use_general)
+    BNPK_CHECK(bnpk_scratch(ctx, std::max<size_t>(bnpk_scan_scratch_bytes(n_buckets), (size_t)bnpk_finish_multi_park_bytes(2 * ctx->compute_units)),
+                            &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
     if (mode == 0 || try_fast || use_multi) {

@@ -548,7 +548,8 @@ class HipOps:
         return int(n_runs.value), tile_off
 
     # -- sparse histogram: MSD radix partition (write-combining scatter) + in-LDS finishing sort -------------
-    FINISH_TARGET = 6000          # average bucket size the plan aims for (bnpk_finish_capacity() is 8192)
+    FINISH_TARGET = 6500          # average bucket size the plan aims for (the fast finishing kernels take 7680 keys, the general one 8192;
+                                  # random keys: sigma = 80, so buckets of 6500 +- 400 fit)
 
     @classmethod
     def radix_plan(cls, n, key_bits, done=0):
@@ -695,6 +696,8 @@ class HipOps:
                                                  ptr(keys_out), ptr(counts), ptr(state), ptr(table),
                                                  0 if table is None else table.numel() // 3, ptr(big_keys), ptr(big_counts),
                                                  C.byref(n_unique), C.byref(overflow), self._s()))
+                if self.keep_finish_state:               # (experiments: the header words of the finishing kernels)
+                    self.last_finish_state = state[:128].cpu().numpy()
                 if overflow.value:                       # every bucket was checked against the capacity above
                     raise RuntimeError("bnpk_finish_sorted reported an overflow on buckets that fit")
                 return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
@@ -707,6 +710,7 @@ class HipOps:
             keys_out, counts = out_keys[pos:pos + d], out_counts[pos:pos + d]
         return HArray(dev=keys_out), HArray(dev=counts)
 
+    keep_finish_state = False
     MAX_PRECOUNTED = 256          # buckets over the finishing kernel's capacity that are counted one by one
 
     def _count_by_sorting(self, work, key_bits):
