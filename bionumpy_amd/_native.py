@@ -65,11 +65,15 @@ SIGNATURES = {
     "bnpk_copy_d2h_async": (_int, [_p, _p, C.c_size_t, _p]),
     "bnpk_pread_parallel": (_int, [_p, _int, _i64, _p, _i64, _int, _i64, _p, _p, C.POINTER(_i64)]),
     "bnpk_stream_sync": (_int, [_p]),
+    "bnpk_fetch_i64": (_int, [_p, _p, _i64, C.POINTER(_i64), _p]),
     "bnpk_scan_tiles": (_i64, [_i64]),
     "bnpk_byte_census": (_int, [_p, _p, _i64, _u8, _p, _p]),
     "bnpk_byte_positions": (_int, [_p, _p, _i64, _u8, _p, _i64, _p, _p]),
     "bnpk_validate_entries": (_int, [_p, _p, _p, _i64, _int, _u8, _int, _p, _p]),
     "bnpk_field_table": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
+    "bnpk_window_cuts_words": (_i64, [_int]),
+    "bnpk_window_cuts": (_int, [_p, _p, _p, _i64, _int, _i64, _i64, _int, _i64, _i64, _int, _p, _p]),
+    "bnpk_rebase_lines": (_int, [_p, _p, _i64, _p, _int, _p, _p]),
     "bnpk_fastq_tiles": (_i64, [_i64]),
     "bnpk_fastq_table_words": (_i64, [_i64]),
     "bnpk_fastq_census": (_int, [_p, _p, _i64, _int, _int, _p, C.POINTER(_i64), _p]),

@@ -1,5 +1,6 @@
 // Context, diagnostics, host staging and per-kernel timers of the bnpk C-ABI (include/bnpk.h).
 #include <errno.h>
+#include <string.h>
 #include <unistd.h>
 
 #include <thread>
@@ -48,6 +49,7 @@ void bnpk_ctx_destroy(bnpk_ctx* ctx) {
   for (auto& p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
   if (ctx->scratch_event) (void)hipEventDestroy(ctx->scratch_event);
   delete ctx;
 }
@@ -208,6 +210,18 @@ int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stre
   if (!h_dst || !d_src) return BNPK_ERR_ARG;
   if (hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess)
     return BNPK_ERR_HIP;
+  return BNPK_OK;
+}
+
+int bnpk_fetch_i64(bnpk_ctx* ctx, const int64_t* d_src, int64_t n, int64_t* h_dst, void* stream) {
+  if (!ctx || n < 0 || n > 512) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_src || !h_dst) return BNPK_ERR_ARG;
+  if (!ctx->mailbox) BNPK_HIP(ctx, hipHostMalloc(&ctx->mailbox, 512 * sizeof(int64_t), hipHostMallocDefault));
+  hipStream_t s = (hipStream_t)stream;
+  BNPK_HIP(ctx, hipMemcpyAsync(ctx->mailbox, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  memcpy(h_dst, ctx->mailbox, (size_t)n * 8);
   return BNPK_OK;
 }
 

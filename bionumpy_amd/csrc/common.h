@@ -46,6 +46,7 @@ struct bnpk_ctx {
   int finish_wave_grid = 0;
   bool finish_multi_ready = false;  // finish_multi.hip
   int finish_multi_grid = 0;
+  void* mailbox = nullptr;       // page-locked words the host scalars of a call come back through (bnpk_fetch_i64)
   int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
 };
 

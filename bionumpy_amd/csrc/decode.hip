@@ -1,6 +1,8 @@
 // FASTQ / FASTA chunk decode on gfx950: newline census + ordered compaction (A2), entry validation (A3),
 // field table (A4/A5).  All of it is byte/integer work bound by the HBM read of the raw chunk; every
 // wavefront streams contiguous 1 KiB pieces (16 B per lane) and ranks its matches with lane shuffles.
+#include <algorithm>
+
 #include "common.h"
 #include "scan.h"
 
@@ -142,6 +144,106 @@ __global__ void field_table_kernel(const uint8_t* __restrict__ buf, const int64_
   }
 }
 
+
+// ---- the chunks of a reader with small windows, cut out of one big batch -------------------------------------------------
+// out: [0] rows written, [1] status (1 = a window without a complete entry grew past max_chunk), [2] the window end of the last
+// chunk cut (what the reference's reader would hold as its left-over is [end of that chunk, this)), [3] entries consumed;
+// rows from word 4 on: {entries up to and including the chunk, end byte of the chunk, has_cr of the chunk, window end}.
+// One lane walks the windows (they depend on each other); the newline table is searched by all 64 lanes at once
+// (a 64-ary search: three or four rounds of one load per lane instead of twenty dependent loads).
+__device__ __forceinline__ int64_t wc_lower_bound(const int64_t* __restrict__ nl, int64_t n, int64_t value) {
+  // number of newlines at a position < value
+  int64_t lo = 0, hi = n;                                // the answer lies in [lo, hi]
+  while (hi - lo > 64) {
+    const int64_t step = (hi - lo + 63) / 64;
+    const int64_t at = lo + (int64_t)(lane_id() + 1) * step - 1;          // lane l probes the end of its piece
+    const bool below = at < hi && nl[at] < value;
+    const unsigned long long m = __ballot(below);
+    const int pieces = __popcll(m);                      // leading pieces that lie entirely below `value`
+    const int64_t new_lo = lo + (int64_t)pieces * step;
+    const int64_t new_hi = min(hi, new_lo + step);
+    lo = min(new_lo, hi);
+    hi = new_hi < lo ? lo : new_hi;
+  }
+  const int64_t at = lo + lane_id();
+  const bool below = at < hi && nl[at] < value;
+  return lo + __popcll(__ballot(below));
+}
+
+__global__ __launch_bounds__(64) void window_cuts_kernel(const uint8_t* __restrict__ buf, const int64_t* __restrict__ nl,
+                                                         int64_t n_lines, int lpe, int64_t window, int64_t avail, int finished,
+                                                         int64_t first_held, int64_t max_chunk, int max_cuts,
+                                                         int64_t* __restrict__ out) {
+  int64_t j = 0, s = 0, held = first_held, last_end = first_held, rows = 0, status = 0;
+  const int64_t n_entries = n_lines / lpe;
+  while (rows < max_cuts && j < n_entries) {
+    // the reference reads min_chunk_size - held new bytes (min_chunk_size if it holds that much already): parser.py:117-120
+    int64_t w_end = s + (held >= window ? held + window : window);
+    int64_t j_end = j;
+    bool stop = false;
+    while (true) {
+      if (w_end > avail) {
+        if (!finished) { stop = true; break; }           // the window reaches past what is here: the next batch's business
+        w_end = avail;
+      }
+      if (max_chunk > 0 && w_end - s > max_chunk) { status = 1; stop = true; break; }
+      j_end = wc_lower_bound(nl, n_lines, w_end) / lpe;
+      if (j_end > j || w_end >= avail) break;
+      w_end += window;                                   // no complete entry yet: min_chunk_size more (parser.py:128-131)
+    }
+    if (stop || j_end <= j) break;
+    const int64_t e = nl[j_end * lpe - 1] + 1;
+    // _modify_for_carriage_return (one_line_buffer.py:176-182) on this chunk: the first lpe header lines
+    int has_cr = 0;
+    if (nl[j * lpe] - s >= 1) {
+      for (int r = 0; r < lpe && j + r < j_end; ++r) {
+        const int64_t le = nl[(j + r) * lpe];
+        if (le - s >= 1 && buf[le - 1] == '\r') has_cr = 1;
+      }
+    }
+    if (lane_id() == 0) {
+      out[4 + 4 * rows] = j_end;
+      out[5 + 4 * rows] = e;
+      out[6 + 4 * rows] = has_cr;
+      out[7 + 4 * rows] = w_end;
+    }
+    ++rows;
+    held = w_end - e;
+    last_end = w_end;
+    s = e;
+    j = j_end;
+  }
+  if (lane_id() == 0) {
+    out[0] = rows;
+    out[1] = status;
+    out[2] = last_end;
+    out[3] = j;
+  }
+}
+
+// out[i] = nl[i] - (start byte of the chunk that holds line i), for the lines of the chunks listed in `cuts` (as above)
+__global__ __launch_bounds__(BNPK_BLOCK) void rebase_lines_kernel(const int64_t* __restrict__ nl, const int64_t* __restrict__ cuts,
+                                                                  int lpe, int64_t* __restrict__ out) {
+  __shared__ int64_t ends[256], starts[256];
+  const int rows = (int)cuts[0];
+  for (int i = threadIdx.x; i < rows; i += blockDim.x) {
+    ends[i] = cuts[4 + 4 * i] * lpe;                     // lines up to and including chunk i
+    starts[i] = i == 0 ? 0 : cuts[5 + 4 * (i - 1)];
+  }
+  __syncthreads();
+  const int64_t n = rows ? ends[rows - 1] : 0;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    int lo = 0, hi = rows - 1;                           // first chunk whose lines end behind i
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ends[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    out[i] = nl[i] - starts[lo];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -214,6 +316,36 @@ int bnpk_field_table(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newli
   bnpk_timer t(ctx, "field_table", s);
   hipLaunchKernelGGL(field_table_kernel, dim3(grid_for(ceil_div(n_entries, 256))), dim3(256), 0, s, d_buf,
                      d_newlines, n_entries, lines_per_entry, field, line_offset, strip_cr, d_starts, d_lens);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int64_t bnpk_window_cuts_words(int max_cuts) { return 4 + 4 * (int64_t)std::max(max_cuts, 0); }
+
+int bnpk_window_cuts(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines, int64_t n_lines, int lines_per_entry,
+                     int64_t window, int64_t avail, int finished, int64_t first_held, int64_t max_chunk, int max_cuts,
+                     int64_t* d_out, void* stream) {
+  if (!ctx || !d_out || lines_per_entry < 1 || n_lines < 0 || n_lines % lines_per_entry != 0 || window < 1 || avail < 0 ||
+      first_held < 0 || max_cuts < 1 || max_cuts > 256)
+    return BNPK_ERR_ARG;
+  if (n_lines > 0 && (!d_buf || !d_newlines)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "window_cuts", s);
+  hipLaunchKernelGGL(window_cuts_kernel, dim3(1), dim3(64), 0, s, d_buf, d_newlines, n_lines, lines_per_entry, window, avail,
+                     finished, first_held, max_chunk, max_cuts, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_rebase_lines(bnpk_ctx* ctx, const int64_t* d_newlines, int64_t n_lines, const int64_t* d_cuts, int lines_per_entry,
+                      int64_t* d_out, void* stream) {
+  if (!ctx || n_lines < 0 || lines_per_entry < 1) return BNPK_ERR_ARG;
+  if (n_lines == 0) return BNPK_OK;
+  if (!d_newlines || !d_cuts || !d_out) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "rebase_lines", s);
+  hipLaunchKernelGGL(rebase_lines_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_lines, BNPK_BLOCK), 2048))), dim3(BNPK_BLOCK), 0, s,
+                     d_newlines, d_cuts, lines_per_entry, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

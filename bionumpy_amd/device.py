@@ -51,6 +51,8 @@ class Device:
         ctx = C.c_void_p()
         check(lib.bnpk_ctx_create(self.index, C.byref(ctx)))
         self.ctx = ctx
+        self._raw_stream = None
+        self._tindex = self.index
 
     @classmethod
     def get(cls):
@@ -66,7 +68,17 @@ class Device:
 
     # -- streams / memory --------------------------------------------------------------------
     def stream(self):
-        return C.c_void_p(torch().cuda.current_stream(self.tdev).cuda_stream)
+        # torch's current stream of this device as a raw handle (the C-level getter where torch has it: a launch asks for the
+        # stream every time — the caller may have switched it — and the Stream object of the public call costs 4 us)
+        raw = self._raw_stream
+        if raw is None:
+            t = torch()
+            raw = getattr(t._C, "_cuda_getCurrentRawStream", None)
+            if raw is None:
+                raw = lambda index: t.cuda.current_stream(index).cuda_stream
+            self._raw_stream = raw
+            self._tindex = self.tdev.index if self.tdev.index is not None else t.cuda.current_device()
+        return C.c_void_p(raw(self._tindex))
 
     def empty(self, n, dtype):
         return torch().empty(int(n), dtype=_torch_dtype(dtype), device=self.tdev)

@@ -53,7 +53,10 @@ class NpDataclassReader:
                 if len(wrapped) == 0:
                     return
                 yield wrapped
-        return NpDataclassStream(chunks(), dataclass=self._reader._buffer_type.dataclass)
+        def again(bigger):                                # (streams.NpDataclassStream._coalesced: before anything was read)
+            return self.read_chunks(max(bigger, min_chunk_size), max_chunk_size)._stream
+        return NpDataclassStream(chunks(), dataclass=self._reader._buffer_type.dataclass,
+                                 rebatch=again if max_chunk_size is None else None)
 
     def __iter__(self):
         return self.read_chunks()

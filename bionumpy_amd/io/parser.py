@@ -44,6 +44,13 @@ _FRONT = 4 << 20                   # room kept in front of a read-ahead for the 
 _EARLY_UPLOAD = os.environ.get("BNPK_EARLY_UPLOAD", "1") != "0"     # the read-ahead thread starts the batch's upload too
 _READ_DEPTH = int(os.environ.get("BNPK_READ_DEPTH", 2))          # batches read ahead under read_chunks (1 or 2)
 _PIECE = int(os.environ.get("BNPK_PIECE_MB", 16)) << 20                   # ... piece by piece, while the reading threads are still at work
+# read_chunks with the reference's small windows (its default is 5 MB): the file still comes in, goes up and is scanned in
+# batches of _WINDOW_BATCH bytes, and the chunks are cut out of the scanned batch on the device (bnpk_window_cuts) — the same
+# chunks, entry for entry, as a reader that reads, uploads and scans 5 MB at a time
+_WINDOWED = os.environ.get("BNPK_WINDOWED", "1") != "0"
+_WINDOW_MIN = int(os.environ.get("BNPK_WINDOW_MIN", 256 << 10))          # windows below this size keep the plain loop
+_WINDOW_BATCH = int(os.environ.get("BNPK_WINDOW_BATCH_MB", 128)) << 20
+_WINDOW_CUTS = 200                                                       # chunks cut out of one batch at most (bnpk_window_cuts takes 256)
 
 
 class _Staging:
@@ -162,6 +169,7 @@ class NumpyFileReader:
         self._staging = None
         self._early = None                 # device side of the read-ahead (_EarlyUpload)
         self._ahead_threads = []
+        self._window_held = 0              # windowed read_chunks: bytes the reference's reader would hold behind the last chunk
         self.n_bytes_read = 0
         self.n_lines_read = 0
 
@@ -210,6 +218,12 @@ class NumpyFileReader:
         if _READ_AHEAD and min_chunk_size >= _BIG and self._plain_file() and not self._stream_mode:
             yield from self._read_chunks_ahead(min_chunk_size, max_chunk_size)
             return
+        if (_READ_AHEAD and _WINDOWED and _WINDOW_MIN <= min_chunk_size < _BIG and self._plain_file() and not self._stream_mode
+                and self._marker is None and hasattr(self._buffer_type, "n_lines_per_entry")
+                and not getattr(get_ops(), "host_only", False)):
+            batch = max(min(_WINDOW_BATCH, _WINDOW_CUTS * min_chunk_size), 2 * min_chunk_size)
+            yield from self._read_chunks_ahead(batch, max_chunk_size, window=min_chunk_size)
+            return
         while not self._is_finished:
             chunk = self.read_chunk(min_chunk_size, max_chunk_size)
             if chunk is None:
@@ -226,11 +240,15 @@ class NumpyFileReader:
         except (OSError, ValueError):
             return False
 
-    def _read_chunks_ahead(self, min_chunk_size, max_chunk_size):
+    def _read_chunks_ahead(self, min_chunk_size, max_chunk_size, window=None):
         """read_chunks for big batches of a plain file: batch i + 1's new bytes are read (behind _FRONT bytes of room) while
-        batch i is uploaded, scanned and used; its left-over is copied in front of them afterwards."""
+        batch i is uploaded, scanned and used; its left-over is copied in front of them afterwards.
+        window: the caller asked for chunks of this (small) size — the batches are a transport, and what is yielded are the
+        chunks a reader with windows of ``window`` bytes would cut (``_cut_windows``)."""
         if self._staging is None:
             self._staging = _Staging()
+        _FRONT = globals()["_FRONT"] if window is None else (max(globals()["_FRONT"], 2 * window + (1 << 20)) + 4095) & ~4095
+        cutter = self._cut_whole if window is None else (lambda b, d: self._cut_windows(b, d, window, max_chunk_size))
 
         early = None
         if _EARLY_UPLOAD and not getattr(get_ops(), "host_only", False):
@@ -294,6 +312,7 @@ class NumpyFileReader:
         held = self._left_over if self._left_over is not None else np.zeros(0, dtype=np.uint8)
         self._left_over = None
         pending = collections.deque([start()])
+        completed = False
         try:
             while not self._is_finished:
                 ahead = pending.popleft()
@@ -318,34 +337,100 @@ class NumpyFileReader:
                 batch = room[first:n]
                 while not self._is_finished and len(pending) < depth:
                     pending.append(start())                  # the next batches' bytes, while this one is parsed and used
-                if max_chunk_size is not None and batch.size > max_chunk_size:
+                if window is None and max_chunk_size is not None and batch.size > max_chunk_size:
                     raise Exception("No complete entry found")
                 on_device = early.assemble(uploaded[0], uploaded[1], room, first, n, _FRONT, got) if uploaded is not None else None
-                buff = self._parse(batch if on_device is None else on_device)
+                pieces = cutter(batch, on_device)
                 del on_device
-                if buff is None:                             # no complete entry yet: the whole batch is carried over
-                    held = batch
-                    continue
-                held = batch[buff.size:] if not self._is_finished else np.zeros(0, dtype=np.uint8)
-                self.n_bytes_read += buff.size
-                self.n_lines_read += buff.n_lines
-                yield buff
+                held = batch                                 # (no complete entry: the whole batch is carried over)
+                for buff, end in pieces:
+                    # what lies behind the piece is the left-over from now on: a caller who stops here finds it again
+                    held = batch[end:]
+                    self.n_bytes_read += buff.size
+                    self.n_lines_read += buff.n_lines
+                    yield buff
+                if self._is_finished:                        # (a finished file's tail without a complete entry is dropped)
+                    held = np.zeros(0, dtype=np.uint8)
+            completed = True
         finally:
-            while pending:                                   # abandoned mid-file: what was read stays available
+            # abandoned mid-file (the caller stopped iterating, or an exception went through): what was read stays available —
+            # the bytes behind the last yielded entry, and what the read-aheads brought in since, are the left-over of the
+            # next read, and the file is NOT finished for the reader even if a read-ahead met its end (that read, of 0 new
+            # bytes, terminates and parses the tail: parser.py:183-200)
+            while pending:
                 room, got = take(pending.popleft())
-                if self._is_finished:                        # (a read started behind the end of the file: nothing)
+                if got == 0:                                 # (a read started behind the end of the file: nothing)
                     continue
                 rest = np.empty(held.size + got, dtype=np.uint8)
                 rest[:held.size] = held
                 rest[held.size:] = room[_FRONT:_FRONT + got]
-                held, self._is_finished = rest, got < min_chunk_size
+                held = rest
             if placed:
                 f.seek(next_pos)                             # (the reads were placed by hand: the file object follows)
-            self._left_over = held if held.size and not self._is_finished else None
-            if self._is_finished and held.size:              # (a finished file's tail without a complete entry is dropped)
+            if not completed and held.size:
+                self._left_over, self._is_finished = np.array(held), False      # (a copy: the staging buffers go back)
+            else:
                 self._left_over = None
             if self._is_finished and self._early is not None:    # the file is through: its device staging goes to the next reader
                 self._release_early()
+
+    def _cut_whole(self, batch, on_device):
+        """one buffer over all complete entries of the batch -> [(buffer, its size)]"""
+        buff = self._parse(batch if on_device is None else on_device)
+        return [] if buff is None else [(buff, buff.size)]
+
+    def _cut_windows(self, batch, on_device, window, max_chunk_size):
+        """the chunks a reader with windows of ``window`` bytes cuts out of the batch (a generator of (buffer, end offset)):
+        one scan of the whole batch, one kernel that walks the windows over its newline table, one download.  A chunk is a
+        VIEW of the batch (text and newline table), so the fixed cost per chunk is a few host objects."""
+        from ..ops import LineScan
+        from ..device import HArray
+        cls, ops = self._buffer_type, get_ops()
+        lpe = cls.n_lines_per_entry
+        try:
+            big = cls.from_raw_buffer(batch if on_device is None else on_device, header_data=self._header_data)
+        except IncompleteEntryException:
+            return
+        except FormatException:
+            # a malformed entry somewhere in the batch: the reference yields the chunks in front of it before it raises, so
+            # this batch is cut the slow way, window by window, each scanned on its own
+            yield from self._cut_windows_slowly(batch, window, max_chunk_size)
+            return
+        cuts, rebased = ops.window_cuts(big._data, big._scan, lpe, window, batch.size, self._is_finished, self._window_held,
+                                        max_chunk_size, 256)
+        text = big._data.dev()
+        j0 = s = 0
+        for i in range(int(cuts[0])):
+            j1, e, has_cr, w_end = (int(v) for v in cuts[4 + 4 * i:8 + 4 * i])
+            scan = LineScan(e - s, (j1 - j0) * lpe, j1 - j0, HArray(dev=rebased[j0 * lpe:j1 * lpe]), bool(has_cr))
+            self._window_held = w_end - e
+            yield cls(HArray(dev=text[s:e]), scan), e
+            j0, s = j1, e
+        if cuts[1]:                                          # (behind the chunks in front of it, as in the plain loop)
+            raise Exception("No complete entry found")
+
+    def _cut_windows_slowly(self, batch, window, max_chunk_size):
+        """_cut_windows by the book (parser.py:96-171 on the bytes of the batch): every window scanned on its own, so that
+        the chunks in front of a malformed entry are yielded and the exception carries the reference's line number"""
+        s, held = 0, self._window_held
+        while s < batch.size:
+            w_end = s + (held + window if held >= window else window)
+            while True:
+                if w_end > batch.size:
+                    if not self._is_finished:
+                        return                               # the window reaches into the next batch
+                    w_end = batch.size
+                if max_chunk_size is not None and w_end - s > max_chunk_size:
+                    raise Exception("No complete entry found")
+                buff = self._parse(np.array(batch[s:w_end]))
+                if buff is not None or w_end >= batch.size:
+                    break
+                w_end += window
+            if buff is None:
+                return
+            self._window_held = held = w_end - (s + buff.size)
+            s += buff.size
+            yield buff, s
 
     def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
         """the next buffer of complete entries, or None at the end of the file (parser.py:96-171)"""

@@ -39,6 +39,13 @@ class HipOps:
         return self.device.empty(n, dtype)
 
     # -- host staging --------------------------------------------------------------------------------
+    def _fetch(self, t, n=None):
+        """the first n int64 words of a device tensor as a list of Python ints (bnpk_fetch_i64: the page-locked mailbox)"""
+        n = t.numel() if n is None else n
+        buf = (C.c_int64 * n)()
+        self._chk(lib.bnpk_fetch_i64(self.ctx, ptr(t), n, buf, self._s()))
+        return list(buf)
+
     def upload_pinned(self, array, pinned_buffer):
         """hipMemcpyAsync of a numpy view of a pinned staging buffer into a fresh HBM tensor"""
         n = array.size
@@ -57,7 +64,7 @@ class HipOps:
         tiles = lib.bnpk_scan_tiles(n)
         tile_off = self._empty(tiles + 1, np.int64)
         self._chk(lib.bnpk_byte_census(self.ctx, ptr(d), n, NEWLINE, ptr(tile_off), self._s()))
-        total = int(tile_off[tiles].item())
+        total = self._fetch(tile_off[tiles:], 1)[0]
         n_lines = total - (total % limit_multiple)
         pos = self._empty(n_lines, np.int64)
         self._chk(lib.bnpk_byte_positions(self.ctx, ptr(d), n, NEWLINE, ptr(tile_off), n_lines, ptr(pos), self._s()))
@@ -74,7 +81,7 @@ class HipOps:
         self._chk(lib.bnpk_validate_entries(self.ctx, ptr(buf.dev()), ptr(nl), n_lines, lines_per_entry, header,
                                             1 if check_plus else 0, ptr(err), self._s()))
         err[3:4].copy_(nl[n_lines - 1:n_lines])          # last newline -> size, one D2H for all four
-        e = err.cpu().numpy()
+        e = self._fetch(err)
         if e[0] != NONE:
             raise FormatException("Expected header line to start with %s" % chr(header),
                                   line_number=int(e[0]) * lines_per_entry)
@@ -82,6 +89,19 @@ class HipOps:
             raise FormatException("Expected '+' at third line of entry",
                                   line_number=2 + int(e[1]) * lines_per_entry)
         return LineScan(int(e[3]) + 1, n_lines, n_lines // lines_per_entry, newlines, bool(e[2]))
+
+    def window_cuts(self, buf, scan, lines_per_entry, window, avail, finished, first_held, max_chunk, max_cuts=256):
+        """the chunks a reader with windows of ``window`` bytes cuts out of a scanned batch (bnpk_window_cuts) and every
+        chunk's newline table relative to its first byte (bnpk_rebase_lines) -> (host int64 words of bnpk_window_cuts,
+        device tensor of the rebased newline positions).  One launch each and ONE download per batch."""
+        out = self._empty(lib.bnpk_window_cuts_words(max_cuts), np.int64)
+        nl = scan.newlines.dev()
+        self._chk(lib.bnpk_window_cuts(self.ctx, ptr(buf.dev()), ptr(nl), scan.n_lines, lines_per_entry, window, avail,
+                                       1 if finished else 0, first_held, max_chunk or 0, max_cuts, ptr(out), self._s()))
+        rebased = self._empty(max(scan.n_lines, 1), np.int64)
+        self._chk(lib.bnpk_rebase_lines(self.ctx, ptr(nl), scan.n_lines, ptr(out), lines_per_entry, ptr(rebased), self._s()))
+        head = self._fetch(out, 4)                       # (chunks cut, status, ...: then only the rows that were written)
+        return np.array(head + self._fetch(out[4:], 4 * head[0]), dtype=np.int64), rebased
 
     # -- A2-A7 fused (k-mer pipeline) -----------------------------------------------------------------------
     def fastq_encode(self, buf, n, lines_per_entry, seq_line, header, check_plus):
@@ -210,7 +230,7 @@ class HipOps:
         n = lens.size
         off = self._empty(n + 1, np.int64)
         self._chk(lib.bnpk_row_offsets(self.ctx, ptr(lens.dev()) if n else None, n, window, ptr(off), self._s()))
-        return HArray(dev=off), int(off[n].item())
+        return HArray(dev=off), self._fetch(off[n:], 1)[0]
 
     def exclusive_scan(self, values):
         n = values.size
@@ -225,7 +245,7 @@ class HipOps:
         return cell
 
     def _raise_if_bad(self, cell):
-        off = int(cell.item())
+        off = self._fetch(cell, 1)[0]
         if off != NONE:
             raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character at flat "
                                 "offset %d" % off, off)
@@ -269,12 +289,13 @@ class HipOps:
     # -- A8 / A11 ------------------------------------------------------------------------------------------
     WINDOWS_FLAT_MAX = 26         # k-mers per window the row-lookup-free generator covers
 
-    def _windows_flat(self, packed, in_offsets, n_rows, n_out, k, window_size):
+    def _windows_flat(self, packed, in_offsets, n_rows, n_out, k, window_size, total=None):
         """hashes (window_size == k) / minimizers through the position-flat generator: start mask + ranks"""
         out = self._empty(n_out, np.int64)
         if n_out == 0:
             return HArray(dev=out)
-        total = int(in_offsets.dev()[n_rows].item())
+        if total is None:                                # (callers that know the number of bases say so: one round trip less)
+            total = self._fetch(in_offsets.dev()[n_rows:], 1)[0]
         mask = self.kmer_start_mask(in_offsets, n_rows, total, window_size)
         self._chk(lib.bnpk_windows_flat(self.ctx, ptr(packed.dev()), ptr(mask.dev()), total, k, window_size - k + 1,
                                         n_out, ptr(out), self._s()))
@@ -288,8 +309,8 @@ class HipOps:
                                             window_size - k + 1, n_out, ptr(out), self._s()))
         return HArray(dev=out)
 
-    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
-        return self._windows_flat(packed, in_offsets, n_rows, n_out, k, k)
+    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, total=None):
+        return self._windows_flat(packed, in_offsets, n_rows, n_out, k, k, total)
 
     def kmers_generic(self, codes, in_offsets, out_offsets, n_rows, n_out, k, alphabet_size):
         """hashes sum_j code[p + j] * alphabet_size^j of every window of k codes (bnpk_kmers_generic): the k-mers of

@@ -91,12 +91,54 @@ class SparseKmerCounts:
     """Histogram of k-mers for k > 8: sorted distinct int64 keys + int64 counts, HBM-resident.
 
     ``+`` merges two histograms (the k = 31 analogue of EncodedCounts.__add__, so that
-    ``sum(count_kmers(chunk.sequence, 31) for chunk in reader)`` works like the reference's streams)."""
+    ``sum(count_kmers(chunk.sequence, 31) for chunk in reader)`` works like the reference's streams).
 
-    def __init__(self, encoding, keys, counts):
+    The counting is LAZY for small inputs: a histogram may hold k-mer hashes that have not been counted yet (``pending``),
+    and adding two histograms only joins those lists.  The reference's loops call count_encoded / count_kmers once per
+    5 MB chunk and add the results up (scripts/kmer_counting_example.py:4-17, streams/decorators.py:78-108); the sum of the
+    chunks' histograms is the histogram of all their k-mers, so the hashes of many chunks are counted TOGETHER — one
+    partition + finishing pass per ~half a billion k-mers instead of one per chunk (a dozen launches and five host round
+    trips each, and a merge of the running total with every chunk's histogram, which is quadratic in the number of
+    chunks) — as soon as somebody looks at the keys or counts, or when PENDING_LIMIT hashes have piled up."""
+
+    PENDING_LIMIT = 1 << 29            # uncounted hashes a histogram holds at most (4 GiB)
+    LAZY_MAX = 1 << 26                 # inputs up to this many hashes are counted lazily (larger ones: at once)
+
+    def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=62):
         self.encoding = encoding
-        self._keys = keys if isinstance(keys, HArray) else HArray(host=np.asarray(keys, dtype=np.int64))
-        self._counts = counts if isinstance(counts, HArray) else HArray(host=np.asarray(counts, dtype=np.int64))
+        as_h = lambda x: x if isinstance(x, HArray) else HArray(host=np.asarray(x, dtype=np.int64))
+        self._k = None if keys is None else as_h(keys)
+        self._c = None if counts is None else as_h(counts)
+        self._pending = list(pending or [])    # HArrays of int64 hashes (shared between histograms, never written to)
+        self._n_pend = sum(p.size for p in self._pending)
+        self._key_bits = key_bits
+
+    def _n_pending(self):
+        return self._n_pend
+
+    def _force(self):
+        """count what is pending and merge it with what has been counted"""
+        if self._pending:
+            ops = get_ops()
+            if len(self._pending) == 1:
+                keys, counts = ops.count_sparse(self._pending[0], key_bits=self._key_bits)
+            else:                                          # (the joined array is this call's own: the counting may use it up)
+                keys, counts = ops.count_sparse(ops.concat(self._pending), key_bits=self._key_bits, consume=True)
+            self._pending, self._n_pend = [], 0
+            if self._k is not None and self._k.size:
+                keys, counts = ops.merge_add(self._k, self._c, keys, counts)
+            self._k, self._c = keys, counts
+        elif self._k is None:
+            self._k = self._c = HArray(host=np.zeros(0, dtype=np.int64))
+        return self
+
+    @property
+    def _keys(self):
+        return self._force()._k
+
+    @property
+    def _counts(self):
+        return self._force()._c
 
     @property
     def keys(self):
@@ -121,7 +163,17 @@ class SparseKmerCounts:
             assert other == 0, "only 0 (the start value of sum) can be added to a sparse histogram"
             return self
         assert self.encoding == other.encoding
-        # both key lists are sorted and distinct: one merge along the merge path, no sort (bnpk_merge_add)
+        if self._pending or other._pending:
+            # nothing is counted here: the uncounted hashes of both go on one list (counted parts are merged now — both
+            # key lists are sorted and distinct: one merge along the merge path, bnpk_merge_add)
+            if self._k is not None and other._k is not None and self._k.size and other._k.size:
+                k, c = get_ops().merge_add(self._k, self._c, other._k, other._c)
+            else:
+                k, c = (self._k, self._c) if (self._k is not None and self._k.size) else (other._k, other._c)
+            out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, max(self._key_bits, other._key_bits))
+            if out._n_pending() >= self.PENDING_LIMIT:
+                out._force()
+            return out
         keys, counts = get_ops().merge_add(self._keys, self._counts, other._keys, other._counts)
         return SparseKmerCounts(self.encoding, keys, counts)
 
@@ -160,6 +212,8 @@ def count_encoded(values, weights=None, axis=-1):
         key_bits = 2 * k if n_letters == 4 else (n_letters ** k - 1).bit_length()
         if key_bits > 62:
             raise NotImplementedError("sparse counts need k-mer hashes below 2^62 (%d letters, k = %d)" % (n_letters, k))
+        if 0 < store.size <= SparseKmerCounts.LAZY_MAX and store.on_device:
+            return SparseKmerCounts(encoding, pending=[store], key_bits=key_bits)    # counted when somebody looks (see the class)
         keys, counts = ops.count_sparse(store, key_bits=key_bits)
         return SparseKmerCounts(encoding, keys, counts)
     alphabet = encoding.get_alphabet() if hasattr(encoding, "get_alphabet") else encoding.get_labels()

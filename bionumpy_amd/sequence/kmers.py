@@ -32,7 +32,7 @@ def _rolling(sequence, window, kernel):
     single = isinstance(sequence, EncodedArray)
     packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
     out_off, n_out = ops.row_offsets(lens, window)
-    values = kernel(ops, packed, in_off, out_off, n_rows, n_out)
+    values = kernel(ops, packed, in_off, out_off, n_rows, n_out, total)
     return values, out_off, lens, n_rows, n_out, single
 
 
@@ -103,7 +103,7 @@ def get_kmers(sequence, k, canonical=False):
     if sequence.encoding.alphabet_size != 4:                 # (kmers.py:82-87: only 4-letter alphabets take the 2-bit path)
         return _get_kmers_generic(sequence, k)
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
-        sequence, k, lambda ops, p, i, o, n, m: ops.kmers(p, i, o, n, m, k))
+        sequence, k, lambda ops, p, i, o, n, m, t: ops.kmers(p, i, o, n, m, k, total=t))
     if canonical and n_out:
         hashes = get_ops().canonical_kmers(hashes, k)
     encoding = KmerEncoding(sequence.encoding, k)
@@ -143,7 +143,7 @@ class _LazyLens:
 _DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB (pipeline.DENSE_MAX_K)
 
 
-@streamable(sum)
+@streamable(sum, coalesce=True)
 def count_kmers(sequence, k, axis=None, canonical=False):
     """count every k-mer (sequence/kmers.py:129-145); k <= 8 gives the reference's dense EncodedCounts,
     larger k the sparse (sorted unique keys, counts) extension — see count_encoded.
@@ -169,7 +169,12 @@ def count_kmers(sequence, k, axis=None, canonical=False):
             raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
         ops = get_ops()
         packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
-        _, n_out = ops.row_offsets(lens, k)
+        out_off, n_out = ops.row_offsets(lens, k)
+        if 0 < n_out <= SparseKmerCounts.LAZY_MAX and not canonical:
+            # a small input — a chunk of a file read the reference's way: its hashes are laid out and counted LATER, with
+            # those of the chunks it is added to (see SparseKmerCounts)
+            hashes = ops.kmers(packed, in_off, out_off, n_rows, n_out, k, total=total)
+            return SparseKmerCounts(KmerEncoding(sequence.encoding, k), pending=[hashes], key_bits=2 * k)
         if n_out > 0:
             mask = ops.kmer_start_mask(in_off, n_rows, total, k)
             skew = 2.0 if canonical else 1.0          # min(h, rc(h)) has density 2(1 - x) over the key range

@@ -18,28 +18,67 @@ class BnpStream:
 
 
 class NpDataclassStream(BnpStream):
-    """stream of chunk objects (streams/stream.py:40-53); attribute access maps over the chunks"""
+    """stream of chunk objects (streams/stream.py:40-53); attribute access maps over the chunks.
 
-    def __init__(self, stream, dataclass=None):
+    rebatch: what a reader hands along — a function (min_chunk_size) -> a fresh generator of chunks of that size over the same
+    entries, usable while nothing has been taken from this stream.  A reduction that does not depend on where the chunks
+    are cut (``streamable(sum)`` over histograms) asks for batches sized for the device instead of the reference's 5 MB."""
+
+    def __init__(self, stream, dataclass=None, rebatch=None):
         super().__init__(stream)
         self.dataclass = dataclass
+        self._rebatch = rebatch
+        self._started = False
+
+    def __next__(self):
+        self._started = True
+        return next(self._stream)
+
+    def _coalesced(self, min_chunk_size):
+        """this stream again, cut into chunks of at least min_chunk_size bytes — or itself, if it cannot be cut anew"""
+        if self._rebatch is None or self._started:
+            return self
+        self._started = True                                 # (the entries are handed out through the new stream from now on)
+        return NpDataclassStream(self._rebatch(min_chunk_size), self.dataclass)
 
     def __getattr__(self, name):
         if name.startswith("_"):
             raise AttributeError(name)
-        return BnpStream(getattr(chunk, name) for chunk in self)
+        return _FieldStream(self, name)
+
+
+class _FieldStream(BnpStream):
+    """one field of every chunk of a chunk stream (what NpDataclassStream.__getattr__ gives)"""
+
+    def __init__(self, parent, name):
+        super().__init__(getattr(chunk, name) for chunk in parent)
+        self._parent, self._name = parent, name
+
+    def _coalesced(self, min_chunk_size):
+        again = self._parent._coalesced(min_chunk_size)
+        return self if again is self._parent else _FieldStream(again, self._name)
 
 
 def _is_stream(x):
     return isinstance(x, (BnpStream, types.GeneratorType))
 
 
+COALESCED_CHUNK = 256 << 20        # bytes per chunk a chunk-boundary-independent reduction asks a file stream for
+
+
 class streamable:
-    def __init__(self, reduction=None):
+    """streams/decorators.py:9-110.  coalesce=True: the reduced result does not depend on where the stream is cut into chunks
+    (a sum of histograms) — a stream that comes straight from a file reader is then cut into COALESCED_CHUNK-byte chunks
+    instead of the size the caller named (the reference's default is 5 MB, a few hundredths of what one launch of the
+    counting kernels is sized for)."""
+
+    def __init__(self, reduction=None, coalesce=False):
         self._reduction = reduction
+        self._coalesce = coalesce
 
     def __call__(self, func):
         reduction = self._reduction
+        coalesce = self._coalesce and reduction is not None
 
         @functools.wraps(func)
         def wrapped(*args, **kwargs):
@@ -47,6 +86,9 @@ class streamable:
             stream_keys = [k for k, v in kwargs.items() if _is_stream(v)]
             if not stream_args and not stream_keys:
                 return func(*args, **kwargs)
+            if coalesce and len(stream_args) + len(stream_keys) == 1:
+                args = tuple(a._coalesced(COALESCED_CHUNK) if hasattr(a, "_coalesced") else a for a in args)
+                kwargs = {k: (v._coalesced(COALESCED_CHUNK) if hasattr(v, "_coalesced") else v) for k, v in kwargs.items()}
 
             def results():
                 iters = {i: iter(args[i]) for i in stream_args}

@@ -134,6 +134,10 @@ int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stre
 int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst, int64_t bytes, int n_threads, int64_t piece_bytes,
                         void* d_dst, void* stream, int64_t* h_read);
 int bnpk_stream_sync(void* stream);
+/* the first n (<= 512) words of a device array, on the host: one hipMemcpyAsync into a page-locked mailbox of the ctx behind
+ * everything enqueued on `stream`, one hipStreamSynchronize — how the host scalars of the chunk loop (totals, error cells,
+ * cut tables) come back; a third of the cost of a pageable copy.  One host thread per ctx. */
+int bnpk_fetch_i64(bnpk_ctx* ctx, const int64_t* d_src, int64_t n, int64_t* h_dst, void* stream);
 
 /* ---- A2: newline scan ------------------------------------------------------------------
  * replaces `np.flatnonzero(chunk == NEWLINE)` (bionumpy/io/one_line_buffer.py:63,
@@ -157,6 +161,30 @@ int bnpk_byte_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t 
 int bnpk_validate_entries(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines,
                           int64_t n_lines, int lines_per_entry, uint8_t header, int check_plus,
                           int64_t* d_err3, void* stream);
+
+/* ---- A1: the chunks of a reader with small windows, cut out of one big batch ---------------------------
+ * replaces the per-chunk loop of NumpyFileReader.read_chunk (bionumpy/io/parser.py:96-171) for a batch that is in HBM
+ * already: a chunk is the complete entries inside a window of `window` (= min_chunk_size) bytes that starts at the first
+ * unconsumed byte — min_chunk_size more than the bytes held if those are min_chunk_size or more (:117-120) —, a window
+ * without a complete entry grows by `window` (:128-131), the file continues behind the last complete entry.
+ * d_newlines: the n_lines newline positions of the batch's complete entries (bnpk_byte_positions; n_lines a multiple of
+ * lines_per_entry), avail: bytes of the file the batch holds (>= last newline + 1), finished: the file ends with the
+ * batch (the last window may be short), first_held: what the reference's reader would hold in front of the batch's first
+ * window beyond the batch's first byte ... i.e. (window end of the chunk before) - (its end); max_chunk: 0 or the size
+ * beyond which a window without a complete entry is an error.
+ * d_out (bnpk_window_cuts_words(max_cuts) words, max_cuts <= 256): [0] chunks cut, [1] 1 = a window grew past max_chunk,
+ * [2] window end of the last chunk cut, [3] entries consumed; then per chunk {entries up to and including it, its end
+ * byte, 1 if one of its first lines_per_entry header lines ends in '\r' (one_line_buffer.py:176-182), its window end}.
+ * A window that reaches past `avail` of an unfinished file is not cut: it belongs to the next batch. */
+int64_t bnpk_window_cuts_words(int max_cuts);
+int bnpk_window_cuts(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_newlines, int64_t n_lines, int lines_per_entry,
+                     int64_t window, int64_t avail, int finished, int64_t first_held, int64_t max_chunk, int max_cuts,
+                     int64_t* d_out, void* stream);
+/* d_out[i] = d_newlines[i] - (first byte of the chunk that holds line i), for the lines of the chunks of d_cuts
+ * (bnpk_window_cuts' output): every chunk's newline table relative to its own first byte, as a scan of the chunk alone
+ * would have given it (np.flatnonzero(chunk == "\n"), one_line_buffer.py:63) */
+int bnpk_rebase_lines(bnpk_ctx* ctx, const int64_t* d_newlines, int64_t n_lines, const int64_t* d_cuts, int lines_per_entry,
+                      int64_t* d_out, void* stream);
 
 /* ---- A4/A5: field table ----------------------------------------------------------------
  * replaces OneLineBuffer._get_buffer_extractor + TextBufferExtractor.get_field_by_number

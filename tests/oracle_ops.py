@@ -263,7 +263,7 @@ class OracleOps:
         assert pos.size == n_out
         return _h(best if best is not None else np.zeros(0, dtype=np.int64))
 
-    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k):
+    def kmers(self, packed, in_offsets, out_offsets, n_rows, n_out, k, total=None):
         off = in_offsets.host()
         h, _ = oracle.get_kmers(_unpack(packed, int(off[-1])), np.diff(off), k)
         assert h.size == n_out

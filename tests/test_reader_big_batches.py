@@ -107,3 +107,111 @@ def test_parallel_fill_reads_what_readinto_reads(small_thresholds, tmp_path):
     assert r._fill(out2) == 20_001 and np.array_equal(out2[:20_001], data[50_000:])
     assert r._fill(out2) == 0
     r._file_obj.close()
+
+
+# ---- read_chunks with the reference's small windows, cut out of big device batches (parser._cut_windows) -----------------
+def _windowed(monkeypatch, on, batch=1 << 16):
+    from bionumpy_amd.io import parser
+    monkeypatch.setattr(parser, "_WINDOWED", on)
+    monkeypatch.setattr(parser, "_WINDOW_MIN", 256)
+    monkeypatch.setattr(parser, "_WINDOW_BATCH", batch)
+    monkeypatch.setattr(parser, "_FRONT", 1 << 9)
+    monkeypatch.setattr(parser, "_PIECE", 1 << 11)
+    return parser
+
+
+def _chunks(bnp, path, chunk, max_chunk=None):
+    """[(names of the chunk, n_lines_read behind it)] and the exception that ended the loop, if any"""
+    reader = bnp.open(str(path))
+    out, err = [], None
+    try:
+        for c in reader.read_chunks(min_chunk_size=chunk, max_chunk_size=max_chunk):
+            out.append((c.name.tolist(), c.sequence.tolist(), reader._reader.n_lines_read, reader._reader.n_bytes_read))
+    except Exception as e:                                    # noqa: BLE001
+        err = (type(e).__name__, getattr(e, "line_number", None), str(e)[:40])
+    reader.close()
+    return out, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,max_len,chunk,batch,final_newline,crlf", [
+    (1, 2000, 60, 5000, 1 << 16, True, False), (2, 2000, 60, 4096, 1 << 15, False, False),
+    (3, 300, 3000, 4096, 1 << 16, True, False),            # entries longer than the window: it grows
+    (4, 40, 20000, 8192, 1 << 16, True, False),            # ... and longer than the front room of a batch
+    (5, 1, 50, 4096, 1 << 16, True, False), (6, 3000, 100, 3000, 1 << 16, True, True),
+    (7, 5000, 40, 1000, 1 << 14, True, False)])            # more chunks per batch than one call cuts (batches of 200 windows)
+def test_windowed_chunks_are_the_plain_loops_chunks(monkeypatch, tmp_path, seed, n, max_len, chunk, batch, final_newline, crlf):
+    """chunk for chunk: the same entries, n_lines_read and n_bytes_read as reading, uploading and scanning one window at a
+    time (bionumpy/io/parser.py:96-171)"""
+    import bionumpy_amd as bnp
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    text = _fastq(np.random.default_rng(seed), n, max_len, final_newline)
+    if crlf:
+        text = text.replace("\n", "\r\n")
+    path = tmp_path / "reads.fq"
+    path.write_bytes(text.encode())
+    _windowed(monkeypatch, False)
+    want, err0 = _chunks(bnp, path, chunk)
+    _windowed(monkeypatch, True, batch)
+    got, err1 = _chunks(bnp, path, chunk)
+    assert err0 is None and err1 is None
+    assert len(got) == len(want) and got == want
+
+
+@pytest.mark.gpu
+def test_windowed_reader_raises_where_the_plain_loop_raises(monkeypatch, tmp_path):
+    """a malformed entry in the middle of a batch: the chunks in front of it are yielded, then FormatException with the
+    line number counted from the start of the file; a window that cannot hold an entry: 'No complete entry found'"""
+    import bionumpy_amd as bnp
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    rng = np.random.default_rng(11)
+    for bad in ("header", "plus"):
+        parts = _fastq(rng, 1500, 60).split("\n")
+        line = 4 * 900 + (0 if bad == "header" else 2)
+        parts[line] = "x" + parts[line][1:]
+        path = tmp_path / ("bad_%s.fq" % bad)
+        path.write_text("\n".join(parts))
+        _windowed(monkeypatch, False)
+        want, err0 = _chunks(bnp, path, 5000)
+        _windowed(monkeypatch, True)
+        got, err1 = _chunks(bnp, path, 5000)
+        assert err0 is not None and err0[0] == "FormatException" and err0[1] == line
+        assert err1 == err0 and got == want and len(got) > 3
+    path = tmp_path / "long.fq"
+    path.write_text(_fastq(rng, 50, 40) + "@long\n%s\n+\n%s\n" % ("A" * 30000, "I" * 30000) + _fastq(rng, 50, 40))
+    _windowed(monkeypatch, False)
+    want, err0 = _chunks(bnp, path, 4096, max_chunk=16384)
+    _windowed(monkeypatch, True)
+    got, err1 = _chunks(bnp, path, 4096, max_chunk=16384)
+    assert err0 is not None and "No complete entry" in err0[2] and err1 == err0 and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stop_at", [0, 3, 14])
+def test_windowed_reader_abandoned_keeps_the_rest_of_the_file(monkeypatch, tmp_path, stop_at):
+    """the caller stops in the middle of a batch (also in the file's last batch, whose read-ahead met the end of the file)
+    and goes on with read_chunk / read_chunks: nothing is lost, nothing comes twice"""
+    import bionumpy_amd as bnp
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    text = _fastq(np.random.default_rng(12), 900, 80, final_newline=False)
+    path = tmp_path / "reads.fq"
+    path.write_text(text)
+    whole = bnp.open(str(path)).read().sequence.tolist()
+    _windowed(monkeypatch, True, 1 << 15)
+    reader = bnp.open(str(path))
+    seqs = []
+    for i, c in enumerate(reader.read_chunks(min_chunk_size=6000)):
+        seqs += c.sequence.tolist()
+        if i == stop_at:
+            break
+    c = reader.read_chunk(min_chunk_size=6000)
+    if len(c):                                               # (stop_at = the last chunk: nothing is left)
+        seqs += c.sequence.tolist()
+    for c in reader.read_chunks(min_chunk_size=6000):
+        seqs += c.sequence.tolist()
+    assert reader._reader.n_lines_read == 4 * 900
+    reader.close()
+    assert seqs == whole
