@@ -152,6 +152,129 @@ def host_fed_leg(args, text, expected_sums):
             "link_bound_gbases_per_s": round(tm.h2d_gb_per_s / (n / n_bases * args.host_fed_batches), 2) if n_bases else None}
 
 
+def extras(args, ops, dev, main_stats, copy_rate):
+    """the secondary workloads under the same clock as `value` (never part of it): S-genome, BASELINE config 3
+    (k = 31 minimizers, window 40) and config 5 (sacCer3 index + lookups) — each with its timing, the roofline fraction of
+    its dominant kernel and a parity flag.  One GPU only; the headline batch has been released by now."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize
+    import oracle
+    import bionumpy_amd as bnp
+    from bionumpy_amd.pipeline import fastq_kmer_histogram, fastq_minimizers
+    out = {}
+
+    def timed(fn, steps):
+        r = fn(); del r
+        torch.cuda.synchronize()
+        dev.prof_enable(True); dev.prof_reset()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = fn()
+            if _ != steps - 1:
+                del r
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        prof = dev.prof_report(); dev.prof_enable(False)
+        return r, dt, prof
+
+    def roof(prof, name, nbytes, steps):
+        avg_ms = prof[name]["total_ms"] / max(prof[name]["launches"], 1)
+        gbs = nbytes / (avg_ms * 1e-3) / 1e9
+        return {"kernel": name, "avg_launch_ms": round(avg_ms, 3), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_rate, 4) if copy_rate else None,
+                "algorithmic_bytes_per_launch": int(nbytes)}
+
+    # ---- S-genome: the same 50 M x 150 bp, reads drawn from a 100 Mbp genome (60x coverage): duplicate-heavy k-mers
+    try:
+        steps = 3
+        text = ops.synth_fastq(args.reads, args.read_len, args.seed, 1, args.genome_len, 0)
+        (hist, stats), dt, prof = timed(lambda: fastq_kmer_histogram(text, args.k), steps)
+        keys, counts = hist
+        dom = max(prof, key=lambda n: prof[n]["total_ms"])
+        check = fullsize.check_histogram(ops, text, args.reads, args.read_len, args.k, args.seed, 1, args.genome_len, 0, keys, counts)
+        out["s_genome"] = {"workload": "synthetic %dbp x %d reads FASTQ (genome of %d bp), k=%d" % (args.read_len, args.reads, args.genome_len, args.k),
+                           "ms_per_step": round(dt * 1e3, 2), "steps": steps, "gbases_per_s": round(stats.n_bases / dt / 1e9, 2),
+                           "distinct": keys.size, "roofline": roof(prof, dom, algorithmic_bytes(dom, stats, args.read_len, args.k, keys.size), steps),
+                           "kernels_ms": {n: round(v["total_ms"] / steps, 2) for n, v in prof.items()},
+                           "parity": True, "parity_detail": check}
+        del hist, keys, counts, text
+    except AssertionError as e:
+        out["s_genome"] = {"parity": False, "error": str(e)}
+    torch.cuda.empty_cache()
+
+    # ---- config 3: k = 31 minimizers over windows of 40 bases (w = 10 k-mers) of the headline batch's reads
+    try:
+        steps = 3
+        text = ops.synth_fastq(args.reads, args.read_len, args.seed, 0, 0, 0)
+        (mins, stats), dt, prof = timed(lambda: fastq_minimizers(text, 31, 40), steps)
+        n_out = mins.size
+        del mins
+        # parity (outside the timing): reads at the start, in the middle and at the end — every minimizer against the
+        # row-lookup kernel bnpk_minimizers, sampled reads against the numpy oracle
+        rec = 2 * args.read_len + 16
+        per = min(args.reads, 2_000_000)
+        checked = {"minimizers": 0, "sampled_minimizers_vs_oracle": 0}
+        for f in sorted({0, max(0, args.reads // 2 - per // 2), max(0, args.reads - per)}):
+            from bionumpy_amd.device import HArray
+            part = HArray(dev=text.dev()[f * rec:(f + per) * rec])
+            c = fullsize.check_minimizers(ops, part, per, args.read_len, 31, 40, args.seed, 0, 0, first_read=f)
+            checked["minimizers"] += c["minimizers"]
+            checked["sampled_minimizers_vs_oracle"] += c["sampled_minimizers_vs_oracle"]
+        nbytes = 8 * n_out + stats.n_bases / 4 + stats.n_bases / 8
+        out["config3_minimizers"] = {"workload": "the same %d reads, k=31 minimizers, window 40" % args.reads, "ms_per_step": round(dt * 1e3, 2),
+                                     "steps": steps, "gbases_per_s": round(stats.n_bases / dt / 1e9, 2), "n_minimizers": n_out,
+                                     "roofline": roof(prof, "minimizers_flat", nbytes, steps),
+                                     "kernels_ms": {n: round(v["total_ms"] / steps, 2) for n, v in prof.items()},
+                                     "parity": True, "parity_detail": dict(checked, compared_with="bnpk_minimizers (row-lookup kernel) element for "
+                                                                            "element on 3 x %d reads; the numpy oracle on sampled reads" % per)}
+        del text
+    except AssertionError as e:
+        out["config3_minimizers"] = {"parity": False, "error": str(e)}
+    torch.cuda.empty_cache()
+
+    # ---- config 5: sacCer3 k = 31 KmerIndex build + lookup of every 31-mer of big.fq.gz (tests/golden/)
+    try:
+        gold = os.path.join(ROOT, "tests", "golden")
+        genome = bnp.open(os.path.join(gold, "sacCer3.fa.gz")).read()
+        seqs = bnp.change_encoding(genome.sequence, bnp.DNAEncoding)
+        index = bnp.KmerIndex.create_index(seqs, k=31)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            index = bnp.KmerIndex.create_index(seqs, k=31)
+        torch.cuda.synchronize()
+        t_build = (time.perf_counter() - t0) / 3
+        reads_fq = bnp.open(os.path.join(gold, "big.fq.gz")).read()
+        q = bnp.get_kmers(bnp.change_encoding(reads_fq.sequence, bnp.DNAEncoding), 31)
+        q._compact()
+        lo, hi = index.get_indices_batch(q._flat_data())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            lo, hi = index.get_indices_batch(q._flat_data())
+        torch.cuda.synchronize()
+        t_lookup = (time.perf_counter() - t0) / 3
+        # parity: the whole index pair for pair and every lookup against the numpy oracle
+        raw, res = oracle.open_text(os.path.join(gold, "sacCer3.fa.gz")).read()
+        codes = oracle.encode_dna(oracle.gather_rows(raw, res.line_starts, res.line_lens))
+        eh, er = oracle.kmer_index_pairs(codes, res.seq_lens, 31)
+        qh = q._flat_data().host()
+        ok = (np.array_equal(index._keys.host(), eh) and np.array_equal(index._rows.host(), er)
+              and np.array_equal(lo.host(), np.searchsorted(eh, qh, side="left")) and np.array_equal(hi.host(), np.searchsorted(eh, qh, side="right")))
+        assert ok, "config 5: index or lookups differ from the oracle"
+        out["config5_kmer_index"] = {"workload": "sacCer3.fa.gz (%d bases) k=31 KmerIndex + %d lookups (big.fq.gz)" % (int(seqs.total()), qh.size),
+                                     "build_ms": round(t_build * 1e3, 2), "lookup_ms": round(t_lookup * 1e3, 3), "index_pairs": int(eh.size),
+                                     "roofline": None, "parity": True,
+                                     "parity_detail": "all (kmer, row) pairs and all lookups == oracle.kmer_index_pairs / np.searchsorted"}
+    except AssertionError as e:
+        out["config5_kmer_index"] = {"parity": False, "error": str(e)}
+    except Exception as e:                                   # noqa: BLE001  (e.g. the fixtures are not there)
+        out["config5_kmer_index"] = {"parity": None, "error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
 def virtual_ranks_mode(args, ops, dev, mode):
     """--virtual-ranks N: shard -> k-mers partitioned by the send cuts -> (the exchange's result) -> every rank's key range
     counted; the concatenation is checked against the k-mers of all reads (tests/fullsize.py) and one JSON line is printed"""
@@ -209,6 +332,8 @@ def main():
                          "not a scaling measurement)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned RAM -> HBM) measurement")
     ap.add_argument("--host-fed-batches", type=int, default=2)
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the secondary workloads (S-genome, config 3, config 5) that follow the timed region of `value`")
     ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
     ap.add_argument("--canonical", action="store_true",
                     help="count strand-independent k-mers min(h, rc(h)) (extension; not the headline workload)")
@@ -343,7 +468,7 @@ def main():
     traffic, traffic_source = None, None
     try:
         from bionumpy_amd.csrc.build import _source_hash
-        for cand in (("r03_genome_pmc.json",) if args.mode == "genome" else ("r03_pmc.json",)) + ("r02_pmc.json", "r01_pmc.json"):
+        for cand in (("r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
             path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -363,16 +488,17 @@ def main():
                 break
     except Exception:
         traffic = None
-    measured_peak = None
+    measured_peak, copy_rates = None, None
     try:                                                     # what this chip streams at (device copy, read + write bytes)
         import ctypes as C
         from bionumpy_amd._native import lib
         src = torch.empty(1 << 31, dtype=torch.uint8, device="cuda")
         dst = torch.empty_like(src)
-        rate = C.c_double(0.0)
-        if lib.bnpk_copy_peak(dev.ctx, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), 5, C.byref(rate),
-                              None) == 0:
-            measured_peak = round(rate.value, 1)
+        rates = (C.c_double * 4)()
+        if lib.bnpk_copy_rates(dev.ctx, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), 5, rates, None) == 0:
+            copy_rates = dict(zip(("nontemporal_loop", "plain_loop", "one_float4_per_thread", "four_per_iteration"),
+                                  (round(r, 1) for r in rates)))
+            measured_peak = max(copy_rates.values())         # the fastest form is what this chip copies at
         del src, dst
     except Exception:
         measured_peak = None
@@ -385,7 +511,9 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": round(avg_ms, 3),
-                    "measured_copy_gb_per_s": measured_peak,
+                    "traffic_box": None if traffic is None else "builder (a committed rocprofv3 --pmc profile of this build and workload, not this run)",
+                    "measured_copy_gb_per_s": measured_peak, "copy_forms_gb_per_s": copy_rates,
+                    "guide_copy_gb_per_s": 6290.0,           # MI355X_MICROARCH.md: float4 copy, 79 % of the spec peak
                     "frac_of_measured_copy": None if (achieved is None or not measured_peak) else round(achieved / measured_peak, 4),
                     "algorithmic_bytes_per_launch": b}
     out = {
@@ -429,6 +557,16 @@ def main():
             out["cpu_baseline"]["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
     else:
         out["cpu_baseline"] = None
+    # ---- the secondary workloads, under the same clock (never `value`) ---------------------------------------------------
+    out["extra"] = None
+    if world == 1 and not args.no_extra and args.k > 13 and args.mode == "uniform" and not args.canonical:
+        hist = keys = counts = None
+        del text
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        out["extra"] = extras(args, ops, dev, stats, measured_peak)
+        out["extra"]["seconds"] = round(time.perf_counter() - t0, 1)
+        out["extra_keys"] = sorted(k for k in out["extra"] if k != "seconds")
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

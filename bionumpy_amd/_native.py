@@ -46,6 +46,7 @@ SIGNATURES = {
     "bnpk_device_info": (_int, [_p, C.c_char_p, C.POINTER(_int), C.POINTER(_i64)]),
     "bnpk_prof_enable": (_int, [_p, _int]),
     "bnpk_copy_peak": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
+    "bnpk_copy_rates": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_set_option": (_int, [_p, C.c_char_p, _i64]),
     "bnpk_comm_unique_id": (_int, [_p]),
     "bnpk_comm_init": (_int, [_p, _p, _int, _int, C.POINTER(C.c_void_p)]),

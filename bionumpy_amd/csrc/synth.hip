@@ -91,6 +91,28 @@ __global__ __launch_bounds__(256) void copy_peak_kernel(const uint4* __restrict_
   for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(&s4[i]), &d4[i]);
 }
 
+// the same copy in the forms a streaming kernel can take (bnpk_copy_rates): plain (temporal) accesses in a grid-stride loop,
+// one 16-byte element per thread with no loop at all (the float4 copy MI355X_MICROARCH.md quotes at 6.29 TB/s), and four
+// independent elements per thread and iteration
+__global__ __launch_bounds__(256) void copy_plain_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy_oneshot_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void copy_unrolled_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -136,6 +158,38 @@ int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes,
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *h_gb_per_s = ms > 0 ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;   // bytes read + bytes written
+  return BNPK_OK;
+}
+
+int bnpk_copy_rates(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s4, void* stream) {
+  if (!ctx || !d_src || !d_dst || bytes < 16 || reps < 1 || !h_gb_per_s4) return BNPK_ERR_ARG;
+  if (((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15)) return BNPK_ERR_ALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n16 = bytes / 16;
+  if ((n16 + 255) / 256 > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  const unsigned loop_grid = (unsigned)std::min<int64_t>((n16 + 255) / 256, (int64_t)ctx->compute_units * 64);
+  const unsigned full_grid = (unsigned)((n16 + 255) / 256);
+  const uint4* src = (const uint4*)d_src;
+  uint4* dst = (uint4*)d_dst;
+  hipEvent_t e0, e1;
+  BNPK_HIP(ctx, hipEventCreate(&e0));
+  BNPK_HIP(ctx, hipEventCreate(&e1));
+  for (int v = 0; v < 4; ++v) {
+    for (int r = -1; r < reps; ++r) {                   // (r = -1: warm-up)
+      if (r == 0) BNPK_HIP(ctx, hipEventRecord(e0, s));
+      if (v == 0) hipLaunchKernelGGL(copy_peak_kernel, dim3(loop_grid), dim3(256), 0, s, src, dst, n16);
+      if (v == 1) hipLaunchKernelGGL(copy_plain_kernel, dim3(loop_grid), dim3(256), 0, s, src, dst, n16);
+      if (v == 2) hipLaunchKernelGGL(copy_oneshot_kernel, dim3(full_grid), dim3(256), 0, s, src, dst, n16);
+      if (v == 3) hipLaunchKernelGGL(copy_unrolled_kernel, dim3(loop_grid), dim3(256), 0, s, src, dst, n16);
+    }
+    BNPK_HIP(ctx, hipEventRecord(e1, s));
+    BNPK_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    BNPK_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    h_gb_per_s4[v] = ms > 0 ? 2.0 * (double)(n16 * 16) * reps / (ms * 1e-3) / 1e9 : 0.0;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return BNPK_OK;
 }
 

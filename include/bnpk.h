@@ -103,6 +103,10 @@ int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t*
  * d_dst with 16-byte non-temporal accesses, timed with hipEvents; *h_gb_per_s = (bytes read + bytes written) / time.
  * Synchronous. */
 int bnpk_copy_peak(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s, void* stream);
+/* the same copy in four forms, h_gb_per_s4 = {16-byte non-temporal accesses in a grid-stride loop (bnpk_copy_peak), plain
+ * accesses in the same loop, one 16-byte element per thread and no loop (the float4 copy MI355X_MICROARCH.md quotes at
+ * 6.29 TB/s), four independent elements per thread and iteration}: bench.py states the fastest as what this chip copies at */
+int bnpk_copy_rates(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes, int reps, double* h_gb_per_s4, void* stream);
 
 /* ---- tuning knobs (tests and experiments; the defaults are what the product path uses) --------
  * "finish_mode": which finishing kernels bnpk_finish_sorted launches — 0 = chosen per call (default): a sample of the
