@@ -332,6 +332,9 @@ def main():
                          "not a scaling measurement)")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned RAM -> HBM) measurement")
     ap.add_argument("--host-fed-batches", type=int, default=2)
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: accept torch.distributed's collectives if the C-ABI (RCCL) communicator cannot be made; without "
+                         "this flag such a run FAILS instead of reporting a number measured on another path")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the secondary workloads (S-genome, config 3, config 5) that follow the timed region of `value`")
     ap.add_argument("--verify", action="store_true", help="check the first reads against the oracle")
@@ -433,6 +436,16 @@ def main():
         per_rank = {"distinct_keys_held": [int(g[0]) for g in gathered], "kmers_generated": [int(g[1]) for g in gathered]}
     dt = float(tmax.item())
 
+    if world > 1:
+        # what ran must be what is claimed: N ranks over the library's own RCCL communicator (every rank checks; the
+        # decision to fall back is collective, so they all agree)
+        from bionumpy_amd import parallel as _par
+        used = _par.collectives().name
+        if not used.startswith("bnpk C-ABI") and not args.allow_fallback:
+            sys.stderr.write("bench.py: rank %d ran its collectives over %r, not the C-ABI communicator (--allow-fallback accepts that)\n"
+                             % (rank, used))
+            dist.destroy_process_group()
+            sys.exit(3)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -86,6 +86,18 @@ const rccl_api& rccl() {
     }                                                       \
   } while (0)
 
+// inside ncclGroupStart ... ncclGroupEnd: an error closes the group before it is reported (a group left open swallows
+// every later call of the thread)
+#define BNPK_RCCL_IN_GROUP(api, call)                       \
+  do {                                                      \
+    ncclResult_t r__ = (call);                              \
+    if (r__ != ncclSuccess) {                               \
+      g_last_rccl_error = (api).GetErrorString(r__);        \
+      (void)(api).GroupEnd();                               \
+      return BNPK_ERR_HIP;                                  \
+    }                                                       \
+  } while (0)
+
 int comm_shape(const rccl_api& a, ncclComm_t comm, int& world, int& rank) {
   BNPK_RCCL(a, a.CommCount(comm, &world));
   BNPK_RCCL(a, a.CommUserRank(comm, &rank));
@@ -163,8 +175,8 @@ int bnpk_exchange_counts(bnpk_ctx* ctx, void* comm, const int64_t* h_send_counts
   BNPK_HIP(ctx, hipMemcpyAsync(d_send, h_send_counts, words * 8, hipMemcpyHostToDevice, s));
   BNPK_RCCL(a, a.GroupStart());
   for (int p = 0; p < world; ++p) {
-    BNPK_RCCL(a, a.Send(d_send + (size_t)p * n_per_peer, (size_t)n_per_peer, ncclInt64, p, (ncclComm_t)comm, s));
-    BNPK_RCCL(a, a.Recv(d_recv + (size_t)p * n_per_peer, (size_t)n_per_peer, ncclInt64, p, (ncclComm_t)comm, s));
+    BNPK_RCCL_IN_GROUP(a, a.Send(d_send + (size_t)p * n_per_peer, (size_t)n_per_peer, ncclInt64, p, (ncclComm_t)comm, s));
+    BNPK_RCCL_IN_GROUP(a, a.Recv(d_recv + (size_t)p * n_per_peer, (size_t)n_per_peer, ncclInt64, p, (ncclComm_t)comm, s));
   }
   BNPK_RCCL(a, a.GroupEnd());
   BNPK_HIP(ctx, hipMemcpyAsync(h_recv_counts, d_recv, words * 8, hipMemcpyDeviceToHost, s));
@@ -199,8 +211,9 @@ int bnpk_exchange_slices(bnpk_ctx* ctx, void* comm, const int64_t* d_send, const
   for (int p = 0; p < world; ++p) {
     if (p == rank) continue;
     if (h_send_counts[p] > 0)
-      BNPK_RCCL(a, a.Send(d_send + h_send_offsets[p], (size_t)h_send_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
-    if (h_recv_counts[p] > 0) BNPK_RCCL(a, a.Recv(d_recv + recv_off[p], (size_t)h_recv_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
+      BNPK_RCCL_IN_GROUP(a, a.Send(d_send + h_send_offsets[p], (size_t)h_send_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
+    if (h_recv_counts[p] > 0)
+      BNPK_RCCL_IN_GROUP(a, a.Recv(d_recv + recv_off[p], (size_t)h_recv_counts[p], ncclInt64, p, (ncclComm_t)comm, s));
   }
   BNPK_RCCL(a, a.GroupEnd());
   return BNPK_OK;

@@ -9,7 +9,9 @@ ABI's communicator cannot be made (reported, never silent).
 * dense histograms (k <= 13): all-reduce (sum) of the 4^k int64 bins.
 * sparse histograms (k up to 31): the 62-bit key space is cut into ``world`` contiguous ranges and the result stays
   distributed — rank r holds the sorted distinct keys of range r and their global counts.  Two plans, chosen from the
-  data (``choose_plan``: every rank counts one of its fine buckets; the distinct / total ratio is summed over ranks):
+  data (``choose_plan``: every rank counts one of its fine buckets, (distinct, total) are summed over the ranks and both
+  plans are priced with them — ``plan_costs``: link bytes at what a GPU's xGMI links move together, the counting passes at
+  what they stream at, the exchange of plan "keys" hidden behind the counting as far as its steps allow):
 
   - ``keys``   (nearly) duplicate-free k-mers: every rank generates its hashes already grouped by their top bits
     (bnpk_kmers_partition; the bucket boundaries are the send cuts), ONE exchange moves every raw 8-byte hash to the
@@ -32,7 +34,6 @@ from .ops import get_ops
 
 FINE_BITS = 8          # partition granularity: 256 fine buckets, contiguous groups of them per rank
 KEY_GROUPS = 4         # plan "keys": steps the exchange is cut into (the parts of a rank's key range), overlapped with the counting
-COUNTS_PLAN_MAX_RATIO = 0.25      # distinct / total below which 16 B per distinct key beats 8 B per k-mer (with room)
 PROBE_KEYS = 4 << 20              # keys of one fine bucket that a rank counts to estimate the ratio
 
 
@@ -99,34 +100,86 @@ class TorchCollectives:
         return self.exchange(_from_tensor(packed, ops), send_counts, recv_counts)
 
 
+def agree_on_communicator(group, take_id, make, undo, vote_device="cpu"):
+    """the handshake of AbiCollectives, with the communicator's own calls passed in (the CPU tests pass stand-ins):
+    rank 0's ``take_id()`` result — or None if it raised — is broadcast; every rank calls ``make(id)``; the outcomes are
+    all-reduced (MIN); unless all succeeded, every rank calls ``undo()`` and raises.  All ranks return or all ranks raise."""
+    import torch
+    dist = _dist()
+    rank = dist.get_rank(group)
+    box, why = [None], ""
+    if rank == 0:
+        try:
+            box[0] = take_id()
+        except Exception as e:                           # noqa: BLE001  (told to everybody below)
+            why = "%s: %s" % (type(e).__name__, e)
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if box[0] is None:
+        raise RuntimeError("rank 0 could not take a communicator id%s" % ((" (%s)" % why) if why else ""))
+    ok = 1
+    try:
+        make(box[0])
+    except Exception as e:                               # noqa: BLE001  (reported below, by every rank, after the vote)
+        ok, why = 0, "%s: %s" % (type(e).__name__, e)
+    vote = torch.tensor([ok], dtype=torch.int32, device=vote_device)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+    if int(vote.item()) == 0:
+        undo()
+        raise RuntimeError("the communicator failed on %s" % (("this rank (%s)" % why) if not ok else "another rank"))
+
+
 class AbiCollectives:
     """the same over the C-ABI (RCCL inside libbnpk.so): a communicator of its own, made from an id that rank 0 takes and
     torch.distributed broadcasts"""
     name = "bnpk C-ABI (RCCL)"
 
     def __init__(self, group=None):
+        """Collective on every path: whether the communicator can be used is decided by ALL ranks together, so that either
+        every rank gets an AbiCollectives or every rank raises (and collectives() falls back everywhere).  A rank that
+        failed on its own and went on with other collectives would leave its peers blocked in this handshake.
+          1. rank 0 takes the id; what is broadcast is the id or None (RCCL cannot be loaded there: nobody goes on);
+          2. every rank makes its communicator and runs one small all-reduce on it; the outcomes are all-reduced (MIN) over
+             torch.distributed — one failure anywhere and every rank destroys what it made and raises."""
         from ._native import lib, check
         from .device import Device
+        import torch
         dist = _dist()
         self.lib, self._check = lib, check
         self.dev = Device.get()
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [None]
-        if self.rank == 0:
+        self.comm = None
+
+        def take_id():
             ident = (C.c_uint8 * 128)()
-            check(lib.bnpk_comm_unique_id(ident), self.dev.ctx)
-            box[0] = bytes(ident)
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
-        comm = C.c_void_p()
-        check(lib.bnpk_comm_init(self.dev.ctx, ident, self.world, self.rank, C.byref(comm)), self.dev.ctx)
-        self.comm = comm
-        # one small all-reduce before anything depends on it
-        import torch
-        probe = torch.ones(1, dtype=torch.int64, device=self.dev.tdev)
-        self._chk(lib.bnpk_allreduce_hist(self.dev.ctx, self.comm, C.c_void_p(probe.data_ptr()), 1, self.dev.stream()))
-        if int(probe.item()) != self.world:
-            raise RuntimeError("bnpk_allreduce_hist over %d ranks returned %d" % (self.world, int(probe.item())))
+            status = lib.bnpk_comm_unique_id(ident)
+            if status != 0:
+                raise RuntimeError("bnpk_comm_unique_id: status %d" % status)
+            return bytes(ident)
+
+        def make(raw_id):
+            ident = (C.c_uint8 * 128).from_buffer_copy(raw_id)
+            comm = C.c_void_p()
+            status = lib.bnpk_comm_init(self.dev.ctx, ident, self.world, self.rank, C.byref(comm))
+            if status != 0:
+                raise RuntimeError("bnpk_comm_init: status %d (%s)" % (status, lib.bnpk_last_comm_error().decode()))
+            self.comm = comm
+            probe = torch.ones(1, dtype=torch.int64, device=self.dev.tdev)     # one small all-reduce before anything depends on it
+            self._chk(lib.bnpk_allreduce_hist(self.dev.ctx, self.comm, C.c_void_p(probe.data_ptr()), 1, self.dev.stream()))
+            if int(probe.item()) != self.world:
+                raise RuntimeError("bnpk_allreduce_hist over %d ranks returned %d" % (self.world, int(probe.item())))
+
+        agree_on_communicator(group, take_id, make, self.close, self.dev.tdev if dist.get_backend(group) == "nccl" else "cpu")
+        import atexit
+        atexit.register(self.close)
+
+    def close(self):
+        """ncclCommDestroy of the communicator this object made (at exit, or when the ranks agree not to use it)"""
+        comm, self.comm = self.comm, None
+        if comm is not None:
+            try:
+                self.lib.bnpk_comm_destroy(comm)
+            except Exception:                            # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def _chk(self, status):
         if status != 0:
@@ -169,7 +222,7 @@ class AbiCollectives:
 
 
 _collectives = {}
-last = {"plan": None, "collectives": None, "groups": None}     # what the last sparse merge of this process did (bench.py reports it)
+last = {"plan": None, "collectives": None, "groups": None, "probe": None}     # what the last sparse merge of this process did (bench.py reports it)
 
 
 def collectives(group=None):
@@ -208,23 +261,90 @@ def _slice(h, a, b):
     return HArray(dev=h.dev()[a:b]) if h.on_device else HArray(host=h.host()[a:b])
 
 
+SKETCH_SLOTS = 1 << 16            # linear-counting slots of the probe's sketch
+SKETCH_SAMPLE = 256               # ... over the distinct keys whose mixed hash is 0 modulo this (the same keys on every rank)
+_MIX = np.uint64(0x9E3779B97F4A7C15)
+
+
 def probe_ratio(part, cuts, key_bits, rank=0):
-    """(distinct, total) of one fine bucket of this rank's k-mers (at most PROBE_KEYS of them)"""
+    """(distinct, total, sketch) of one fine bucket of this rank's k-mers (at most PROBE_KEYS of them) — the SAME bucket on
+    every rank, so that what the ranks found can be put together: the sketch marks, for a hash-chosen 1/SKETCH_SAMPLE of the
+    distinct keys, one of SKETCH_SLOTS slots each; summed over the ranks, the number of marked slots gives the number of
+    distinct keys of the bucket in the whole job (linear counting), i.e. how far the runs of the "counts" plan shrink when
+    they are merged"""
     ops = get_ops()
+    sketch = np.zeros(SKETCH_SLOTS, dtype=np.int64)
     sizes = np.diff(cuts)
     if sizes.sum() == 0:
-        return 0, 0
-    order = np.flatnonzero(sizes > 0)
-    b = int(order[(rank * 37) % order.size])                 # (different ranks look at different buckets)
+        return 0, 0, sketch
+    b = int(np.argmax(sizes > 0)) if sizes[37 % sizes.size] == 0 else 37 % sizes.size   # (bucket 37 unless this rank has nothing there)
     a, e = int(cuts[b]), int(min(cuts[b + 1], cuts[b] + PROBE_KEYS))
     sample = _slice(part, a, e)
     sample = HArray(dev=sample.dev().clone()) if sample.on_device else HArray(host=sample.host().copy())
     keys, _ = ops.count_sparse(sample, key_bits=key_bits, consume=True)
-    return keys.size, e - a
+    mixed = keys.host().astype(np.uint64) * _MIX
+    mixed ^= mixed >> np.uint64(29)
+    chosen = mixed[(mixed & np.uint64(SKETCH_SAMPLE - 1)) == 0]
+    sketch[((chosen >> np.uint64(8)) % np.uint64(SKETCH_SLOTS)).astype(np.int64)] = 1
+    return keys.size, e - a, sketch
 
 
-def choose_plan(distinct, total):
-    return "counts" if total > 0 and distinct <= COUNTS_PLAN_MAX_RATIO * total else "keys"
+def global_distinct(sketch_sum):
+    """distinct keys of the probed bucket over all ranks, from the summed sketches (linear counting: n = -m ln(empty / m))"""
+    m = sketch_sum.size
+    empty = int(np.count_nonzero(sketch_sum == 0))
+    if empty == 0:
+        return float("inf")
+    return -m * np.log(empty / m) * SKETCH_SAMPLE
+
+
+# what the plans are priced with (per GPU): bytes per second all xGMI links of a GPU move together in a grouped send/recv —
+# ASSUMED, never measured (no multi-GPU node has run this): 7 links x 25 GB/s of payload each way, a third of the 76.8 GB/s
+# per direction the wire is quoted at (MI355X_MICROARCH.md: 153.6 GB/s per link, both ways); a pessimistic link favours
+# the plan that moves fewer bytes, which is the safer mistake where the link is the bound — and what the counting kernels
+# stream at (DESIGN §5: the partition levels and the finishing kernels run at ~5 TB/s)
+LINK_BYTES_PER_S = 175e9
+HBM_BYTES_PER_S = 5.0e12
+
+
+def plan_costs(distinct, total, world, distinct_global=None):
+    """seconds per k-mer of one rank for either plan of the sparse merge, from the probe summed over the ranks:
+    ``distinct`` of the ``total`` sampled k-mers are distinct on the rank that holds them (what the ranks' own histograms
+    keep, summed), ``distinct_global`` are distinct in the whole job (default: as if the ranks shared no key).
+
+    keys    level 1 with the send cuts (8 B written), the exchange of 8 B per k-mer to the N - 1 peers hidden behind the
+            counting of what arrived (KEY_GROUPS steps: the longer of the two, plus one step that overlaps with nothing),
+            and the counting itself: the levels below the send cuts (the 8-bit pre-exchange level resolves less than a full
+            one, so the received keys take two levels where a GPU on its own takes one more than the fused first) and the
+            finishing pass over keys that repeat as they do in the whole job;
+    counts  the single-GPU count of the rank's own k-mers, 16 B per LOCALLY distinct key over the links, and the tree of
+            merges over the N runs a rank receives: level j writes (and reads) 16 B per key of runs that cannot hold more than
+            the job's distinct keys of their range."""
+    if total <= 0:
+        return {"keys": 0.0, "counts": 0.0}
+    world = max(int(world), 2)
+    r = distinct / total
+    rg = r if distinct_global is None else min(r, distinct_global / total)     # (per k-mer of the job: total is summed over the ranks)
+    f = (world - 1) / world
+    level = (8 + 16) / HBM_BYTES_PER_S                     # histogram pass + scatter of one partition level, per key
+    finish = lambda ratio: (8 + 16 * ratio) / HBM_BYTES_PER_S
+    link = 8 * f / LINK_BYTES_PER_S
+    count_received = 2 * level + finish(rg)
+    keys = 8 / HBM_BYTES_PER_S + max(link, count_received) + min(link, count_received) / KEY_GROUPS
+    merges, sources = 0.0, 1
+    while sources < world:                                 # (per k-mer of this rank: its runs hold r keys, the job's range world * rg)
+        sources *= 2
+        merges += 2 * 16 * min(r, world * rg / max(world / sources, 1)) / HBM_BYTES_PER_S
+    counts = 8 / HBM_BYTES_PER_S + level + finish(r) + 16 * r * f / LINK_BYTES_PER_S + merges
+    return {"keys": float(keys), "counts": float(counts)}
+
+
+def choose_plan(distinct, total, world=8, distinct_global=None):
+    """the cheaper plan by plan_costs (world: ranks of the job)"""
+    if total <= 0:
+        return "keys"
+    c = plan_costs(distinct, total, world, distinct_global)
+    return "counts" if c["counts"] < c["keys"] else "keys"
 
 
 def _merge_runs(runs):
@@ -372,9 +492,10 @@ def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto
         hashes, cuts_np = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
         cuts = HArray(host=np.asarray(cuts_np, dtype=np.int64))
     if plan == "auto":
-        d, t = probe_ratio(hashes, np.asarray(cuts.host(), dtype=np.int64), key_bits, coll.rank)
-        both = coll.allreduce_sum(HArray(host=np.array([d, t], dtype=np.int64))).host()
-        plan = choose_plan(int(both[0]), int(both[1]))
+        d, t, sketch = probe_ratio(hashes, np.asarray(cuts.host(), dtype=np.int64), key_bits, coll.rank)
+        both = coll.allreduce_sum(HArray(host=np.concatenate([[d, t], sketch]).astype(np.int64))).host()
+        plan = choose_plan(int(both[0]), int(both[1]), coll.world, global_distinct(both[2:]))
+        last["probe"] = {"distinct_local_sum": int(both[0]), "total": int(both[1]), "distinct_global_estimate": float(global_distinct(both[2:]))}
     last["plan"], last["collectives"] = plan, coll.name
     if plan == "counts":
         keys, counts = ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, FINE_BITS))
@@ -403,10 +524,12 @@ def count_sparse_virtual(shards, key_bits, plan="auto", groups=None):
     cuts = [np.asarray(c.host(), dtype=np.int64) for _, c in shards]
     if plan == "auto":
         d = t = 0
+        sketch = np.zeros(SKETCH_SLOTS, dtype=np.int64)
         for r, ((part, _), c) in enumerate(zip(shards, cuts)):
-            dr, tr = probe_ratio(part, c, key_bits, r)
-            d, t = d + dr, t + tr
-        plan = choose_plan(d, t)
+            dr, tr, sr = probe_ratio(part, c, key_bits, r)
+            d, t, sketch = d + dr, t + tr, sketch + sr
+        plan = choose_plan(d, t, world, global_distinct(sketch))
+        last["probe"] = {"distinct_local_sum": int(d), "total": int(t), "distinct_global_estimate": float(global_distinct(sketch))}
     out, received = [], []
     if plan == "counts":
         local = [ops.count_sparse(part, key_bits=key_bits, partition=(c, FINE_BITS)) for part, c in shards]   # (c: the HArray)

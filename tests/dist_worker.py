@@ -41,6 +41,27 @@ def main():
         assert parallel.last["plan"] == plan and (plan == "counts" or parallel.last["groups"] == (groups or parallel.KEY_GROUPS))
         out[plan if groups is None else "keys/%d" % groups] = (keys.host().copy(), counts.host().copy())
     assert parallel.collectives().name == "torch.distributed"
+    # the handshake of the C-ABI communicator (parallel.agree_on_communicator) with stand-ins for its calls: whatever fails
+    # on whichever rank, EVERY rank raises (and falls back together) — none is left blocked in a collective
+    made, undone = [], []
+    parallel.agree_on_communicator(None, lambda: b"id", lambda raw: made.append(raw), lambda: undone.append(1))
+    assert made == [b"id"] and not undone
+    def fails_on(bad_rank):
+        def make(raw):
+            if rank == bad_rank:
+                raise OSError("librccl.so: cannot open shared object file")
+        return make
+    def no_id():
+        raise OSError("no RCCL here")
+    for take, make, word in ((lambda: b"id", fails_on(world - 1), "failed on"), (lambda: b"id", fails_on(0), "failed on"),
+                             (no_id, lambda raw: None, "rank 0 could not")):
+        undone = []
+        try:
+            parallel.agree_on_communicator(None, take, make, lambda: undone.append(1))
+            raise AssertionError("a communicator that failed somewhere was accepted on rank %d" % rank)
+        except RuntimeError as e:
+            assert word in str(e), e
+    dist.barrier()                                            # (every rank is still in step)
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:
