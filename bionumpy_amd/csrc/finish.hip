@@ -1225,7 +1225,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
     if (use_general) BNPK_CHECK(general(false, 0));
   }
   BNPK_CHECK(read_header());
-  *h_overflow = (host[FS_FLAGS] & 3) != 0;
+  *h_overflow = (int)(host[FS_FLAGS] & 3);              // 1: a bucket over the capacity without a pre-counted entry; 2: a wait gave up
   *h_n_unique = host[FS_UNIQUE];
   return BNPK_OK;
 }

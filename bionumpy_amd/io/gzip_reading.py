@@ -15,6 +15,7 @@ import collections
 import os
 import struct
 import threading
+import gzip
 import zlib
 from concurrent.futures import ThreadPoolExecutor
 
@@ -46,7 +47,13 @@ def _inflate_members(blob):
     while pos < n:
         size = _bgzf_block_size(blob[pos:pos + 64])
         xlen = struct.unpack_from("<H", blob, pos + 10)[0]
-        out.append(zlib.decompress(blob[pos + 12 + xlen:pos + size - 8], wbits=-15))
+        text = zlib.decompress(blob[pos + 12 + xlen:pos + size - 8], wbits=-15)
+        # the member's trailer: CRC32 and length of its text, as gzip.GzipFile (and isal in the reference) check them —
+        # a damaged bgzip file raises instead of being parsed
+        crc, isize = struct.unpack_from("<II", blob, pos + size - 8)
+        if zlib.crc32(text) != crc or (len(text) & 0xFFFFFFFF) != isize:
+            raise gzip.BadGzipFile("CRC check failed in a BGZF member at compressed offset %d" % pos)
+        out.append(text)
         pos += size
     return b"".join(out)
 

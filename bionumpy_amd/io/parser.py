@@ -75,6 +75,7 @@ class _Staging:
 
 
 _early_cache = []                  # _EarlyUpload objects of closed readers
+_EARLY_KEEP_BYTES = 1 << 30        # device staging a closed reader may leave behind for the next one
 
 
 class _EarlyUpload:
@@ -200,6 +201,13 @@ class NumpyFileReader:
 
     def _release_early(self):
         self._early.stream.synchronize()                     # nothing may still be copying into its buffers when they change hands
+        # the next reader takes it over — its copy stream and its staging in HBM, as long as that is small: what a reader of
+        # gigabyte batches staged (three buffers of a batch each) goes back to the allocator instead of being kept from the
+        # counting kernels for the life of the process
+        held = sum(b.numel() for b in self._early.buffers if b is not None)
+        if held > _EARLY_KEEP_BYTES:
+            self._early.buffers = [None] * len(self._early.buffers)
+            self._early.free_events = [None] * len(self._early.free_events)
         if len(_early_cache) < 2:
             _early_cache.append(self._early)
         self._early = None

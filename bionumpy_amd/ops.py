@@ -719,9 +719,14 @@ class HipOps:
                                                  C.byref(n_unique), C.byref(overflow), self._s()))
                 if self.keep_finish_state:               # (experiments: the header words of the finishing kernels)
                     self.last_finish_state = state[:128].cpu().numpy()
-                if overflow.value:                       # every bucket was checked against the capacity above
+                if overflow.value & 1:                   # every bucket was checked against the capacity above
                     raise RuntimeError("bnpk_finish_sorted reported an overflow on buckets that fit")
-                return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
+                if overflow.value == 0:
+                    return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
+                # a wait between workgroups gave up (bit 1: a run-time condition, not a capacity one — more plausible with
+                # another stream's kernels on the CUs): the partitioned keys are intact, the slower sort gives the answer
+                cur, owned = work, True
+                del keys_out, counts, state
             del spare, big
         keys_out, counts = self._count_by_sorting(cur if owned else cur.clone(), key_bits)
         if dest is not None:

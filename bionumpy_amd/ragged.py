@@ -258,7 +258,13 @@ class RaggedArray:
         data = data._unpacked() if hasattr(data, "_unpacked") else data
         return data.host()[:self.total()]
 
+    @staticmethod
+    def _check_axis(axis):
+        if axis not in (None, 0, 1, -1):
+            raise ValueError("axis %r of a ragged (two-dimensional) array" % (axis,))
+
     def sum(self, axis=-1):
+        self._check_axis(axis)
         if axis is None:
             return self._flat_values().sum()
         if axis == 0:
@@ -266,6 +272,7 @@ class RaggedArray:
         return self._row_reduce("sum")
 
     def mean(self, axis=-1):
+        self._check_axis(axis)
         if axis is None:
             return self._flat_values().mean()
         if axis == 0:
@@ -289,6 +296,10 @@ class RaggedArray:
         if axis == 0:                                                       # per column, over the rows that reach it
             values, cols = self._host_columns()
             n_cols = int(self.lengths.max()) if self._n_rows else 0
+            if values.dtype == np.bool_:                                    # (np.iinfo knows no bool: min = all, max = any per column)
+                as_u8 = RaggedArray._from_parts(HArray(host=values.view(np.uint8)), None, as_harray(self.lengths.astype(np.int64)), None,
+                                                self._n_rows, values.size)
+                return as_u8._extreme(what, 0).astype(np.bool_)
             if what == "min":
                 out = np.full(n_cols, np.inf if np.issubdtype(values.dtype, np.floating) else np.iinfo(values.dtype).max, dtype=values.dtype)
                 np.minimum.at(out, cols, values)

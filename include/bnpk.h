@@ -496,8 +496,11 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  *                         returns the number of distinct keys.  Buckets over the capacity (heavy-hitter keys) must
  *                         have been counted by the caller beforehand: d_big_table holds n_big {bucket, number of
  *                         distinct keys, offset into d_big_keys / d_big_counts} int64 triples sorted by bucket;
- *                         their pairs are copied into place.  *h_overflow = 1 means a bucket exceeded the capacity
- *                         without being listed: the outputs must be discarded (bnpk_sort_keys + run kernels).
+ *                         their pairs are copied into place.  *h_overflow != 0: the outputs must be discarded
+ *                         (bnpk_sort_keys + run kernels) — bit 0: a bucket exceeded the capacity without being
+ *                         listed (the caller's mistake); bit 1: a kernel that waits for other workgroups' results
+ *                         gave up waiting (a run-time condition — e.g. the CUs were shared with another stream's
+ *                         kernels; d_part is intact in that case and can be sorted instead).
  *                         d_state needs bnpk_finish_state_words(n_buckets) int64.  d_part is WORKSPACE: its contents
  *                         are undefined afterwards (the duplicate-aware kernel writes every bucket's distinct keys
  *                         back over the bucket's own keys before they are moved into place). */

@@ -891,6 +891,11 @@ def test_ragged_reductions_of_every_shape(bnp):
             assert sub.lengths.tolist() == [r[sl].size for r in rows]
     with pytest.raises(ValueError):
         RaggedArray(np.arange(3), [3, 0]).min(axis=-1)
+    for name in ("sum", "mean", "min", "max"):                                # a ragged array has two axes
+        with pytest.raises(ValueError):
+            getattr(RaggedArray(np.arange(3), [2, 1]), name)(axis=2)
+    flags = RaggedArray([[True, False, True], [False, False], [True]])       # bool rows: per column, any / all of the rows that reach it
+    assert np.array_equal(flags.max(axis=0), [True, False, True]) and np.array_equal(flags.min(axis=0), [False, False, True])
     # the k-mer use: the smallest hash of every read == what get_minimizers gives for one window per read
     seqs = bnp.as_encoded_array(["ACGTACGTAC", "TTTTGGGGCC", "GATTACAGAT"], bnp.DNAEncoding)
     kmers = bnp.sequence.get_kmers(seqs, 4)

@@ -81,6 +81,22 @@ def test_bgzf_without_the_empty_last_member_and_truncated(tmp_path):
             f.read()
 
 
+def test_damaged_bgzf_member_is_an_error_not_wrong_text(tmp_path):
+    """a member whose trailer does not match its text (CRC32 / length, as gzip.GzipFile and isal check them): the stored
+    checksum of one member is changed — the deflate stream still inflates, the text must not be handed out"""
+    data = fastq_text(5000)
+    blob = bytearray(bgzf_compress(data))
+    size = gz._bgzf_block_size(bytes(blob[:64]))
+    blob[size - 8] ^= 0x5A                                           # first member: a bit pattern of its CRC32
+    path = str(tmp_path / "damaged.fq.gz")
+    open(path, "wb").write(bytes(blob))
+    with pytest.raises(OSError):                                     # (gzip.BadGzipFile is an OSError)
+        with gz.open_gzip_for_reading(path) as f:
+            f.read()
+    with pytest.raises(OSError):
+        gzip.open(path, "rb").read()                                 # (the standard library agrees)
+
+
 @pytest.mark.parametrize("members", [1, 3])
 def test_plain_gzip_streams_one_member_or_several(tmp_path, members):
     data = fastq_text(20000)
