@@ -129,6 +129,7 @@ SIGNATURES = {
     "bnpk_radix_partition": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
     "bnpk_radix_small_capacity": (_i64, []),
     "bnpk_radix_partition_small": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
+    "bnpk_bucket_census": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_finish_state_words": (_i64, [_i64]),
     "bnpk_finish_sorted": (_int, [_p, _p, _i64, _p, _i64, _int, _p, _p, _p, _p, _int, _p, _p, C.POINTER(_i64),
                                   C.POINTER(_int), _p]),

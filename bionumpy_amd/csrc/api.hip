@@ -214,10 +214,10 @@ int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stre
 }
 
 int bnpk_fetch_i64(bnpk_ctx* ctx, const int64_t* d_src, int64_t n, int64_t* h_dst, void* stream) {
-  if (!ctx || n < 0 || n > 512) return BNPK_ERR_ARG;
+  if (!ctx || n < 0 || n > 4096) return BNPK_ERR_ARG;
   if (n == 0) return BNPK_OK;
   if (!d_src || !h_dst) return BNPK_ERR_ARG;
-  if (!ctx->mailbox) BNPK_HIP(ctx, hipHostMalloc(&ctx->mailbox, 512 * sizeof(int64_t), hipHostMallocDefault));
+  if (!ctx->mailbox) BNPK_HIP(ctx, hipHostMalloc(&ctx->mailbox, 4096 * sizeof(int64_t), hipHostMallocDefault));
   hipStream_t s = (hipStream_t)stream;
   BNPK_HIP(ctx, hipMemcpyAsync(ctx->mailbox, d_src, (size_t)n * 8, hipMemcpyDeviceToHost, s));
   BNPK_HIP(ctx, hipStreamSynchronize(s));

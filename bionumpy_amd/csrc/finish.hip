@@ -975,6 +975,47 @@ __global__ void finish_collect_kernel(const int64_t* __restrict__ T, const unsig
   }
 }
 
+// What the host decides on before the finishing call, in one reduction over the offsets: out[0] = keys of the largest bucket,
+// out[1] = buckets over `cap`, then {bucket, first key, keys} of the first max_list of those (ascending: one workgroup walks
+// the buckets in order once it is known that there are few).
+__global__ __launch_bounds__(256) void bucket_census_kernel(const int64_t* __restrict__ bucket_off, int64_t n_buckets, int64_t cap,
+                                                            unsigned long long* __restrict__ out) {
+  int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long largest = 0, over = 0;
+  for (; b < n_buckets; b += stride) {
+    const unsigned long long m = (unsigned long long)(bucket_off[b + 1] - bucket_off[b]);
+    largest = max(largest, m);
+    over += m > (unsigned long long)cap ? 1ull : 0ull;
+  }
+  largest = wave_reduce_max(largest);
+  over = wave_reduce_sum(over);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out[0], largest);
+    if (over) atomicAdd(&out[1], over);
+  }
+}
+__global__ __launch_bounds__(64) void bucket_list_kernel(const int64_t* __restrict__ bucket_off, int64_t n_buckets, int64_t cap, int max_list,
+                                                         unsigned long long* __restrict__ out) {
+  // (only launched when out[1] <= max_list: the list is short, the scan over the offsets is one wavefront's)
+  int listed = 0;
+  for (int64_t base = 0; base < n_buckets && listed < max_list; base += 64) {
+    const int64_t b = base + threadIdx.x;
+    const int64_t lo = b < n_buckets ? bucket_off[b] : 0, m = b < n_buckets ? bucket_off[b + 1] - lo : 0;
+    unsigned long long mask = __ballot(m > cap);
+    while (mask && listed < max_list) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      if ((int)threadIdx.x == l) {
+        out[2 + 3 * listed] = (unsigned long long)b;
+        out[3 + 3 * listed] = (unsigned long long)lo;
+        out[4 + 3 * listed] = (unsigned long long)m;
+      }
+      ++listed;
+    }
+  }
+}
+
 // How many buckets are too large for the fast kernel but not for the general one (the caller pre-counts only buckets
 // over the general kernel's capacity): with any of them the general kernel takes the call.
 __global__ void finish_fit_kernel(const int64_t* __restrict__ bucket_off, int64_t n_buckets, unsigned long long* __restrict__ header) {
@@ -1024,6 +1065,21 @@ __global__ __launch_bounds__(256) void finish_out_offsets_kernel(const int64_t* 
 extern "C" {
 
 int64_t bnpk_finish_capacity(void) { return FN_CAP; }
+
+int bnpk_bucket_census(bnpk_ctx* ctx, const int64_t* d_bucket_offsets, int64_t n_buckets, int64_t cap, int max_list, int64_t* d_out,
+                       void* stream) {
+  if (!ctx || !d_bucket_offsets || !d_out || n_buckets < 1 || cap < 0 || max_list < 0 || max_list > 4096) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "bucket_census", s);
+  BNPK_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)(2 + 3 * max_list) * 8, s));
+  hipLaunchKernelGGL(bucket_census_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
+                     d_bucket_offsets, n_buckets, cap, reinterpret_cast<unsigned long long*>(d_out));
+  if (max_list > 0)
+    hipLaunchKernelGGL(bucket_list_kernel, dim3(1), dim3(64), 0, s, d_bucket_offsets, n_buckets, cap, max_list,
+                       reinterpret_cast<unsigned long long*>(d_out));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
 
 // d_state: the header words; then either the general kernel's 64-bit status words, or the fast path's bookkeeping
 // (announcements, distinct counts, per-bucket notes, redo marks); the redo list; the adjusted output offsets.

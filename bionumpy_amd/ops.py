@@ -676,15 +676,17 @@ class HipOps:
             cap = int(lib.bnpk_finish_capacity())
             big, fits = None, False
             for attempt in range(3):
-                sizes = offsets[1:] - offsets[:-1]
-                largest = int(sizes.max().item())
+                # the largest bucket, how many are over the capacity, and which (one reduction, one download)
+                census = self._empty(2 + 3 * self.MAX_PRECOUNTED, np.int64)
+                self._chk(lib.bnpk_bucket_census(self.ctx, ptr(offsets), n_seg, cap, self.MAX_PRECOUNTED, ptr(census), self._s()))
+                largest, n_over = self._fetch(census, 2)
                 if largest <= cap:
                     fits = True
                     break
-                over = (sizes > cap).nonzero().flatten()
                 bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
-                if over.numel() <= self.MAX_PRECOUNTED:
-                    big = self._precount_buckets(cur, offsets, over, key_bits)
+                if n_over <= self.MAX_PRECOUNTED:
+                    listed = np.array(self._fetch(census[2:], 3 * n_over), dtype=np.int64).reshape(n_over, 3)
+                    big = self._precount_buckets(cur, listed, key_bits)
                     fits = True
                     break
                 if attempt == 2 or bits <= 0:
@@ -752,31 +754,33 @@ class HipOps:
         self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, None, ptr(counts), self._s()))
         return keys_out, counts
 
-    def _precount_buckets(self, keys_t, offsets_t, bucket_ids_t, key_bits):
-        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets (ascending ids) counted in ONE batch — their
-        keys are gathered into one array (bnpk_gather_rows over the buckets' byte ranges), sorted and run-length-counted
-        once (buckets differ in their top bits, so the batch sorts bucket by bucket), and the distinct keys are cut
-        back into buckets by a binary search of every bucket's first possible key."""
+    def _precount_buckets(self, keys_t, listed, key_bits):
+        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets — rows {bucket, index of its first key, its keys}
+        on the host, ascending (bnpk_bucket_census) — counted in ONE batch: their keys are gathered into one array
+        (bnpk_gather_rows over the buckets' byte ranges), sorted and run-length-counted once (buckets differ in their top
+        bits, so the batch sorts bucket by bucket), and the distinct keys are cut back into buckets by a binary search of
+        every bucket's first possible key.  The few offsets involved are host arithmetic; nothing of it is a tensor op."""
         t = torch_mod()
-        nb = int(bucket_ids_t.numel())
-        lo = offsets_t[bucket_ids_t]
-        sizes = offsets_t[bucket_ids_t + 1] - lo
-        byte_off = self._empty(nb + 1, np.int64)
-        byte_off[0] = 0
-        byte_off[1:] = t.cumsum(sizes * 8, 0)
-        total = int(byte_off[nb].item())
+        nb = listed.shape[0]
+        ids, lo, sizes = listed[:, 0], listed[:, 1], listed[:, 2]
+        byte_off = np.zeros(nb + 1, dtype=np.int64)
+        byte_off[1:] = np.cumsum(sizes * 8)
+        total = int(byte_off[nb])
         batch = self._empty(total, np.uint8)
-        self._chk(lib.bnpk_gather_rows(self.ctx, ptr(keys_t.view(t.uint8)), ptr(lo * 8), ptr(byte_off), nb, total, 0,
-                                       ptr(batch), self._s()))
+        # (named, so that they live until the launch: a temporary freed between two uploads hands its memory to the next one)
+        d_lo, d_off = self.device.upload(lo * 8), self.device.upload(byte_off)
+        self._chk(lib.bnpk_gather_rows(self.ctx, ptr(keys_t.view(t.uint8)), ptr(d_lo), ptr(d_off), nb, total, 0, ptr(batch), self._s()))
         k, c = self._count_by_sorting(batch.view(t.int64), key_bits)
         # the distinct keys of listed bucket b start where the keys (with multiplicity) of the earlier listed buckets end
-        prefix = t.cumsum(sizes, 0) - sizes                  # keys (with multiplicity) of earlier buckets in the batch
+        prefix = np.cumsum(sizes) - sizes                    # keys (with multiplicity) of earlier buckets in the batch
         cum = self._empty(k.numel() + 1, np.int64)
         self._chk(lib.bnpk_exclusive_scan_i64(self.ctx, ptr(c), c.numel(), ptr(cum), self._s()))
-        starts = self._empty(nb, np.int64)
-        self._chk(lib.bnpk_search_sorted(self.ctx, ptr(cum), cum.numel(), ptr(prefix), nb, 0, ptr(starts), self._s()))
-        ends = t.cat([starts[1:], t.tensor([k.numel()], dtype=t.int64, device=starts.device)])
-        table = t.stack([bucket_ids_t.to(t.int64), ends - starts, starts], dim=1).reshape(-1).contiguous()
+        starts_t = self._empty(nb, np.int64)
+        d_prefix = self.device.upload(prefix)
+        self._chk(lib.bnpk_search_sorted(self.ctx, ptr(cum), cum.numel(), ptr(d_prefix), nb, 0, ptr(starts_t), self._s()))
+        starts = np.array(self._fetch(starts_t), dtype=np.int64)
+        ends = np.concatenate([starts[1:], [k.numel()]])
+        table = self.device.upload(np.stack([ids, ends - starts, starts], axis=1).reshape(-1).astype(np.int64))
         return table, k, c
 
     def merge_add(self, a_keys, a_counts, b_keys, b_counts):

@@ -138,7 +138,7 @@ int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stre
 int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst, int64_t bytes, int n_threads, int64_t piece_bytes,
                         void* d_dst, void* stream, int64_t* h_read);
 int bnpk_stream_sync(void* stream);
-/* the first n (<= 512) words of a device array, on the host: one hipMemcpyAsync into a page-locked mailbox of the ctx behind
+/* the first n (<= 4096) words of a device array, on the host: one hipMemcpyAsync into a page-locked mailbox of the ctx behind
  * everything enqueued on `stream`, one hipStreamSynchronize — how the host scalars of the chunk loop (totals, error cells,
  * cut tables) come back; a third of the cost of a pageable copy.  One host thread per ctx. */
 int bnpk_fetch_i64(bnpk_ctx* ctx, const int64_t* d_src, int64_t n, int64_t* h_dst, void* stream);
@@ -515,6 +515,12 @@ int64_t bnpk_radix_small_capacity(void);
 int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets,
                                int64_t n_seg, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets,
                                void* stream);
+/* what the caller of bnpk_finish_sorted decides on, in one pass over the bucket offsets and ONE download: d_out[0] = keys of
+ * the largest bucket, d_out[1] = buckets of more than `cap` keys, then {bucket, its first key's index, its keys} of the
+ * first max_list (<= 4096) of those in ascending order (all of them if d_out[1] <= max_list).  d_out: 2 + 3 * max_list words.
+ * (replaces sizes.max() / (sizes > cap).nonzero() on the offsets: two reductions and two downloads) */
+int bnpk_bucket_census(bnpk_ctx* ctx, const int64_t* d_bucket_offsets, int64_t n_buckets, int64_t cap, int max_list, int64_t* d_out,
+                       void* stream);
 int64_t bnpk_finish_state_words(int64_t n_buckets);
 int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t* d_bucket_offsets,
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,

@@ -515,6 +515,19 @@ def test_reverse_complement(bnp):
         assert out.tolist() == ["".join(comp[c] for c in reversed(r)) for r in rows]
         assert out.lengths.tolist() == [len(r) for r in rows]
         assert bnp.sequence.get_reverse_complement(out).tolist() == rows              # an involution
+    # the other alphabets over A, C, G, T, N (dna.py:13-26: the complemented alphabet encoded with the alphabet itself)
+    comp_n = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rows_n = ["ACGNT", "", "N", "GGANNTTC", "ACGTN" * 9]
+    for enc in (bnp.encodings.ACGTnEncoding, bnp.encodings.ACTGEncoding, bnp.encodings.ACTGnEncoding):
+        use = [r.replace("N", "A") for r in rows_n] if len(enc.get_alphabet()) == 4 else rows_n
+        seqs = bnp.as_encoded_array(use, enc)
+        out = bnp.sequence.get_reverse_complement(seqs)
+        assert out.encoding == enc and [x.upper() for x in out.tolist()] == ["".join(comp_n[c] for c in reversed(r)) for r in use]
+        assert [x.upper() for x in bnp.sequence.get_reverse_complement(out).tolist()] == use
+        one = bnp.sequence.get_reverse_complement(bnp.as_encoded_array(use[3], enc))
+        assert str(one).upper() == "".join(comp_n[c] for c in reversed(use[3]))
+    with pytest.raises(KeyError):                                                     # an alphabet with a letter that has no complement
+        bnp.sequence.get_reverse_complement(bnp.as_encoded_array("ACUG", bnp.encodings.ACUGEncoding))
     # the ASCII table of the reference: N stays N, anything else becomes NUL (dna.py:29-33)
     odd = bnp.sequence.get_reverse_complement(bnp.as_encoded_array("ANxT"))
     assert np.asarray(odd.raw()).tolist() == [ord("A"), 0, ord("N"), ord("T")]
