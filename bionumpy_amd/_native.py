@@ -70,6 +70,7 @@ SIGNATURES = {
     "bnpk_scan_tiles": (_i64, [_i64]),
     "bnpk_byte_census": (_int, [_p, _p, _i64, _u8, _p, _p]),
     "bnpk_byte_positions": (_int, [_p, _p, _i64, _u8, _p, _i64, _p, _p]),
+    "bnpk_line_positions": (_int, [_p, _p, _i64, _p, _i64, _int, _u8, _int, _p, _p, _p]),
     "bnpk_validate_entries": (_int, [_p, _p, _p, _i64, _int, _u8, _int, _p, _p]),
     "bnpk_field_table": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
     "bnpk_window_cuts_words": (_i64, [_int]),

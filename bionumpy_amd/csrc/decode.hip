@@ -65,13 +65,24 @@ __global__ __launch_bounds__(BNPK_BLOCK) void byte_census_kernel(const uint8_t* 
   }
 }
 
+// VALIDATE: the newline table of a FASTQ / FASTA chunk and the checks of OneLineBuffer._validate / FastQBuffer._validate
+// (bionumpy/io/one_line_buffer.py:156-173, fastq_buffer.py:39-45) in the same pass: the thread that finds the newline in
+// front of a line looks at the line's first byte — it is in the tile it holds, or the byte behind it — instead of a second
+// kernel that gathers two table entries and two text bytes per entry from all over memory (2.4 ms per 50 M reads: 0.05 of
+// the HBM peak).  err[0] / err[1]: first entry whose header / third line starts wrongly (atomicMin); err[2]: bit 0 = a header
+// line of the first lpe entries ends in '\r', bit 1 = the first line is empty (then the reference leaves '\r' alone:
+// _modify_for_carriage_return, one_line_buffer.py:176-182).
+template <bool VALIDATE>
 __global__ __launch_bounds__(BNPK_BLOCK) void byte_positions_kernel(const uint8_t* __restrict__ buf, int64_t n,
                                                                     uint32_t rep,
                                                                     const int64_t* __restrict__ tile_offsets,
-                                                                    int64_t limit, int64_t* __restrict__ out) {
+                                                                    int64_t limit, int64_t* __restrict__ out, int lpe,
+                                                                    uint8_t header, int check_plus,
+                                                                    unsigned long long* __restrict__ err) {
   __shared__ int smem[WAVES];
   int64_t tile_base = (int64_t)blockIdx.x * TILE_BYTES;
   int64_t first = tile_offsets[blockIdx.x];
+  if (VALIDATE && blockIdx.x == 0 && threadIdx.x == 0 && limit >= lpe && buf[0] != header) atomicMin(&err[0], 0ull);
   if (first >= limit || tile_offsets[blockIdx.x + 1] == first) return;   // uniform per block
   uint32_t m[ITERS];
   int c = 0;
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void byte_positions_kernel(const uint8_
   __syncthreads();
   int64_t rank = first;
   for (int w = 0; w < wave_id(); ++w) rank += smem[w];
+  const int first_phase = VALIDATE ? (int)(first % lpe) : 0;           // (line index modulo lines per entry, in 32 bits from here)
   // matches are ordered (wave, iteration, lane, byte): rank the lanes of each iteration with a wave scan
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
@@ -96,7 +108,22 @@ __global__ __launch_bounds__(BNPK_BLOCK) void byte_positions_kernel(const uint8_
     while (mm) {
       int j = __ffs(mm) - 1;
       mm &= mm - 1;
-      if (r < limit) out[r] = pos + j;
+      if (r < limit) {
+        out[r] = pos + j;
+        if (VALIDATE) {
+          const int64_t p = pos + j;
+          const int phase = (int)((unsigned)(r - first) + (unsigned)first_phase) % lpe;     // of the line this newline ends
+          if (r + 1 < limit) {                               // the line behind it belongs to a complete entry
+            const int next = phase + 1 == lpe ? 0 : phase + 1;
+            if (next == 0 && buf[p + 1] != header) atomicMin(&err[0], (unsigned long long)((r + 1) / lpe));
+            if (check_plus && next == 2 && buf[p + 1] != '+') atomicMin(&err[1], (unsigned long long)((r + 1) / lpe));
+          }
+          if (phase == 0 && r < (int64_t)lpe * lpe) {        // the header line of one of the first lpe entries
+            if (r == 0 && p == 0) atomicOr(&err[2], 2ull);
+            if (p >= 1 && buf[p - 1] == '\r') atomicOr(&err[2], 1ull);
+          }
+        }
+      }
       ++r;
     }
     rank += __shfl(inc, 63, 64);
@@ -281,8 +308,28 @@ int bnpk_byte_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t 
   if (!d_pos) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "byte_positions", s);
-  hipLaunchKernelGGL(byte_positions_kernel, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n,
-                     0x01010101u * value, d_tile_offsets, limit, d_pos);
+  hipLaunchKernelGGL(byte_positions_kernel<false>, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n,
+                     0x01010101u * value, d_tile_offsets, limit, d_pos, 1, (uint8_t)0, 0, (unsigned long long*)nullptr);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_line_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, const int64_t* d_tile_offsets, int64_t n_lines,
+                        int lines_per_entry, uint8_t header, int check_plus, int64_t* d_pos, int64_t* d_err3, void* stream) {
+  if (!ctx || n < 0 || !d_tile_offsets || (n > 0 && !d_buf) || n_lines < 0 || !d_err3 || lines_per_entry < 1 ||
+      n_lines % lines_per_entry != 0 || (check_plus && lines_per_entry < 3))
+    return BNPK_ERR_ARG;
+  if (((uintptr_t)d_buf & 15) != 0) return BNPK_ERR_ALIGN;
+  int64_t tiles = bnpk_scan_tiles(n);
+  if (tiles > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "line_positions", s);
+  hipLaunchKernelGGL(init_err_kernel, dim3(1), dim3(1), 0, s, d_err3);
+  if (tiles > 0 && n_lines > 0) {
+    if (!d_pos) return BNPK_ERR_ARG;
+    hipLaunchKernelGGL(byte_positions_kernel<true>, dim3((unsigned)tiles), dim3(BNPK_BLOCK), 0, s, d_buf, n, 0x01010101u * (uint32_t)'\n',
+                       d_tile_offsets, n_lines, d_pos, lines_per_entry, header, check_plus, reinterpret_cast<unsigned long long*>(d_err3));
+  }
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

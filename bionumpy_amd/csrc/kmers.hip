@@ -244,7 +244,9 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __rest
                                                               uint64_t pattern_hash, wf_pattern pat,
                                                               const int64_t* __restrict__ tile_off,
                                                               uint8_t* __restrict__ out) {
-  __shared__ uint8_t stage[WF_TILE];
+  // (the tile's flags are staged at the output's own offset within 16 bytes, so that both the LDS reads and the global stores
+  // of the run are aligned 16-byte accesses: one store per lane and 16 flags instead of sixteen single-byte stores)
+  __shared__ __attribute__((aligned(16))) uint8_t stage[WF_TILE + 32];
   __shared__ unsigned wsum[BNPK_BLOCK / 64];
   const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
   const unsigned v = o < n_items ? mask8[o >> 3] : 0u;
@@ -279,7 +281,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __rest
     }
   }
   __syncthreads();
-  unsigned rank = inc - cnt;
+  const int64_t base = tile_off[blockIdx.x];
+  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
+  const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(out + base) & 15u);
+  unsigned rank = skew + inc - cnt;
   for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
   if (v) {
 #pragma unroll
@@ -287,9 +292,14 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __rest
       if ((v >> q) & 1u) stage[rank++] = (uint8_t)((hits >> q) & 1u);
   }
   __syncthreads();
-  const int64_t base = tile_off[blockIdx.x];
-  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
-  for (unsigned i = threadIdx.x; i < total; i += BNPK_BLOCK) out[base + i] = stage[i];
+  // stage[skew + i] -> out[base + i]: the bytes in front of the first 16-byte boundary, whole 16-byte groups, the rest
+  uint8_t* dst = out + base - skew;                           // (16-byte aligned; its first `skew` bytes are the tile before's)
+  const unsigned end = skew + total;
+  const unsigned first16 = skew ? 16u : 0u, last16 = end & ~15u;
+  if (threadIdx.x < 16u && threadIdx.x >= skew && threadIdx.x < min(first16, end)) dst[threadIdx.x] = stage[threadIdx.x];
+  for (unsigned i = first16 + 16u * threadIdx.x; i + 16u <= last16; i += 16u * BNPK_BLOCK)
+    *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(stage + i);
+  if (last16 >= first16 && threadIdx.x < (end & 15u) && last16 + threadIdx.x >= skew) dst[last16 + threadIdx.x] = stage[last16 + threadIdx.x];
 }
 
 // Position weight matrix scores (bionumpy/sequence/position_weight_matrix.py:86-104,177-196): for every window of W

@@ -71,15 +71,20 @@ class HipOps:
         return HArray(dev=pos), total
 
     def scan_lines(self, buf, n, lines_per_entry, header, check_plus):
-        """OneLineBuffer.from_raw_buffer + _validate on a device chunk (one_line_buffer.py:45-71,156-173)."""
-        newlines, total = self.newline_positions(buf, n, lines_per_entry)
+        """OneLineBuffer.from_raw_buffer + _validate on a device chunk (one_line_buffer.py:45-71,156-173): the newline census,
+        then positions and validation in ONE pass over the text (bnpk_line_positions), one download for every host scalar."""
+        d = buf.dev()
+        tiles = lib.bnpk_scan_tiles(n)
+        tile_off = self._empty(tiles + 1, np.int64)
+        self._chk(lib.bnpk_byte_census(self.ctx, ptr(d), n, NEWLINE, ptr(tile_off), self._s()))
+        total = self._fetch(tile_off[tiles:], 1)[0]
         if total < lines_per_entry:
             raise IncompleteEntryException("No complete entry in buffer. Try increasing chunk_size.")
-        n_lines = newlines.size
-        nl = newlines.dev()
+        n_lines = total - (total % lines_per_entry)
+        nl = self._empty(n_lines, np.int64)
         err = self._empty(4, np.int64)
-        self._chk(lib.bnpk_validate_entries(self.ctx, ptr(buf.dev()), ptr(nl), n_lines, lines_per_entry, header,
-                                            1 if check_plus else 0, ptr(err), self._s()))
+        self._chk(lib.bnpk_line_positions(self.ctx, ptr(d), n, ptr(tile_off), n_lines, lines_per_entry, header,
+                                          1 if check_plus else 0, ptr(nl), ptr(err), self._s()))
         err[3:4].copy_(nl[n_lines - 1:n_lines])          # last newline -> size, one D2H for all four
         e = self._fetch(err)
         if e[0] != NONE:
@@ -88,7 +93,7 @@ class HipOps:
         if check_plus and e[1] != NONE:
             raise FormatException("Expected '+' at third line of entry",
                                   line_number=2 + int(e[1]) * lines_per_entry)
-        return LineScan(int(e[3]) + 1, n_lines, n_lines // lines_per_entry, newlines, bool(e[2]))
+        return LineScan(int(e[3]) + 1, n_lines, n_lines // lines_per_entry, HArray(dev=nl), (e[2] & 3) == 1)
 
     def window_cuts(self, buf, scan, lines_per_entry, window, avail, finished, first_held, max_chunk, max_cuts=256):
         """the chunks a reader with windows of ``window`` bytes cuts out of a scanned batch (bnpk_window_cuts) and every

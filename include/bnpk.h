@@ -154,6 +154,14 @@ int bnpk_byte_census(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t val
 int bnpk_byte_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, uint8_t value,
                         const int64_t* d_tile_offsets, int64_t limit, int64_t* d_pos, void* stream);
 
+/* A2 + A3 in one pass: bnpk_byte_positions of '\n' over the first n_lines (a multiple of lines_per_entry) newlines of the
+ * chunk AND bnpk_validate_entries' checks — the thread that finds the newline in front of a line looks at the line's first
+ * byte.  d_err3 as bnpk_validate_entries writes it, except [2]: bit 0 = one of the first lines_per_entry header lines ends
+ * in '\r', bit 1 = the first line is empty (the reference then leaves carriage returns alone: one_line_buffer.py:176-182),
+ * i.e. has_cr = (d_err3[2] & 3) == 1. */
+int bnpk_line_positions(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t n, const int64_t* d_tile_offsets, int64_t n_lines,
+                        int lines_per_entry, uint8_t header, int check_plus, int64_t* d_pos, int64_t* d_err3, void* stream);
+
 /* ---- A3: record validation ------------------------------------------------------------
  * replaces OneLineBuffer._validate + FastQBuffer._validate
  * (bionumpy/io/one_line_buffer.py:156-173, bionumpy/io/fastq_buffer.py:39-45).

@@ -20,6 +20,6 @@ for mode in [int(m) for m in (sys.argv[3].split(',') if len(sys.argv) > 3 else '
     rep = dev.prof_report(); dev.prof_enable(False)
     print("finish_mode %d: finish_sorted %.1f ms, distinct %d of %d" % (mode, rep["finish_sorted"]["total_ms"], keys.size, st.n_kmers), flush=True)
     if os.environ.get("FM_SPARE"):
-        print("   spare words:", ops.last_finish_state[72:80])
+        print("   spare words:", ops.last_finish_state[72:80].tolist(), "fractions", [round(float(x) / max(float(ops.last_finish_state[72:80].sum()), 1.0), 3) for x in ops.last_finish_state[72:80]])
     del keys, counts
 lib.bnpk_set_option(dev.ctx, b"finish_mode", 0)
