@@ -691,6 +691,7 @@ class HipOps:
                 bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
                 if n_over <= self.MAX_PRECOUNTED:
                     listed = np.array(self._fetch(census[2:], 3 * n_over), dtype=np.int64).reshape(n_over, 3)
+                    listed = listed[np.argsort(listed[:, 0])]        # (the kernel lists them as it finds them)
                     big = self._precount_buckets(cur, listed, key_bits)
                     fits = True
                     break

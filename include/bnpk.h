@@ -524,8 +524,8 @@ int bnpk_radix_partition_small(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, 
                                int64_t n_seg, int shift, int bits, int64_t* d_out, int64_t* d_child_offsets,
                                void* stream);
 /* what the caller of bnpk_finish_sorted decides on, in one pass over the bucket offsets and ONE download: d_out[0] = keys of
- * the largest bucket, d_out[1] = buckets of more than `cap` keys, then {bucket, its first key's index, its keys} of the
- * first max_list (<= 4096) of those in ascending order (all of them if d_out[1] <= max_list).  d_out: 2 + 3 * max_list words.
+ * the largest bucket, d_out[1] = buckets of more than `cap` keys, then {bucket, its first key's index, its keys} of up to
+ * max_list (<= 4096) of those in no particular order (all of them if d_out[1] <= max_list).  d_out: 2 + 3 * max_list words.
  * (replaces sizes.max() / (sizes > cap).nonzero() on the offsets: two reductions and two downloads) */
 int bnpk_bucket_census(bnpk_ctx* ctx, const int64_t* d_bucket_offsets, int64_t n_buckets, int64_t cap, int max_list, int64_t* d_out,
                        void* stream);

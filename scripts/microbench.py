@@ -9,13 +9,14 @@ from bionumpy_amd.pipeline import fastq_kmer_histogram
 reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 mode = int(os.environ.get("MB_MODE", "0"))
+k = int(os.environ.get("MB_K", "31"))
 ops = get_ops(); dev = Device.get()
 text = ops.synth_fastq(reads, 150, 20260925, mode, 100_000_000, 0)
-h, st = fastq_kmer_histogram(text, 31); del h
+h, st = fastq_kmer_histogram(text, k); del h
 torch.cuda.synchronize()
 dev.prof_enable(True); dev.prof_reset()
 for _ in range(reps):
-    h, st = fastq_kmer_histogram(text, 31); del h
+    h, st = fastq_kmer_histogram(text, k); del h
 torch.cuda.synchronize()
 rep = dev.prof_report()
 tot = 0

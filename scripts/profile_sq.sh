@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: [MB_MODE=1 SQ_TAG=_genome] profile_sq.sh   (MB_MODE=1: S-genome reads)
+# usage: [MB_MODE=1] [MB_K=21] [SQ_TAG=_genome] profile_sq.sh   (MB_MODE=1: S-genome reads; MB_K: k, default 31)
 # SQ counter passes (VALU / LDS / wait cycles) of the pipeline kernels on one 50 M-read batch; summaries -> gpurun_out/sq/
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/sq
@@ -18,7 +18,7 @@ for pm in ("pmc1", "pmc2"):
             name = row["Kernel_Name"]
             if "kernel<true>" in name and ("fq_encode" in name or "fq_census" in name):
                 continue                                   # (the list-mode launches over the tiles handed back: empty)
-            for key in ("finish_wave", "finish_dup", "finish_compact", "finish_fast", "finish_sorted", "rp_scatter", "rp_hist", "fq_encode_fast", "fq_census_fast", "fq_encode", "fq_census"):
+            for key in ("finish_multi", "finish_wave", "finish_dup", "finish_compact", "finish_fast", "finish_sorted", "rp_scatter", "rp_hist", "fq_encode_fast", "fq_census_fast", "fq_encode", "fq_census"):
                 if key in name:
                     short = key + ("<kmer>" if ("kmer_source" in name or "rp_hist_kmer" in name) else "<mem>" if ("mem_source" in name or "rp_hist_mem" in name) else "")
                     agg[short][row["Counter_Name"]] += float(row["Counter_Value"])
@@ -34,6 +34,6 @@ for k, c in agg.items():
     d["_valu_active_frac_of_wave_cycles"] = round(d.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3)
     d["_lds_bank_conflict_frac_of_lds_active"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0) / (d.get("SQ_LDS_IDX_ACTIVE", 0) or 1), 3)
     res[k] = d
-json.dump(res, open(out + "/r03_sq_counters%s.json" % os.environ.get("SQ_TAG", ""), "w"), indent=1, sort_keys=True)
+json.dump(res, open(out + "/sq_counters%s.json" % os.environ.get("SQ_TAG", ""), "w"), indent=1, sort_keys=True)
 print(json.dumps({k: {x: y for x, y in v.items() if x.startswith("_")} for k, v in res.items()}, indent=1))
 PY

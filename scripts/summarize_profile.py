@@ -35,6 +35,11 @@ def _short(name):
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
         return "%s<%s>" % (kind, src)
+    for key in ("finish_multi_kernel", "bucket_census", "bucket_list", "window_cuts", "rebase_lines", "copy_plain", "copy_oneshot", "copy_unrolled"):
+        if key in name:
+            return key.replace("_kernel", "")
+    if "byte_positions_kernel<true>" in name or "byte_positions_kernelILb1" in name:
+        return "line_positions"
     for key in ("finish_wave_kernel", "finish_dup_kernel", "finish_compact", "fw_finalize", "wf_minimizer", "hist_weighted", "row_reduce_wide"):
         if key in name:
             return key.replace("_kernel", "") + ("<probe>" if key == "finish_wave_kernel" and name.rstrip(">").endswith("true") else "")
@@ -90,7 +95,7 @@ def main():
     if os.path.exists(stats_db):
         text = kernel_stats(stats_db)
         bench = os.path.join(src, "bench_stats.json")
-        header = "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline\n"
+        header = "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-fed --no-extra [args of the profiled line below]\n"
         if os.path.exists(bench):
             header += "# bench line of the profiled run: " + open(bench).read().strip()[:1500] + "\n"
         open(out + "_kernel_stats.txt", "w").write(header + text)
