@@ -28,8 +28,6 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     histogram is a dense int64 HArray (k <= 13; summed over ranks if ``group``) or a (keys, counts) pair
     of HArrays (k > 13; range-partitioned over ranks if ``group``)."""
     assert 0 < k < 32, "k must be larger than 0 and smaller than 32"
-    if canonical and not (k > DENSE_MAX_K and fused):
-        raise NotImplementedError("canonical k-mers: the fused sparse path (k > %d)" % DENSE_MAX_K)
     ops = get_ops()
     lpe = buffer_type.n_lines_per_entry
     distributed = group is not None or _world_size() > 1
@@ -72,6 +70,8 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
     if k <= DENSE_MAX_K:                                                                              # A8 + A9 dense
         hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
         del packed, offsets, out_offsets
+        if canonical and n_kmers:                            # min(h, hash of the reverse complement k-mer), in place
+            hashes = ops.canonical_kmers(hashes, k)
         hist = ops.count_dense(hashes, 4 ** k)
         del hashes
         if distributed:
@@ -81,14 +81,16 @@ def fastq_kmer_histogram(text, k, group=None, buffer_type=FastQBuffer, fused=Tru
         # generate the hashes already partitioned by their top 8 bits == grouped by owning rank
         ends = ops.kmer_start_mask(offsets, n, n_bases, k)
         del offsets, out_offsets
-        part, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, parallel.FINE_BITS)
+        part, cuts = ops.kmers_partitioned(packed, ends, n_bases, n_kmers, k, parallel.FINE_BITS, canonical=canonical)
         del packed, ends
         holder = [part]                       # hand the 8 B/k-mer buffer over: it is freed right after the exchange
         del part
         return parallel.count_sparse_distributed(holder, key_bits, group, cuts=cuts), stats
     hashes = ops.kmers(packed, offsets, out_offsets, n, n_kmers, k)
     del packed, offsets, out_offsets
-    return ops.count_sparse(hashes, key_bits=key_bits, consume=True), stats
+    if canonical and n_kmers:
+        hashes = ops.canonical_kmers(hashes, k)
+    return ops.count_sparse(hashes, key_bits=key_bits, consume=True, skew=2.0 if canonical else 1.0), stats
 
 
 def fastq_kmer_histogram_virtual_ranks(texts, k, buffer_type=FastQBuffer, canonical=False, plan="auto", with_plan=False,
@@ -122,7 +124,15 @@ def fastq_minimizers(text, k, window_size, buffer_type=FastQBuffer):
     assert 0 < k < 32 and window_size >= k
     ops = get_ops()
     if window_size - k + 1 > 26:                            # (HipOps.WINDOWS_FLAT_MAX: what bnpk_windows_flat covers)
-        raise NotImplementedError("windows of more than 26 k-mers: use get_minimizers")
+        # wider windows: the row-lookup kernel behind get_minimizers (bnpk_minimizers), which takes any width — through
+        # the API objects, since it wants row offsets and the fused decode has none
+        from .encoded_array import change_encoding, DNAEncoding
+        from .sequence.minimizers import get_minimizers
+        buf = buffer_type.from_raw_buffer(text)
+        seqs = change_encoding(buf.get_field_by_number(1), DNAEncoding)
+        out = get_minimizers(seqs, k, window_size)
+        out._compact()
+        return out._flat_data(), BatchStats(len(seqs), seqs.total(), out.total(), buf.size)
     packed, ends, n, n_bases = ops.fastq_encode(text, text.size, buffer_type.n_lines_per_entry, 1,
                                                 ord(buffer_type.HEADER), buffer_type._check_plus)
     starts_mask, n_windows = ops.kmer_starts_from_ends(ends, n_bases, window_size)

@@ -12,6 +12,27 @@ from ..ops import get_ops
 from ..ragged import RaggedArray
 
 
+def _match_long(ops, ragged, offsets, n_rows, total, codes, n_out):
+    """a pattern of more than 64 symbols (what one launch of the byte kernel compares): its pieces of at most 64 symbols are
+    matched on their own and a window matches iff every piece matches at its offset inside the window — the flags of piece j
+    for row r start at (windows of piece j before row r) + offset of the piece"""
+    m = codes.size
+    lens = ragged.lengths
+    n_win = np.maximum(lens - (m - 1), 0)                      # windows of the whole pattern per row
+    row_of = np.repeat(np.arange(n_rows), n_win)
+    within = np.arange(int(n_win.sum())) - np.repeat(np.cumsum(n_win) - n_win, n_win)
+    flags = np.ones(int(n_win.sum()), dtype=bool)
+    for o in range(0, m, 64):
+        piece = codes[o:o + 64]
+        _, n_piece = ops.row_offsets(ragged._lens, piece.size)
+        hit = ops.match_windows(ragged._flat_data(), offsets, n_rows, total, n_piece, piece, False).host().astype(bool)
+        per_row = np.maximum(lens - (piece.size - 1), 0)
+        starts = np.cumsum(per_row) - per_row
+        flags &= hit[starts[row_of] + within + o]
+    assert flags.size == n_out
+    return flags
+
+
 def match_string(sequence, matching_sequence):
     sequence = as_encoded_array(sequence)
     pattern = as_encoded_array(matching_sequence, sequence.encoding)
@@ -31,11 +52,12 @@ def match_string(sequence, matching_sequence):
         (isinstance(ragged._data, _PackedDna) or total >= 4096)
     if packed:
         hits = ops.match_windows(packed_words(ragged._data), offsets, n_rows, total, n_out, codes, True)
+    elif m > 64:
+        flags = _match_long(ops, ragged, offsets, n_rows, total, codes, n_out)
     else:
-        if m > 64:
-            raise NotImplementedError("patterns longer than 64 symbols are not on the MI355X path")
         hits = ops.match_windows(ragged._flat_data(), offsets, n_rows, total, n_out, codes, False)
-    flags = hits.host().astype(bool)
+    if m <= 64 or packed:
+        flags = hits.host().astype(bool)
     if single:
         return flags
     new_lens = np.maximum(ragged.lengths - (m - 1), 0)

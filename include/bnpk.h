@@ -473,7 +473,11 @@ int bnpk_count_dense_rows(bnpk_ctx* ctx, const int64_t* d_values, const int64_t*
  *     d_hist[r * n_bins + d_values[r * value_stride + i]] += d_weights[r * weight_stride + i],  r < n_rows, i < n.
  * weights_f64 = 0: int64 weights and an int64 histogram (exact: what numpy's double accumulation of integer weights gives
  * below 2^53), 1: float64 weights and a float64 histogram — accumulated with atomics, i.e. in another order than numpy's
- * left-to-right loop: equal to it up to the rounding of the additions (tests state the tolerance).  d_hist is accumulated
+ * left-to-right loop.  BIT-EQUAL to numpy: integer and bool weights (weights_f64 = 0), and float64 weights whose partial sums
+ * per bin are all exactly representable (integers below 2^53, dyadic fractions of bounded size — every additions is exact,
+ * so their order does not matter).  Any other float64 weights: equal up to the rounding of the additions, |difference| <=
+ * (items in the bin) x eps x sum |w| (the tests check exactly representable weights with tolerance 0 and random ones with
+ * rtol 1e-12).  d_hist is accumulated
  * into (zero it first).  *h_out_of_range = 1 if a value was not in [0, n_bins) (it was skipped; numpy would have grown
  * the histogram or raised).  Synchronous. */
 int bnpk_count_weighted(bnpk_ctx* ctx, const int64_t* d_values, const void* d_weights, int weights_f64, int64_t n,

@@ -623,6 +623,17 @@ def test_match_string(bnp):
             assert np.array_equal(np.asarray(got.ravel()).astype(np.uint8), hit)
     assert bnp.match_string(bnp.as_encoded_array("TACTAC", bnp.DNAEncoding), "AC").tolist() == \
         [False, True, False, False, True]
+    # a pattern of more than 64 symbols (more than one launch of the byte kernel compares): matched piece by piece
+    long_rows = ["".join(rng.choice(list("ACGT"), size=n)) for n in (400, 100, 150, 0)]
+    pattern = long_rows[0][37:37 + 150]
+    long_rows[2] = pattern                                            # a row that IS the pattern; one that is shorter
+    for enc in (bnp.DNAEncoding, None):
+        seqs = bnp.as_encoded_array(long_rows, enc) if enc is not None else bnp.as_encoded_array(long_rows)
+        got = bnp.match_string(seqs, pattern)
+        flat = np.frombuffer("".join(long_rows).encode(), dtype=np.uint8)
+        hit, lens = oracle.match_string(flat, [len(r) for r in long_rows], np.frombuffer(pattern.encode(), dtype=np.uint8))
+        assert got.lengths.tolist() == lens.tolist() == [251, 0, 1, 0]
+        assert np.array_equal(np.asarray(got.ravel()).astype(np.uint8), hit) and int(hit.sum()) == 2
 
 
 def test_motif_scores(bnp):
@@ -721,11 +732,32 @@ def test_fused_minimizer_pipeline_equals_the_api_path(bnp, big_fq_gz):
     text = np.frombuffer(gzip.open(big_fq_gz, "rb").read(), dtype=np.uint8)
     whole = bnp.open(big_fq_gz).read()
     seqs = bnp.change_encoding(whole.sequence, bnp.DNAEncoding)
-    for k, w in ((31, 40), (5, 5), (12, 30)):
+    for k, w in ((31, 40), (5, 5), (12, 30), (8, 60)):                # (8, 60): 53 k-mers per window — the row-lookup kernel's
         got, stats = fastq_minimizers(HArray(host=text.copy()), k, w)
         expect = np.asarray(bnp.get_minimizers(seqs, k, w).raw().ravel())
         assert stats.n_reads == len(whole) and stats.n_kmers == expect.size
         assert np.array_equal(got.host(), expect)
+
+
+def test_canonical_counts_on_every_path_of_the_pipeline(bnp, big_fq_gz):
+    """pipeline.fastq_kmer_histogram(canonical=True): dense (k <= 13), sparse fused and sparse through the field tables give
+    the histogram of min(h, hash of the reverse complement) — extension SURVEY 8f-1"""
+    import gzip
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    from bionumpy_amd.device import HArray
+    text = np.frombuffer(gzip.open(big_fq_gz, "rb").read(), dtype=np.uint8)
+    res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
+    codes = oracle.encode_dna(oracle.gather_rows(text, res.field_starts[:, 1], res.field_lens[:, 1]))
+    for k, fused in ((5, True), (11, True), (15, True), (15, False), (31, False)):
+        h, _ = oracle.get_kmers(codes, res.field_lens[:, 1], k)
+        can = oracle.canonical_kmers(h, k)
+        hist, stats = fastq_kmer_histogram(HArray(host=text.copy()), k, fused=fused, canonical=True)
+        assert stats.n_kmers == h.size
+        if k <= 13:
+            assert np.array_equal(hist.host(), oracle.count_dense(can, k))
+        else:
+            ek, ec = oracle.count_sparse(can)
+            assert np.array_equal(hist[0].host(), ek) and np.array_equal(hist[1].host(), ec)
 
 
 def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
