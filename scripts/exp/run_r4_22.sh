@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_finish_modes.py -x -q -m gpu 2>&1 | tail -4

@@ -138,3 +138,27 @@ def test_clusters_of_the_duplicate_aware_table_are_ranked(env):
         keys = rng.permutation(np.concatenate([tops | (np.arange(run, dtype=np.int64) * 2654435761 & 0xFFFFF)] * 3))
         got = _direct(env, keys, 0)
         assert got[3] == 0 or not stays, run
+
+
+@pytest.mark.parametrize("mode", [5, 0])
+def test_repeats_in_every_bucket_at_scale(env, mode):
+    """50 M keys, 8192 buckets (sixteen per workgroup of the multiplicity-counting kernel): the prefix of the distinct counts
+    is looked up across thousands of status words, the parking ring goes round many times, tickets run far ahead of the
+    blockIdx — what the 2 M-key cases above (one bucket per workgroup) cannot show.  0.1 % repeats, a few per bucket;
+    whole-histogram equality with np.unique."""
+    ops, lib, dev, ptr, torch = env
+    rng = np.random.default_rng(77)
+    n = 50_000_000
+    base = rng.integers(0, 1 << 62, size=n, dtype=np.int64)
+    again = rng.integers(0, n, size=n // 1000)
+    base[rng.integers(0, n, size=n // 1000)] = base[again]            # ~50 000 keys occur twice (some three times)
+    ek, ec = np.unique(base, return_counts=True)
+    assert 0 < n - ek.size < n // 500
+    assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
+    ops.keep_finish_state = True
+    try:
+        gk, gc = ops.count_sparse(HArray(host=base), key_bits=62)
+        assert gk.size == ek.size and np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
+        assert int(ops.last_finish_state[0]) == 0                     # no flag: nothing overflowed, no wait gave up
+    finally:
+        ops.keep_finish_state = False
