@@ -100,14 +100,25 @@ class TorchCollectives:
         return self.exchange(_from_tensor(packed, ops), send_counts, recv_counts)
 
 
-def agree_on_communicator(group, take_id, make, undo, vote_device="cpu"):
+def agree_on_communicator(group, take_id, make, undo, vote_device="cpu", can_make=None):
     """the handshake of AbiCollectives, with the communicator's own calls passed in (the CPU tests pass stand-ins):
-    rank 0's ``take_id()`` result — or None if it raised — is broadcast; every rank calls ``make(id)``; the outcomes are
-    all-reduced (MIN); unless all succeeded, every rank calls ``undo()`` and raises.  All ranks return or all ranks raise."""
+    every rank says whether it could make a communicator at all (``can_make()``: the library loads — voted on FIRST, because
+    ``make`` is itself collective: a rank that cannot even enter it would leave the others waiting inside); rank 0's
+    ``take_id()`` result — or None if it raised — is broadcast; every rank calls ``make(id)``; the outcomes are all-reduced
+    (MIN); unless all succeeded, every rank calls ``undo()`` and raises.  All ranks return or all ranks raise."""
     import torch
     dist = _dist()
     rank = dist.get_rank(group)
     box, why = [None], ""
+    if can_make is not None:
+        try:
+            able = 1 if can_make() else 0
+        except Exception as e:                           # noqa: BLE001
+            able, why = 0, "%s: %s" % (type(e).__name__, e)
+        vote = torch.tensor([able], dtype=torch.int32, device=vote_device)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN, group=group)
+        if int(vote.item()) == 0:
+            raise RuntimeError("a communicator cannot be made on %s" % (("this rank (%s)" % (why or "can_make() said no")) if not able else "another rank"))
     if rank == 0:
         try:
             box[0] = take_id()
@@ -168,7 +179,11 @@ class AbiCollectives:
             if int(probe.item()) != self.world:
                 raise RuntimeError("bnpk_allreduce_hist over %d ranks returned %d" % (self.world, int(probe.item())))
 
-        agree_on_communicator(group, take_id, make, self.close, self.dev.tdev if dist.get_backend(group) == "nccl" else "cpu")
+        def can_make():                                  # (loads RCCL: bnpk_comm_unique_id needs nothing else)
+            return lib.bnpk_comm_unique_id((C.c_uint8 * 128)()) == 0
+
+        agree_on_communicator(group, take_id, make, self.close, self.dev.tdev if dist.get_backend(group) == "nccl" else "cpu",
+                              can_make=can_make)
         import atexit
         atexit.register(self.close)
 

@@ -61,6 +61,13 @@ def main():
             raise AssertionError("a communicator that failed somewhere was accepted on rank %d" % rank)
         except RuntimeError as e:
             assert word in str(e), e
+    # a rank that cannot even enter the collective make (its library does not load): found out BEFORE anybody enters it
+    entered = []
+    try:
+        parallel.agree_on_communicator(None, lambda: b"id", lambda raw: entered.append(1), lambda: None, can_make=lambda: rank != world - 1)
+        raise AssertionError("accepted")
+    except RuntimeError as e:
+        assert "cannot be made" in str(e) and not entered, e
     dist.barrier()                                            # (every rank is still in step)
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
