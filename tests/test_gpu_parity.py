@@ -678,3 +678,52 @@ def test_fast_and_general_decode_kernels_agree_on_random_line_structures(ops):
         assert decoded > 50
     finally:
         lib.bnpk_set_option(Device.get().ctx, b"fastq_encoder", 1)
+
+
+@pytest.mark.parametrize("lpe,header,plus", [(4, "@", True), (2, ">", False)])
+def test_fused_line_scan_against_the_oracle_on_random_line_structures(ops, lpe, header, plus):
+    """bnpk_line_positions (newline positions + the checks of _validate in one pass, ops.scan_lines) on texts of random
+    line lengths — empty lines, lines of a few kilobytes, '\\r\\n' ends, an incomplete tail — with a wrong header byte or a
+    missing '+' planted in a random entry of some of them: LineScan and the exception (type, line_number) of the oracle's
+    scan_one_line_buffer (one_line_buffer.py:45-71,156-182; fastq_buffer.py:39-45), 300 texts per format"""
+    from bionumpy_amd.exceptions import FormatException, IncompleteEntryException
+    from oracle import text as otext
+    fmt = oracle.FASTQ if lpe == 4 else oracle.TWO_LINE_FASTA
+    rng = np.random.default_rng(lpe)
+    for trial in range(300):
+        n_entries = int(rng.integers(0, 60))
+        crlf = rng.random() < 0.3
+        parts = []
+        for e in range(n_entries):
+            for line in range(lpe):
+                ln = int(rng.choice([0, 1, 3, 17, 150, 2500], p=[0.1, 0.1, 0.2, 0.3, 0.28, 0.02]))
+                body = rng.choice(np.frombuffer(b"ACGTNacgt!#IJ", dtype=np.uint8), size=ln).tobytes()
+                if line == 0:
+                    body = header.encode() + body
+                if plus and line == 2:
+                    body = b"+" + body
+                parts.append(body + (b"\r\n" if crlf and rng.random() < 0.9 else b"\n"))
+        text = bytearray(b"".join(parts))
+        if n_entries and rng.random() < 0.4:                              # plant an error at the start of a random line
+            starts = np.concatenate(([0], np.flatnonzero(np.frombuffer(bytes(text), dtype=np.uint8) == 10) + 1))[:-1]
+            entry = int(rng.integers(0, n_entries))
+            which = 0 if (not plus or rng.random() < 0.5) else 2
+            text[starts[entry * lpe + which]] = ord("x")
+        text += rng.choice(np.frombuffer(b"@ACGT+\n", dtype=np.uint8), size=int(rng.integers(0, 40))).tobytes()   # an incomplete tail
+        buf = np.frombuffer(bytes(text), dtype=np.uint8)
+        want = err = None
+        try:
+            want = oracle.scan_one_line_buffer(buf, fmt)
+        except (otext.FormatException, otext.IncompleteEntryException) as e:
+            err = (type(e).__name__, getattr(e, "line_number", None))
+        try:
+            got = ops.scan_lines(_h(buf) if buf.size else _h(np.zeros(0, dtype=np.uint8)), buf.size, lpe, ord(header), plus)
+        except (FormatException, IncompleteEntryException) as e:
+            assert err == (type(e).__name__, getattr(e, "line_number", None)), (trial, err, e)
+            continue
+        assert err is None, (trial, err)
+        assert (got.size, got.n_lines, got.n_records) == (want.size, want.n_lines, want.n_records), trial
+        assert np.array_equal(got.newlines.host(), want.new_lines), trial
+        # has_cr as the field table uses it: the sequence line's lengths
+        starts, lens = ops.field_table(_h(buf), got.newlines, got.n_records, lpe, 1, 0, got.has_cr)
+        assert np.array_equal(lens.host(), want.field_lens[:, 1]) and np.array_equal(starts.host(), want.field_starts[:, 1]), trial

@@ -215,3 +215,28 @@ def test_windowed_reader_abandoned_keeps_the_rest_of_the_file(monkeypatch, tmp_p
     assert reader._reader.n_lines_read == 4 * 900
     reader.close()
     assert seqs == whole
+
+
+@pytest.mark.gpu
+def test_windowed_chunks_on_random_files_and_chunk_sizes(monkeypatch, tmp_path):
+    """40 random combinations of entry lengths (up to several windows), window size, batch size, line ends and final newline:
+    the windowed reader's chunks — entries, n_lines_read, n_bytes_read per chunk — are the plain loop's"""
+    import bionumpy_amd as bnp
+    from bionumpy_amd import ops as ops_mod
+    ops_mod.set_ops(None)
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        n = int(rng.integers(1, 1500))
+        max_len = int(rng.choice([8, 60, 400, 5000]))
+        chunk = int(rng.choice([300, 1000, 4096, 20000]))
+        batch = int(rng.choice([1 << 12, 1 << 14, 1 << 16]))
+        text = _fastq(np.random.default_rng(trial), n, max_len, final_newline=bool(rng.integers(0, 2)))
+        if rng.random() < 0.25:
+            text = text.replace("\n", "\r\n")
+        path = tmp_path / ("r%d.fq" % trial)
+        path.write_bytes(text.encode())
+        _windowed(monkeypatch, False)
+        want, err0 = _chunks(bnp, path, chunk)
+        _windowed(monkeypatch, True, batch)
+        got, err1 = _chunks(bnp, path, chunk)
+        assert err0 is None and err1 is None and got == want, (trial, n, max_len, chunk, batch, len(got), len(want))
