@@ -238,68 +238,121 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t
 constexpr int WF_MAX_PATTERN = 64;
 struct wf_pattern { uint8_t b[WF_MAX_PATTERN]; };
 
+constexpr int WF_MATCH_GROUP = 4;                           // tiles of 2048 positions a workgroup of wf_match takes, one after the other
 template <bool PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void wf_match_kernel(const void* __restrict__ src, int64_t n_words,
                                                               const uint8_t* __restrict__ mask8, int64_t n_items, int m,
                                                               uint64_t pattern_hash, wf_pattern pat,
-                                                              const int64_t* __restrict__ tile_off,
+                                                              const int64_t* __restrict__ tile_off, int64_t n_tiles,
                                                               uint8_t* __restrict__ out) {
   // (the tile's flags are staged at the output's own offset within 16 bytes, so that both the LDS reads and the global stores
-  // of the run are aligned 16-byte accesses: one store per lane and 16 flags instead of sixteen single-byte stores)
+  // of the run are aligned 16-byte accesses: one store per lane and 16 flags instead of sixteen single-byte stores.  A tile is
+  // 2 KB of output: a workgroup takes WF_MATCH_GROUP of them in a row — 3.7 M workgroups of two barriers each were
+  // bound by their dispatch)
   __shared__ __attribute__((aligned(16))) uint8_t stage[WF_TILE + 32];
   __shared__ unsigned wsum[BNPK_BLOCK / 64];
-  const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
-  const unsigned v = o < n_items ? mask8[o >> 3] : 0u;
-  const unsigned cnt = __popc(v);
-  const unsigned inc = wave_inclusive_scan(cnt);
-  if (lane_id() == 63) wsum[wave_id()] = inc;
-  unsigned hits = 0;                                          // bit q: the window at o + q matches
-  if (v) {
-    if (PACKED) {
-      const uint64_t* W = reinterpret_cast<const uint64_t*>(src);
-      const int64_t wi = o >> 5;
-      const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0;
-      const int sh0 = 2 * (int)(o & 31), top = 2 * m - 2;
-      const uint64_t kmask = (1ull << (2 * m)) - 1ull;
-      uint64_t h = wf_window(w0, w1, w2, sh0) & kmask;
-      const uint64_t next = wf_window(w0, w1, w2, sh0 + 2 * m);
+  for (int g = 0; g < WF_MATCH_GROUP; ++g) {
+    const int64_t tile = (int64_t)blockIdx.x * WF_MATCH_GROUP + g;
+    if (tile >= n_tiles) break;                               // (uniform)
+    const int64_t o = tile * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+    const unsigned v = o < n_items ? mask8[o >> 3] : 0u;
+    const unsigned cnt = __popc(v);
+    const unsigned inc = wave_inclusive_scan(cnt);
+    if (lane_id() == 63) wsum[wave_id()] = inc;
+    unsigned hits = 0;                                        // bit q: the window at o + q matches
+    if (v) {
+      if (PACKED) {
+        const uint64_t* W = reinterpret_cast<const uint64_t*>(src);
+        const int64_t wi = o >> 5;
+        const uint64_t w0 = W[wi], w1 = W[wi + 1], w2 = wi + 2 < n_words ? W[wi + 2] : 0;
+        const int sh0 = 2 * (int)(o & 31), top = 2 * m - 2;
+        const uint64_t kmask = (1ull << (2 * m)) - 1ull;
+        uint64_t h = wf_window(w0, w1, w2, sh0) & kmask;
+        const uint64_t next = wf_window(w0, w1, w2, sh0 + 2 * m);
 #pragma unroll
-      for (int q = 0; q < WF_ITEMS; ++q) {
-        if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
-        hits |= (h == pattern_hash ? 1u : 0u) << q;
-      }
-    } else {
-      const uint8_t* B = reinterpret_cast<const uint8_t*>(src);
+        for (int q = 0; q < WF_ITEMS; ++q) {
+          if (q) h = (h >> 2) | (((next >> (2 * (q - 1))) & 3ull) << top);
+          hits |= (h == pattern_hash ? 1u : 0u) << q;
+        }
+      } else {
+        const uint8_t* B = reinterpret_cast<const uint8_t*>(src);
 #pragma unroll
-      for (int q = 0; q < WF_ITEMS; ++q) {
-        if ((v >> q) & 1u) {                                  // (a marked position has m bytes of its row ahead)
-          bool same = true;
-          for (int j = 0; j < m; ++j) same = same && B[o + q + j] == pat.b[j];
-          hits |= (same ? 1u : 0u) << q;
+        for (int q = 0; q < WF_ITEMS; ++q) {
+          if ((v >> q) & 1u) {                                // (a marked position has m bytes of its row ahead)
+            bool same = true;
+            for (int j = 0; j < m; ++j) same = same && B[o + q + j] == pat.b[j];
+            hits |= (same ? 1u : 0u) << q;
+          }
         }
       }
     }
-  }
-  __syncthreads();
-  const int64_t base = tile_off[blockIdx.x];
-  const unsigned total = (unsigned)(tile_off[blockIdx.x + 1] - base);
-  const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(out + base) & 15u);
-  unsigned rank = skew + inc - cnt;
-  for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
-  if (v) {
+    __syncthreads();
+    const int64_t base = tile_off[tile];
+    const unsigned total = (unsigned)(tile_off[tile + 1] - base);
+    const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(out + base) & 15u);
+    unsigned rank = skew + inc - cnt;
+    for (int w = 0; w < wave_id(); ++w) rank += wsum[w];
+    if (v) {
 #pragma unroll
-    for (int q = 0; q < WF_ITEMS; ++q)
-      if ((v >> q) & 1u) stage[rank++] = (uint8_t)((hits >> q) & 1u);
+      for (int q = 0; q < WF_ITEMS; ++q)
+        if ((v >> q) & 1u) stage[rank++] = (uint8_t)((hits >> q) & 1u);
+    }
+    __syncthreads();
+    // stage[skew + i] -> out[base + i]: the bytes in front of the first 16-byte boundary, whole 16-byte groups, the rest
+    uint8_t* dst = out + base - skew;                         // (16-byte aligned; its first `skew` bytes are the tile before's)
+    const unsigned end = skew + total;
+    const unsigned first16 = skew ? 16u : 0u, last16 = end & ~15u;
+    if (threadIdx.x < 16u && threadIdx.x >= skew && threadIdx.x < min(first16, end)) dst[threadIdx.x] = stage[threadIdx.x];
+    for (unsigned i = first16 + 16u * threadIdx.x; i + 16u <= last16; i += 16u * BNPK_BLOCK)
+      *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(stage + i);
+    if (last16 >= first16 && threadIdx.x < (end & 15u) && last16 + threadIdx.x >= skew) dst[last16 + threadIdx.x] = stage[last16 + threadIdx.x];
+    __syncthreads();                                          // (the stage and the wave totals are the next tile's)
   }
-  __syncthreads();
-  // stage[skew + i] -> out[base + i]: the bytes in front of the first 16-byte boundary, whole 16-byte groups, the rest
+}
+
+// match_string on 2-bit DNA, one WAVEFRONT per tile of 2048 positions: a lane owns 32 positions — one packed word and the
+// one behind it, 16 bytes loaded for 32 windows (the eight-positions-per-lane kernel above loads 24 bytes for 8: its load
+// instructions, not its 2 KB of output per tile, set its pace) —, ranks by a wave scan of the mask popcounts, stages its
+// flags by predicated byte writes at the output's own offset within 16 bytes, and the wavefront stores the run as aligned
+// 16-byte pieces.  No workgroup barrier: the four wavefronts of a workgroup work on four tiles of their own.
+__global__ __launch_bounds__(BNPK_BLOCK) void wf_match32_kernel(const uint64_t* __restrict__ W, int64_t n_words,
+                                                                const uint32_t* __restrict__ mask32, int64_t n_items, int m,
+                                                                uint64_t pattern_hash, const int64_t* __restrict__ tile_off,
+                                                                int64_t n_tiles, uint8_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage_all[BNPK_BLOCK / 64][WF_TILE + 48];
+  const int lane = lane_id();
+  uint8_t* stage = stage_all[wave_id()];
+  const int64_t tile = (int64_t)blockIdx.x * (BNPK_BLOCK / 64) + wave_id();
+  if (tile >= n_tiles) return;                                // (uniform per wavefront; nothing below synchronises the workgroup)
+  const int64_t o = tile * WF_TILE + (int64_t)lane * 32;      // first position of the lane: a word boundary of W and of the mask
+  const int64_t wi = o >> 5;
+  const uint32_t v = o < n_items ? mask32[wi] : 0u;
+  const uint64_t w0 = (v && wi < n_words) ? W[wi] : 0ull, w1 = (v && wi + 1 < n_words) ? W[wi + 1] : 0ull;
+  const uint64_t kmask = (1ull << (2 * m)) - 1ull;            // m <= 31
+  uint32_t hits = 0;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const uint64_t h = (q ? (w0 >> (2 * q)) | (w1 << (64 - 2 * q)) : w0) & kmask;
+    hits |= (h == pattern_hash ? 1u : 0u) << q;
+  }
+  const unsigned cnt = __popc(v);
+  const unsigned inc = wave_inclusive_scan(cnt);
+  const int64_t base = tile_off[tile];
+  const unsigned total = (unsigned)(tile_off[tile + 1] - base);
+  const unsigned skew = (unsigned)(reinterpret_cast<uintptr_t>(out + base) & 15u);
+  const unsigned rank = skew + inc - cnt;
+#pragma unroll
+  for (int q = 0; q < 32; ++q)
+    if ((v >> q) & 1u) stage[rank + __popc(v & ((1u << q) - 1u))] = (uint8_t)((hits >> q) & 1u);
+  __builtin_amdgcn_wave_barrier();                            // (the wavefront's LDS writes are in order before its reads)
+  __builtin_amdgcn_s_waitcnt(0xc07f);                         // lgkmcnt(0)
   uint8_t* dst = out + base - skew;                           // (16-byte aligned; its first `skew` bytes are the tile before's)
   const unsigned end = skew + total;
   const unsigned first16 = skew ? 16u : 0u, last16 = end & ~15u;
-  if (threadIdx.x < 16u && threadIdx.x >= skew && threadIdx.x < min(first16, end)) dst[threadIdx.x] = stage[threadIdx.x];
-  for (unsigned i = first16 + 16u * threadIdx.x; i + 16u <= last16; i += 16u * BNPK_BLOCK)
+  if ((unsigned)lane < 16u && (unsigned)lane >= skew && (unsigned)lane < min(first16, end)) dst[lane] = stage[lane];
+  for (unsigned i = first16 + 16u * (unsigned)lane; i + 16u <= last16; i += 16u * 64u)
     *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(stage + i);
-  if (last16 >= first16 && threadIdx.x < (end & 15u) && last16 + threadIdx.x >= skew) dst[last16 + threadIdx.x] = stage[last16 + threadIdx.x];
+  if (last16 >= first16 && (unsigned)lane < (end & 15u) && last16 + (unsigned)lane >= skew) dst[last16 + lane] = stage[last16 + lane];
 }
 
 // Position weight matrix scores (bionumpy/sequence/position_weight_matrix.py:86-104,177-196): for every window of W
@@ -500,13 +553,13 @@ static int match_windows(bnpk_ctx* ctx, bool packed, const void* d_src, const ui
   BNPK_HIP(ctx, hipGetLastError());
   BNPK_CHECK(bnpk_scan_launch(ctx, tile_off, n_tiles, 1, tile_off, true, scan_scratch, s));
   if (packed)
-    hipLaunchKernelGGL((wf_match_kernel<true>), dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_src, n_items / 32 + 2,
-                       reinterpret_cast<const uint8_t*>(d_start_mask), n_items, m, pattern_hash, pat,
-                       (const int64_t*)tile_off, d_out);
+    hipLaunchKernelGGL(wf_match32_kernel, dim3((unsigned)ceil_div(n_tiles, BNPK_BLOCK / 64)), dim3(BNPK_BLOCK), 0, s,
+                       reinterpret_cast<const uint64_t*>(d_src), n_items / 32 + 2, reinterpret_cast<const uint32_t*>(d_start_mask),
+                       n_items, m, pattern_hash, (const int64_t*)tile_off, n_tiles, d_out);
   else
-    hipLaunchKernelGGL((wf_match_kernel<false>), dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_src, (int64_t)0,
+    hipLaunchKernelGGL((wf_match_kernel<false>), dim3((unsigned)ceil_div(n_tiles, WF_MATCH_GROUP)), dim3(BNPK_BLOCK), 0, s, d_src, (int64_t)0,
                        reinterpret_cast<const uint8_t*>(d_start_mask), n_items, m, pattern_hash, pat,
-                       (const int64_t*)tile_off, d_out);
+                       (const int64_t*)tile_off, n_tiles, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
