@@ -91,13 +91,33 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
                                                               const int64_t* __restrict__ off, int64_t n_rows,
                                                               int64_t total, const int64_t* __restrict__ tile_rows,
                                                               int64_t n_tiles, uint8_t* __restrict__ out) {
+  // The rows of the tile (4 KB of output: ~27 reads of 150 bases) are few: their offsets are loaded ONCE, by one coalesced
+  // load, into LDS, and every lane finds its row there — a binary search over global memory was five dependent loads per
+  // lane in front of the first byte of data.  Tiles of many tiny rows keep the search over global memory.
+  constexpr int RC_LDS_ROWS = 254;
+  __shared__ int64_t srow[RC_LDS_ROWS + 2];
   const int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * RC_BYTES_PER_LANE;
-  if (p0 >= total) return;
   int64_t lo, hi;
   tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, lo, hi);
-  int64_t r = row_of(off, lo, hi, p0);
+  const bool staged = hi - lo + 2 <= RC_LDS_ROWS + 2;          // (uniform) offsets lo .. hi + 1
+  if (staged) {
+    if ((int64_t)threadIdx.x <= hi - lo + 1) srow[threadIdx.x] = off[lo + threadIdx.x];
+    __syncthreads();
+  }
+  if (p0 >= total) return;
+  int64_t r;
+  if (staged) {
+    int a = 0, b = (int)(hi - lo);
+    while (a < b) {
+      const int mid = a + ((b - a + 1) >> 1);
+      if (srow[mid] <= p0) a = mid; else b = mid - 1;
+    }
+    r = lo + a;
+  } else {
+    r = row_of(off, lo, hi, p0);
+  }
   const int64_t p1 = min(p0 + RC_BYTES_PER_LANE, total);
-  int64_t s = off[r], e = off[r + 1];
+  int64_t s = staged ? srow[r - lo] : off[r], e = staged ? srow[r - lo + 1] : off[r + 1];
   uint64_t word[2] = {0, 0};                                  // the lane's sixteen output bytes, stored once
   if (p0 + RC_BYTES_PER_LANE <= e) {                          // (then p1 == p0 + 16 too)
     uint64_t a[2];
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
     // 150-base reads): the first 16 bytes of this row and the last 16 of the next one, two independent loads, reversed
     // and shifted together — instead of sixteen dependent single-byte loads that the other lanes of the wavefront wait for
     const int64_t k = e - p0;
-    const int64_t e2 = (r + 2 <= n_rows && p1 - p0 == RC_BYTES_PER_LANE) ? off[r + 2] : e;
+    const int64_t e2 = (r + 2 <= n_rows && p1 - p0 == RC_BYTES_PER_LANE) ? ((staged && r + 2 <= hi + 1) ? srow[r + 2 - lo] : off[r + 2]) : e;
     if (k > 0 && e - s >= RC_BYTES_PER_LANE && e2 - e >= RC_BYTES_PER_LANE) {
       uint64_t a[2], b[2];
       __builtin_memcpy(a, in + s, 16);
