@@ -82,6 +82,7 @@ SIGNATURES = {
     "bnpk_fastq_encode": (_int, [_p, _p, _i64, _int, _int, _u8, _int, _p, _i64, _i64, _p, _p, _p, _p]),
     "bnpk_kmer_starts_from_ends": (_int, [_p, _p, _i64, _int, _p, _p, _p]),
     "bnpk_row_offsets": (_int, [_p, _p, _i64, _int, _p, _p]),
+    "bnpk_packed_rows_slice": (_int, [_p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _p]),
     "bnpk_gather_encode_dna": (_int, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p]),
     "bnpk_gather_rows": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_take_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),

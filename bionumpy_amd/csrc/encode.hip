@@ -215,6 +215,30 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
   }
 }
 
+// Rows [r0, r1) of a compact packed DNA ragged array as a compact packed array of their own: the bases
+// [first, first + n_bases) of the packed stream shifted down to bit 0 (zero behind them) and the rows' offsets minus `first`.
+// (What a chunk of a batch that was encoded as a whole takes: the rows are contiguous in the batch's stream.)
+__global__ __launch_bounds__(BNPK_BLOCK) void packed_rows_slice_kernel(const uint64_t* __restrict__ packed, int64_t n_words_in,
+                                                                       const int64_t* __restrict__ offsets, int64_t r0, int64_t n_rows,
+                                                                       int64_t first, int64_t n_bases, uint64_t* __restrict__ out,
+                                                                       int64_t* __restrict__ out_offsets) {
+  const int64_t n_words = n_bases / 32 + 2;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int sh = 2 * (int)(first & 31);
+  const int64_t w0 = first >> 5;
+  for (int64_t w = i; w < n_words; w += stride) {
+    const int64_t a = w0 + w;
+    uint64_t v = a < n_words_in ? packed[a] >> sh : 0ull;
+    if (sh && a + 1 < n_words_in) v |= packed[a + 1] << (64 - sh);
+    const int64_t left = n_bases - 32 * w;                   // bases of this word that belong to the slice
+    if (left <= 0) v = 0;
+    else if (left < 32) v &= (1ull << (2 * left)) - 1ull;
+    out[w] = v;
+  }
+  for (int64_t r = i; r <= n_rows; r += stride) out_offsets[r] = offsets[r0 + r] - first;
+}
+
 // plain gather (optionally subtracting a constant from every byte): 4 x 16 output bytes per lane.
 // The rows a workgroup's 16 KiB of output come from (usually ~50) are staged in LDS first — their offsets relative to
 // the block and their starts — with one coalesced load each: without that every lane walks a chain of six to eight
@@ -503,6 +527,21 @@ int bnpk_take_bytes(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_pos, i
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "take_bytes", s);
   hipLaunchKernelGGL(take_bytes_kernel, dim3(grid_for(ceil_div(m, 256))), dim3(256), 0, s, d_buf, d_pos, m, delta, d_out);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases_in, const int64_t* d_offsets, int64_t first_row,
+                           int64_t n_rows, int64_t first_base, int64_t n_bases, uint64_t* d_out_packed, int64_t* d_out_offsets,
+                           void* stream) {
+  if (!ctx || n_bases_in < 0 || first_row < 0 || n_rows < 0 || first_base < 0 || n_bases < 0 || first_base + n_bases > n_bases_in ||
+      !d_packed || !d_offsets || !d_out_packed || !d_out_offsets)
+    return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "packed_rows_slice", s);
+  const int64_t work = std::max<int64_t>(n_bases / 32 + 2, n_rows + 1);
+  hipLaunchKernelGGL(packed_rows_slice_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(work, BNPK_BLOCK), 4096))), dim3(BNPK_BLOCK), 0, s,
+                     d_packed, n_bases_in / 32 + 2, d_offsets, first_row, n_rows, first_base, n_bases, d_out_packed, d_out_offsets);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -84,6 +84,11 @@ class OneToOneEncoding(Encoding):
 
     def _encode_ragged(self, ragged):
         """encode every row of a base-encoded ragged array (gather fused with the LUT on the device)"""
+        shared = getattr(ragged, "_batch_rows", None)
+        if shared is not None and getattr(self, "_is_dna", lambda: False)():
+            rows = shared[0].encoded_rows(self, shared[1], shared[2], shared[3])    # (io/buffers.py: BatchShare)
+            if rows is not None:
+                return rows
         data = ragged._flat_data()
         if ragged.is_compact():
             enc = self._encode_flat(data)

@@ -72,6 +72,44 @@ class FileBuffer:
         return n_new_lines >= cls.n_lines_per_entry
 
 
+class BatchShare:
+    """What the chunks that a reader cut out of ONE device batch have in common (io/parser.py:_cut_windows): the batch's
+    buffer and, computed once on first request, a field of ALL its entries encoded as DNA.  The reference's loop encodes the
+    sequence column of every 5 MB chunk on its own (``as_encoded_array(chunk.sequence, DNAEncoding)``,
+    scripts/kmer_counting_example.py:5): here that is the gather + 2-bit encode of the whole batch, once, and a chunk takes
+    its rows out of the packed result with one small kernel and no round trip to the host (``bnpk_packed_rows_slice``) —
+    the rows of a chunk are a contiguous run of the batch's.  An invalid base anywhere in the batch switches the
+    shortcut off for the batch: every chunk then encodes itself and the EncodingError comes from the chunk that holds the base,
+    with its own offset."""
+
+    def __init__(self, big, cut_rows):
+        self.big = big
+        self.cut_rows = np.asarray(cut_rows, dtype=np.int64)   # entry indices at which chunks begin / end
+        self._fields = {}
+
+    def encoded_rows(self, encoding, line, j0, j1):
+        state = self._fields.get(line)
+        if state is None:
+            from ..exceptions import EncodingError
+            try:
+                whole = encoding._encode_ragged(self.big._field_view(line))
+                bases = get_ops().read_i64(whole.offsets(), self.cut_rows)
+                state = (whole, dict(zip(self.cut_rows.tolist(), bases.tolist())))
+            except EncodingError:
+                state = False
+            self._fields[line] = state
+        if state is False:
+            return None
+        whole, base_at = state
+        if j0 not in base_at or j1 not in base_at:
+            return None
+        from ..encoded_array import _PackedDna, packed_words
+        b0, b1 = base_at[j0], base_at[j1]
+        packed, offsets = get_ops().packed_rows_slice(packed_words(whole._data), whole.total(), whole.offsets(), j0, j1 - j0, b0, b1 - b0)
+        lens = HArray(dev=whole._lens.dev()[j0:j1])
+        return EncodedRaggedArray._from_parts(_PackedDna(packed, b1 - b0), None, lens, offsets, j1 - j0, b1 - b0, encoding)
+
+
 class OneLineBuffer(FileBuffer):
     n_lines_per_entry = 2
     _line_offsets = (1, 0)
@@ -120,6 +158,9 @@ class OneLineBuffer(FileBuffer):
         view = EncodedRaggedArray._from_parts(self._data, starts, lens, None, self._scan.n_records, None,
                                               BaseEncoding)
         if self._rows is None:
+            share = getattr(self, "_share", None)
+            if share is not None:                            # (a chunk cut out of a device batch: see BatchShare)
+                view._batch_rows = (share[0], line, share[1], share[2])
             return view
         return view[self._rows.host() if isinstance(self._rows, HArray) else self._rows]
 

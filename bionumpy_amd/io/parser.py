@@ -50,6 +50,7 @@ _PIECE = int(os.environ.get("BNPK_PIECE_MB", 16)) << 20                   # ... 
 _WINDOWED = os.environ.get("BNPK_WINDOWED", "1") != "0"
 _WINDOW_MIN = int(os.environ.get("BNPK_WINDOW_MIN", 256 << 10))          # windows below this size keep the plain loop
 _WINDOW_BATCH = int(os.environ.get("BNPK_WINDOW_BATCH_MB", 128)) << 20
+_SHARE = os.environ.get("BNPK_WINDOW_SHARE", "1") != "0"                   # ... and the sequence column of a batch is encoded once for its chunks
 _WINDOW_CUTS = 200                                                       # chunks cut out of one batch at most (bnpk_window_cuts takes 256)
 
 
@@ -407,12 +408,22 @@ class NumpyFileReader:
         cuts, rebased = ops.window_cuts(big._data, big._scan, lpe, window, batch.size, self._is_finished, self._window_held,
                                         max_chunk_size, 256)
         text = big._data.dev()
+        n_cut = int(cuts[0])
+        # what the chunks of this batch share (the sequence column encoded once for all of them) — if every chunk strips
+        # carriage returns the way the batch as a whole does (the reference decides that per chunk)
+        share = None
+        if n_cut and _SHARE and all(bool(cuts[6 + 4 * i]) == big._scan.has_cr for i in range(n_cut)):
+            from .buffers import BatchShare
+            share = BatchShare(big, [0] + [int(cuts[4 + 4 * i]) for i in range(n_cut)])
         j0 = s = 0
-        for i in range(int(cuts[0])):
+        for i in range(n_cut):
             j1, e, has_cr, w_end = (int(v) for v in cuts[4 + 4 * i:8 + 4 * i])
             scan = LineScan(e - s, (j1 - j0) * lpe, j1 - j0, HArray(dev=rebased[j0 * lpe:j1 * lpe]), bool(has_cr))
             self._window_held = w_end - e
-            yield cls(HArray(dev=text[s:e]), scan), e
+            buff = cls(HArray(dev=text[s:e]), scan)
+            if share is not None:
+                buff._share = (share, j0, j1)
+            yield buff, e
             j0, s = j1, e
         if cuts[1]:                                          # (behind the chunks in front of it, as in the plain loop)
             raise Exception("No complete entry found")

@@ -264,6 +264,15 @@ class HipOps:
         self._raise_if_bad(cell)
         return (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)
 
+    def packed_rows_slice(self, packed, n_bases_in, offsets, first_row, n_rows, first_base, n_bases):
+        """rows [first_row, first_row + n_rows) of a compact packed ragged array as one of their own (bnpk_packed_rows_slice)
+        -> (packed words, offsets)"""
+        out = self._empty(n_bases // 32 + 2, np.int64)
+        off = self._empty(n_rows + 1, np.int64)
+        self._chk(lib.bnpk_packed_rows_slice(self.ctx, ptr(packed.dev()), n_bases_in, ptr(offsets.dev()), first_row, n_rows,
+                                             first_base, n_bases, ptr(out), ptr(off), self._s()))
+        return HArray(dev=out), HArray(dev=off)
+
     def gather_rows(self, buf, starts, offsets, n_rows, total, subtract=0):
         out = self._empty(total, np.uint8)
         self._chk(lib.bnpk_gather_rows(self.ctx, ptr(buf.dev()), ptr(starts.dev()), ptr(offsets.dev()), n_rows, total,

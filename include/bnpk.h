@@ -242,6 +242,15 @@ int bnpk_kmer_starts_from_ends(bnpk_ctx* ctx, const uint64_t* d_row_ends, int64_
 int bnpk_row_offsets(bnpk_ctx* ctx, const int64_t* d_lens, int64_t n, int window,
                      int64_t* d_offsets, void* stream);
 
+/* rows [first_row, first_row + n_rows) of a compact 2-bit packed ragged array (d_packed: n_bases_in bases in the layout of
+ * bnpk_gather_encode_dna, d_offsets: its row offsets) as a compact packed array of their own: the bases [first_base,
+ * first_base + n_bases) shifted down to bit 0 (n_bases / 32 + 2 words, zero behind the last base) and the rows' n_rows + 1
+ * offsets minus first_base.  What `change_encoding(chunk.sequence, DNAEncoding)` amounts to for a chunk that is a run of rows
+ * of a batch encoded as a whole (encoded_array.py:655-695 per chunk; bionumpy_amd/io/parser.py cuts the reference's 5 MB
+ * chunks out of 128 MB batches). */
+int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases_in, const int64_t* d_offsets, int64_t first_row,
+                           int64_t n_rows, int64_t first_base, int64_t n_bases, uint64_t* d_out_packed, int64_t* d_out_offsets,
+                           void* stream);
 /* ---- A6 + A7: ragged gather + ASCII -> DNA code ------------------------------------------
  * replaces EncodedRaggedArray.ravel() of the RaggedView (bionumpy/encoded_array.py:688-690) fused
  * with AlphabetEncoding._encode for 'ACGT' (bionumpy/encodings/alphabet_encoding.py:19-46):
