@@ -174,6 +174,45 @@ class HArray:
             self._np = None
 
 
+class LazyHArray(HArray):
+    """An int64 HArray of a known size whose elements are only produced (by ``make() -> HArray``) when somebody reads them: the
+    row offsets of a result nobody may ever index by row (a chunk's k-mers that go straight into a histogram)."""
+
+    __slots__ = ("_make", "_n")
+
+    def __init__(self, n, make):
+        self._np, self._t, self._n, self._make = None, None, int(n), make
+
+    def _fill(self):
+        if self._make is not None:
+            made, self._make = self._make(), None
+            self._np, self._t = made._np, made._t
+
+    @property
+    def size(self):
+        return self._n
+
+    @property
+    def dtype(self):
+        return np.dtype(np.int64)
+
+    @property
+    def on_device(self):
+        return True
+
+    def host(self):
+        self._fill()
+        return HArray.host(self)
+
+    def dev(self):
+        self._fill()
+        return HArray.dev(self)
+
+    def drop_host(self):
+        if self._make is None:
+            HArray.drop_host(self)
+
+
 def as_harray(x, dtype=None):
     if isinstance(x, HArray) or (hasattr(x, "host") and hasattr(x, "dev")):
         return x                      # HArray or an HArray-like lazy buffer (e.g. packed DNA)

@@ -107,7 +107,25 @@ class BatchShare:
         b0, b1 = base_at[j0], base_at[j1]
         packed, offsets = get_ops().packed_rows_slice(packed_words(whole._data), whole.total(), whole.offsets(), j0, j1 - j0, b0, b1 - b0)
         lens = HArray(dev=whole._lens.dev()[j0:j1])
-        return EncodedRaggedArray._from_parts(_PackedDna(packed, b1 - b0), None, lens, offsets, j1 - j0, b1 - b0, encoding)
+        rows = EncodedRaggedArray._from_parts(_PackedDna(packed, b1 - b0), None, lens, offsets, j1 - j0, b1 - b0, encoding)
+        rows._trim_source = (self, line, j0, j1)            # (sequence/kmers.py:_rolling asks trimmed() below)
+        return rows
+
+    def trimmed(self, line, window, j0, j1):
+        """(n_out, offsets) of rows [j0, j1) of the encoded field after the trim to windows of ``window`` letters (kmers.py:100):
+        the number of windows comes from ONE table per (field, window) over the whole batch, read at the cut rows once — a
+        chunk's get_kmers then needs no answer from the device; its row offsets are only computed if somebody asks."""
+        whole = self._fields[line][0]
+        key = (line, window)
+        table = self._fields.get(key)
+        if table is None:
+            ops = get_ops()
+            off, _ = ops.row_offsets(whole._lens, window)
+            at = ops.read_i64(off, self.cut_rows)
+            table = self._fields[key] = (off, dict(zip(self.cut_rows.tolist(), at.tolist())))
+        off, at = table
+        from ..device import LazyHArray
+        return at[j1] - at[j0], LazyHArray(j1 - j0 + 1, lambda: HArray(dev=off.dev()[j0:j1 + 1] - off.dev()[j0]))
 
 
 class OneLineBuffer(FileBuffer):
@@ -151,15 +169,25 @@ class OneLineBuffer(FileBuffer):
         scan = get_ops().scan_lines(data, data.size, cls.n_lines_per_entry, ord(cls.HEADER), cls._check_plus)
         return cls(data, scan)
 
+    def _field_table(self, line):
+        return get_ops().field_table(self._data, self._scan.newlines, self._scan.n_records, self.n_lines_per_entry, line,
+                                     self._line_offsets[line], self._scan.has_cr)
+
     def _field_view(self, line):
-        starts, lens = get_ops().field_table(self._data, self._scan.newlines, self._scan.n_records,
-                                             self.n_lines_per_entry, line, self._line_offsets[line],
-                                             self._scan.has_cr)
+        share = getattr(self, "_share", None) if self._rows is None else None
+        if share is not None:
+            # a chunk cut out of a device batch (see BatchShare): a consumer that encodes the field as DNA takes the rows of
+            # the batch's shared column and never looks at this chunk's own table — it is only filled in when read
+            from ..device import LazyHArray
+            n, made = self._scan.n_records, []
+            table = lambda i: (made or made.extend(self._field_table(line)) or made)[i]
+            starts, lens = LazyHArray(n, lambda: table(0)), LazyHArray(n, lambda: table(1))
+        else:
+            starts, lens = self._field_table(line)
         view = EncodedRaggedArray._from_parts(self._data, starts, lens, None, self._scan.n_records, None,
                                               BaseEncoding)
         if self._rows is None:
-            share = getattr(self, "_share", None)
-            if share is not None:                            # (a chunk cut out of a device batch: see BatchShare)
+            if share is not None:
                 view._batch_rows = (share[0], line, share[1], share[2])
             return view
         return view[self._rows.host() if isinstance(self._rows, HArray) else self._rows]

@@ -104,13 +104,13 @@ class SparseKmerCounts:
     PENDING_LIMIT = 1 << 29            # uncounted hashes a histogram holds at most (4 GiB)
     LAZY_MAX = 1 << 26                 # inputs up to this many hashes are counted lazily (larger ones: at once)
 
-    def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=62):
+    def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=62, n_pending=None):
         self.encoding = encoding
         as_h = lambda x: x if isinstance(x, HArray) else HArray(host=np.asarray(x, dtype=np.int64))
         self._k = None if keys is None else as_h(keys)
         self._c = None if counts is None else as_h(counts)
         self._pending = list(pending or [])    # HArrays of int64 hashes (shared between histograms, never written to)
-        self._n_pend = sum(p.size for p in self._pending)
+        self._n_pend = sum(p.size for p in self._pending) if n_pending is None else n_pending
         self._key_bits = key_bits
 
     def _n_pending(self):
@@ -170,7 +170,8 @@ class SparseKmerCounts:
                 k, c = get_ops().merge_add(self._k, self._c, other._k, other._c)
             else:
                 k, c = (self._k, self._c) if (self._k is not None and self._k.size) else (other._k, other._c)
-            out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, max(self._key_bits, other._key_bits))
+            out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, max(self._key_bits, other._key_bits),
+                                   self._n_pend + other._n_pend)
             if out._n_pending() >= self.PENDING_LIMIT:
                 out._force()
             return out

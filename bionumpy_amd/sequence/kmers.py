@@ -30,8 +30,12 @@ def _rolling(sequence, window, kernel):
     """shared skeleton of get_kmers / get_minimizers: trimmed output offsets + one kernel launch"""
     ops = get_ops()
     single = isinstance(sequence, EncodedArray)
+    source = None if single else getattr(sequence, "_trim_source", None)
     packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
-    out_off, n_out = ops.row_offsets(lens, window)
+    if source is not None and window >= 1:                   # rows of a reader's batch (io/buffers.py: BatchShare.trimmed)
+        n_out, out_off = source[0].trimmed(source[1], window, source[2], source[3])
+    else:
+        out_off, n_out = ops.row_offsets(lens, window)
     values = kernel(ops, packed, in_off, out_off, n_rows, n_out, total)
     return values, out_off, lens, n_rows, n_out, single
 

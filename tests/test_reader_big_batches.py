@@ -274,8 +274,14 @@ def test_chunks_of_a_batch_share_the_encoded_sequence_column(monkeypatch, tmp_pa
             for c in reader.read_chunks(min_chunk_size=4000):
                 enc = bnp.as_encoded_array(c.sequence, bnp.DNAEncoding)
                 kmers = bnp.get_kmers(enc, 5)
-                out.append((enc.tolist(), enc.lengths.tolist(), np.asarray(kmers.raw().ravel()).tolist(),
-                            bnp.count_encoded(kmers, axis=None).counts.tolist()))
+                mins = bnp.get_minimizers(enc, 3, 7)
+                # (the counts are taken BEFORE anything reads the k-mers by row: the row offsets of a shared chunk's k-mers
+                #  and the field table of its text view are only made on first use — device.py: LazyHArray)
+                counts = bnp.count_encoded(kmers, axis=None).counts.tolist()
+                out.append((enc.tolist(), enc.lengths.tolist(), np.asarray(kmers.raw().ravel()).tolist(), counts,
+                            [np.asarray(r).tolist() for r in kmers.raw()], kmers.lengths.tolist(),
+                            [np.asarray(r).tolist() for r in mins.raw()], c.sequence.lengths.tolist(),
+                            c.sequence[1:3].tolist() if len(c) > 3 else None))
         except EncodingError as e:
             err = (e.offset, str(e)[:30])
         reader.close()
