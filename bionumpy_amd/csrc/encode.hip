@@ -73,18 +73,55 @@ __device__ __forceinline__ void encode32(const uint64_t (&x)[4], uint64_t& word,
   }
 }
 
-constexpr int GE_ROWS = 512;                                   // rows of a tile (8192 bases) staged in LDS
+// The same 32 bytes as eight dwords, a few instructions each: V_PERM_B32 looks the letter of every code up again and the
+// XOR with the (case-folded) text is the validity test; a dot product packs four codes into a byte (as fastq.hip's
+// fq_codes4).  encode32 above costs ~380 vector instructions and was, with one lane in five running it twice more for
+// a row boundary, what bounded this kernel (6.1 ms per 50 M reads at 4 cycles an instruction), not memory.
+__device__ __forceinline__ void encode32_perm(const uint32_t (&x)[8], uint64_t& word, unsigned& bad32, uint32_t (&cw)[8]) {
+  uint32_t z[8], zany = 0, lo = 0, hi = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t u = x[q] & 0xDFDFDFDFu;                     // fold lower case onto upper case (exact for A C G T)
+    const uint32_t c = ((u >> 1) & 0x03030303u) ^ ((u >> 2) & 0x01010101u);
+    z[q] = u ^ __builtin_amdgcn_perm(0u, 0x54474341u, c);      // 'A' 'C' 'G' 'T' selected by the code
+    zany |= z[q];
+    cw[q] = c;
+    const uint32_t b = __builtin_amdgcn_udot4(c, 0x40100401u, 0u, false);
+    if (q < 4) lo |= b << (8 * q); else hi |= b << (8 * (q - 4));
+  }
+  bad32 = 0;
+  if (zany) {                                                  // some byte is no base: its code is 0, its bit is set
+    lo = hi = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t keep = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if ((z[q] >> (8 * j)) & 0xffu) bad32 |= 1u << (4 * q + j); else keep |= 0xffu << (8 * j);
+      }
+      cw[q] &= keep;
+      const uint32_t b = __builtin_amdgcn_udot4(cw[q], 0x40100401u, 0u, false);
+      if (q < 4) lo |= b << (8 * q); else hi |= b << (8 * (q - 4));
+    }
+  }
+  word = (uint64_t)lo | ((uint64_t)hi << 32);
+}
 
-// The rows a workgroup's 8192 bases come from (~55 reads) are staged in LDS — offsets relative to the tile, starts —
+constexpr int GE_WPL = 2;                                      // packed words per lane: a tile is 256 * GE_WPL words
+constexpr int GE_ROWS = 1024;                                  // rows of a tile (16384 bases) staged in LDS
+
+// The rows a workgroup's 16384 bases come from (~110 reads) are staged in LDS — offsets relative to the tile, starts —
 // with one coalesced load each; a lane finds the row of its 32 bases there.  Four lanes in five have all 32 inside one
-// row: two unaligned 16-byte loads, issued together.  Most of the others straddle ONE row boundary with at least 32
-// bases on either side: the 32 bytes that END the first row and the 32 that START the next are encoded separately and
-// joined in the 2-bit domain by two 64-bit shifts (likewise their invalid-byte masks).  Only lanes over short rows walk
-// row segments with 8-byte loads as rounds 1-2 did for every lane — after a binary search over the offsets in GLOBAL
-// memory: 12.7 ms per 50 M reads, a chain of ten dependent loads per lane, 0.09 of the HBM peak.
+// row: two unaligned 16-byte loads, issued together.  Most of the others straddle ONE row boundary, k bases before it
+// and a next row of at least 32 - k: they load the 32 bytes at their position in the first row as well (the bytes past
+// the row's end are whatever follows it in the buffer) and the 32 bytes that begin k bytes BEFORE the next row, and
+// take byte i from the first load for i < k and from the second otherwise — one select per dword; every lane then
+// encodes its 32 bytes once (encode32_perm).  Only lanes over short rows, or whose two loads would leave the buffer,
+// walk row segments with 8-byte loads as rounds 1-2 did for every lane — after a binary search over the offsets in
+// GLOBAL memory: 12.7 ms per 50 M reads, a chain of ten dependent loads per lane, 0.09 of the HBM peak.
 template <bool WRITE_CODES, bool WRITE_PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
-    const uint8_t* __restrict__ buf, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
+    const uint8_t* __restrict__ buf, int64_t buf_size, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
     int64_t n_rows, int64_t total, const int64_t* __restrict__ tile_rows, int64_t n_tiles,
     uint8_t* __restrict__ codes, uint64_t* __restrict__ packed, unsigned long long* __restrict__ err) {
   __shared__ int rel[GE_ROWS + 1];                             // offsets[rr0 + i] - first base of the tile (clamped below)
@@ -92,10 +129,11 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
   __shared__ int64_t first_off;
   int64_t rr[2];
   const int64_t n_words = (total + BASES_PER_WORD - 1) / BASES_PER_WORD;
-  const int64_t w0 = (int64_t)blockIdx.x * BNPK_BLOCK;
-  const int64_t w = w0 + threadIdx.x;
-  if (w0 >= n_words) {                          // pad word(s) read by the k-mer kernel
-    if (WRITE_PACKED && w <= n_words) packed[w] = 0;
+  const int64_t n_alloc = total / BASES_PER_WORD + 2;          // words of `packed`: the pad word(s) are read by the k-mer kernel
+  const int64_t w0 = (int64_t)blockIdx.x * (BNPK_BLOCK * GE_WPL);
+  if (w0 >= n_words) {
+    if (WRITE_PACKED)
+      for (int64_t w = w0 + threadIdx.x; w < n_alloc; w += BNPK_BLOCK) packed[w] = 0;
     return;
   }
   tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, rr[0], rr[1]);
@@ -115,15 +153,18 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     }
     __syncthreads();
   }
+  unsigned long long bad = (unsigned long long)BNPK_NONE;
+#pragma unroll
+  for (int it = 0; it < GE_WPL; ++it) {
+  const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
   if (w >= n_words) {
-    if (WRITE_PACKED && w == n_words) packed[w] = 0;
-    return;
+    if (WRITE_PACKED && w < n_alloc) packed[w] = 0;
+    continue;
   }
   int64_t pos = w * BASES_PER_WORD;
   const int64_t end = min(pos + BASES_PER_WORD, total);
   uint64_t word = 0;
   uint64_t cw[5] = {0, 0, 0, 0, 0};
-  unsigned long long bad = (unsigned long long)BNPK_NONE;
   bool done = false;
   int64_t row;
   if (staged) {
@@ -137,34 +178,37 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     const int row_end = rel[lo + 1];
     const int64_t start_r = lo == 0 ? first_off - blk_first : (int64_t)rel[lo];      // (tile-relative; may lie far before the tile)
     if (end - pos == BASES_PER_WORD) {
-      uint64_t x[4], c4[4];
-      unsigned bad32 = 0;
-      if (row_end - at >= BASES_PER_WORD) {                    // all 32 bases inside the row
-        const uint8_t* src = buf + st[lo] + ((int64_t)at - start_r);
-        __builtin_memcpy(x, src, 16);
-        __builtin_memcpy(x + 2, src + 16, 16);
-        encode32(x, word, bad32, c4);
+      uint32_t x[8], c8[8];
+      const int k = row_end - at;                              // bases of the row from here on (>= 1)
+      const int64_t from = st[lo] + ((int64_t)at - start_r);
+      if (k >= BASES_PER_WORD) {                               // all 32 bases inside the row
+        __builtin_memcpy(x, buf + from, 16);
+        __builtin_memcpy(x + 4, buf + from + 16, 16);
         done = true;
-      } else if (!WRITE_CODES && lo + 2 <= n_stage && (int64_t)row_end - start_r >= BASES_PER_WORD &&
-                 rel[lo + 2] - row_end >= BASES_PER_WORD) {    // one boundary, k bases before it
-        const int k = row_end - at;                            // 1 .. 31
-        uint64_t y[4], c5[4], wa, wb;
-        unsigned bad_a, bad_b;
-        const uint8_t* tail = buf + st[lo] + ((int64_t)row_end - start_r) - BASES_PER_WORD;
-        const uint8_t* head = buf + st[lo + 1];
-        __builtin_memcpy(x, tail, 16);
-        __builtin_memcpy(x + 2, tail + 16, 16);
+      } else if (lo + 2 <= n_stage && rel[lo + 2] - row_end >= BASES_PER_WORD - k && from + BASES_PER_WORD <= buf_size &&
+                 st[lo + 1] >= k && st[lo + 1] - k + BASES_PER_WORD <= buf_size) {   // one boundary, k bases before it
+        uint32_t y[8];
+        const uint8_t* head = buf + (st[lo + 1] - k);
+        __builtin_memcpy(x, buf + from, 16);
+        __builtin_memcpy(x + 4, buf + from + 16, 16);
         __builtin_memcpy(y, head, 16);
-        __builtin_memcpy(y + 2, head + 16, 16);
-        encode32(x, wa, bad_a, c4);
-        encode32(y, wb, bad_b, c5);
-        word = (wa >> (2 * (BASES_PER_WORD - k))) | (wb << (2 * k));
-        bad32 = (bad_a >> (BASES_PER_WORD - k)) | (bad_b << k);
+        __builtin_memcpy(y + 4, head + 16, 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int nb = min(max(k - 4 * q, 0), 4);            // bytes of this dword that come from the first row
+          const uint32_t m = nb == 4 ? ~0u : (1u << (8 * nb)) - 1u;
+          x[q] = (x[q] & m) | (y[q] & ~m);
+        }
         done = true;
       }
       if (done) {
-        if (bad32) bad = (unsigned long long)(pos + (__ffs((int)bad32) - 1));
-        if (WRITE_CODES) { cw[0] = c4[0]; cw[1] = c4[1]; cw[2] = c4[2]; cw[3] = c4[3]; }
+        unsigned bad32;
+        encode32_perm(x, word, bad32, c8);
+        if (bad32) bad = min(bad, (unsigned long long)(pos + (__ffs((int)bad32) - 1)));
+        if (WRITE_CODES) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cw[q] = (uint64_t)c8[2 * q] | ((uint64_t)c8[2 * q + 1] << 32);
+        }
       }
     }
   } else {
@@ -201,7 +245,6 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
       }
     }
   }
-  if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
   if (WRITE_PACKED) packed[w] = word;
   if (WRITE_CODES) {
     int64_t p0 = w * BASES_PER_WORD;
@@ -213,6 +256,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
       for (int q = 0; p0 + q < total; ++q) codes[p0 + q] = (uint8_t)(cw[q >> 3] >> (8 * (q & 7)));
     }
   }
+  }
+  if (bad != (unsigned long long)BNPK_NONE) atomicMin(err, bad);
 }
 
 // Rows [r0, r1) of a compact packed DNA ragged array as a compact packed array of their own: the bases
@@ -546,36 +591,37 @@ int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_ba
   return BNPK_OK;
 }
 
-int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
+int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t buf_size, const int64_t* d_starts,
                            const int64_t* d_offsets, int64_t n_rows, int64_t total, uint8_t* d_codes,
                            uint64_t* d_packed, int64_t* d_err_offset, void* stream) {
-  if (!ctx || n_rows < 0 || total < 0 || !d_err_offset) return BNPK_ERR_ARG;
+  if (!ctx || n_rows < 0 || total < 0 || buf_size < 0 || !d_err_offset) return BNPK_ERR_ARG;
   if (!d_codes && !d_packed) return BNPK_ERR_ARG;
   if (total > 0 && (!d_buf || !d_starts || !d_offsets || n_rows == 0)) return BNPK_ERR_ARG;
   if (d_codes && ((uintptr_t)d_codes & 15)) return BNPK_ERR_ALIGN;
   hipStream_t s = (hipStream_t)stream;
   int64_t n_words = (total + 31) / 32;
-  int64_t blocks = ceil_div(n_words + 1, BNPK_BLOCK);
+  constexpr int64_t tile_words = (int64_t)BNPK_BLOCK * GE_WPL;
+  int64_t blocks = ceil_div(total / 32 + 2, tile_words);
   if (blocks > BNPK_MAX_BLOCKS) return BNPK_ERR_RANGE;
   auto* err = reinterpret_cast<unsigned long long*>(d_err_offset);
-  // tiles of 256 packed words (8192 bases); the launch has extra workgroup(s) for the pad word
-  const int64_t n_tiles = ceil_div(n_words, BNPK_BLOCK);
+  // tiles of 512 packed words (16384 bases); the launch covers the pad word(s) too
+  const int64_t n_tiles = ceil_div(n_words, tile_words);
   void* table = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "gather_encode_dna", s);
   if (total > 0)
-    BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, (int64_t)BNPK_BLOCK * 32, (int64_t*)table, s));
+    BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, tile_words * 32, (int64_t*)table, s));
   const int64_t* tr = (const int64_t*)table;
   dim3 g((unsigned)blocks), b(BNPK_BLOCK);
   if (d_codes && d_packed)
-    hipLaunchKernelGGL((gather_encode_kernel<true, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       tr, n_tiles, d_codes, d_packed, err);
+    hipLaunchKernelGGL((gather_encode_kernel<true, true>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
+                       total, tr, n_tiles, d_codes, d_packed, err);
   else if (d_packed)
-    hipLaunchKernelGGL((gather_encode_kernel<false, true>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       tr, n_tiles, d_codes, d_packed, err);
+    hipLaunchKernelGGL((gather_encode_kernel<false, true>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
+                       total, tr, n_tiles, d_codes, d_packed, err);
   else
-    hipLaunchKernelGGL((gather_encode_kernel<true, false>), g, b, 0, s, d_buf, d_starts, d_offsets, n_rows, total,
-                       tr, n_tiles, d_codes, d_packed, err);
+    hipLaunchKernelGGL((gather_encode_kernel<true, false>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
+                       total, tr, n_tiles, d_codes, d_packed, err);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

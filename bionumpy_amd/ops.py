@@ -259,7 +259,7 @@ class HipOps:
         codes = self._empty(total, np.uint8) if want_codes else None
         packed = self._empty(total // 32 + 2, np.int64) if want_packed else None
         cell = self._err_cell()
-        self._chk(lib.bnpk_gather_encode_dna(self.ctx, ptr(buf.dev()), ptr(starts.dev()), ptr(offsets.dev()), n_rows,
+        self._chk(lib.bnpk_gather_encode_dna(self.ctx, ptr(buf.dev()), buf.size, ptr(starts.dev()), ptr(offsets.dev()), n_rows,
                                              total, ptr(codes), ptr(packed), ptr(cell), self._s()))
         self._raise_if_bad(cell)
         return (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)

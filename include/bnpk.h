@@ -259,8 +259,9 @@ int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_ba
  * bnpk_fill_i64).  Row r is d_buf[d_starts[r] .. +len) and lands at flat offset d_offsets[r].
  * d_codes (1 byte/base, the reference layout) and d_packed (2 bits/base, 32 bases per uint64,
  * base i at bits 2*(i%32) of word i/32 == npstructures BitArray.pack(.., bit_stride=2),
- * bionumpy/sequence/kmers.py:121) are both optional; d_packed needs total/32 + 2 words. */
-int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, const int64_t* d_starts,
+ * bionumpy/sequence/kmers.py:121) are both optional; d_packed needs total/32 + 2 words.
+ * buf_size: bytes of d_buf (the kernel reads up to 31 bytes either side of a row, never outside [0, buf_size)). */
+int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t buf_size, const int64_t* d_starts,
                            const int64_t* d_offsets, int64_t n_rows, int64_t total,
                            uint8_t* d_codes, uint64_t* d_packed, int64_t* d_err_offset,
                            void* stream);

@@ -90,6 +90,47 @@ def test_gather_encode_and_kmers(ops, seed, n_rows, max_len):
                 assert np.array_equal(kernel(packed, offsets, out_off, n_rows, n_out, k, w).host(), m)
 
 
+@pytest.mark.parametrize("seed,n_rows,lo,hi,shuffle", [(5, 4000, 90, 110, False), (6, 4000, 33, 64, True), (7, 3000, 1, 150, True),
+                                                      (8, 500, 100, 101, False), (9, 2000, 20, 45, False)])
+def test_gather_encode_rows_between_other_text(ops, seed, n_rows, lo, hi, shuffle):
+    """rows laid out as in a file — other text (no bases) between them, the first row at byte 0 and the last one ending the
+    buffer, optionally gathered in another order than they lie: the lanes that straddle a row boundary read past the end
+    of one row and in front of the next (encode.hip: gather_encode_kernel) and must take nothing from there; one invalid
+    base at a time, next to a boundary, is reported with its own offset"""
+    from bionumpy_amd.exceptions import EncodingError
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(lo, hi, size=n_rows).astype(np.int64)
+    junk = rng.integers(0, 6, size=n_rows)
+    junk[-1] = 0
+    pieces, starts, at = [], [], 0
+    for l, j in zip(lengths, junk):
+        starts.append(at)
+        pieces.append(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=l))
+        pieces.append(np.frombuffer(b"\n+\n!I5\n@r\n"[:2 * j], dtype=np.uint8))
+        at += int(l) + 2 * int(j)
+    text = np.concatenate(pieces)
+    starts = np.array(starts, dtype=np.int64)
+    order = rng.permutation(n_rows) if shuffle else np.arange(n_rows)
+    starts, lengths = starts[order], lengths[order]
+    offsets, total = ops.row_offsets(_h(lengths), 1)
+    expect = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
+    words = oracle.pack_2bit(expect)
+    for want_codes in (False, True):
+        codes, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=want_codes)
+        assert np.array_equal(packed.host().view(np.uint64)[:words.size], words)
+        assert packed.host()[words.size:].max(initial=0) == 0
+        if want_codes:
+            assert np.array_equal(codes.host(), expect)
+    off = offsets.host()
+    for r in rng.choice(n_rows - 1, size=6, replace=False):
+        for where in (0, int(lengths[r]) - 1):                 # the first / last base of a row
+            spoiled = text.copy()
+            spoiled[starts[r] + where] = ord("N")
+            with pytest.raises(EncodingError) as e:
+                ops.gather_encode_dna(_h(spoiled), _h(starts), offsets, n_rows, total)
+            assert e.value.offset == int(off[r]) + where
+
+
 def test_encoding_error_offset_is_first_bad_byte(ops):
     from bionumpy_amd.exceptions import EncodingError
     text, starts, lengths = _random_reads(11, 2000, 100, with_empty=False)
