@@ -102,6 +102,24 @@ __device__ __forceinline__ uint64_t reverse_2bit_groups(uint64_t x) {
   return __builtin_bswap64(x);
 }
 
+// bit j of the result = byte j of the sixteen bytes w[0..3] is NOT `rep`'s byte.  Per 32-bit word the classic exact
+// zero-byte test leaves 0x7f in a matching byte and 0xff in any other; V_DOT4_U32_U8 against the weights 1,2,4,...,128 then
+// gathers eight flags at a time: sum(w_i * g_i) = 0x7f * 255 + 0x80 * (mask of the non-matching bytes), and the
+// constant goes into the accumulator.  (About 27 vector instructions; the shift-and-mask gather costs twice that, and a
+// pass over text has ~100 instructions per sixteen bytes to spend before it, not HBM, sets the pace.)
+__device__ __forceinline__ uint32_t nomatch16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t rep) {
+  const uint32_t w[4] = {w0, w1, w2, w3};
+  uint32_t g[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t x = w[q] ^ rep;
+    g[q] = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
+  }
+  const uint32_t bias = 0u - 0x7fu * 255u;
+  const uint32_t a = __builtin_amdgcn_udot4(g[1], 0x80402010u, __builtin_amdgcn_udot4(g[0], 0x08040201u, bias, false), false);
+  const uint32_t b = __builtin_amdgcn_udot4(g[3], 0x80402010u, __builtin_amdgcn_udot4(g[2], 0x08040201u, bias, false), false);
+  return (a >> 7) | (b << 1);                                // a, b = 128 * (eight flags)
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

@@ -21,21 +21,15 @@ __device__ __forceinline__ uint32_t match_bytes(uint32_t w, uint32_t rep) {
   return ~(t | x | 0x7f7f7f7fu);
 }
 
+__device__ __forceinline__ uint32_t nomatch16_of(uint4 v, uint32_t rep) { return nomatch16(v.x, v.y, v.z, v.w, rep); }
+
 // 16-bit mask (bit j = byte pos+j matches) for the 16 bytes at `pos`; bytes >= n never match
 __device__ __forceinline__ uint32_t match16(const uint8_t* __restrict__ buf, int64_t pos, int64_t n,
                                             uint32_t rep) {
   if (pos >= n) return 0;
   uint32_t m = 0;
   if (pos + VEC <= n) {
-    uint4 v = *reinterpret_cast<const uint4*>(buf + pos);
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      uint32_t h = match_bytes(w[q], rep);
-      // gather the 4 high bits (bits 7,15,23,31) into 4 consecutive bits
-      uint32_t b = ((h >> 7) & 1u) | ((h >> 14) & 2u) | ((h >> 21) & 4u) | ((h >> 28) & 8u);
-      m |= b << (4 * q);
-    }
+    m = ~nomatch16_of(*reinterpret_cast<const uint4*>(buf + pos), rep) & 0xffffu;
   } else {
     uint8_t value = (uint8_t)(rep & 0xff);
     for (int j = 0; j < VEC && pos + j < n; ++j)
@@ -43,6 +37,9 @@ __device__ __forceinline__ uint32_t match16(const uint8_t* __restrict__ buf, int
   }
   return m;
 }
+
+// bit j of the result = byte j of v matches
+__device__ __forceinline__ uint32_t match_vec(uint4 v, uint32_t rep) { return ~nomatch16(v.x, v.y, v.z, v.w, rep) & 0xffffu; }
 
 __device__ __forceinline__ int64_t lane_pos(int64_t tile_base, int it) {
   return tile_base + (int64_t)wave_id() * (ITERS * WAVE_BYTES) + (int64_t)it * WAVE_BYTES + lane_id() * VEC;
@@ -85,41 +82,78 @@ __global__ __launch_bounds__(BNPK_BLOCK) void byte_positions_kernel(const uint8_
   if (VALIDATE && blockIdx.x == 0 && threadIdx.x == 0 && limit >= lpe && buf[0] != header) atomicMin(&err[0], 0ull);
   if (first >= limit || tile_offsets[blockIdx.x + 1] == first) return;   // uniform per block
   uint32_t m[ITERS];
+  uint4 text[VALIDATE ? ITERS : 1];                          // VALIDATE: the sixteen bytes themselves stay in registers: the byte that
+  uint32_t behind[VALIDATE ? ITERS : 1];                     // starts the next line is one of them, or the next lane's first
   int c = 0;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    m[it] = match16(buf, lane_pos(tile_base, it), n, rep);
+    const int64_t pos = lane_pos(tile_base, it);
+    if (VALIDATE && pos + VEC <= n) {
+      text[it] = *reinterpret_cast<const uint4*>(buf + pos);
+      m[it] = match_vec(text[it], rep);
+      behind[it] = text[it].x & 0xffu;
+    } else {
+      m[it] = match16(buf, pos, n, rep);
+      if (VALIDATE) {
+        text[it] = make_uint4(0u, 0u, 0u, 0u);
+        behind[it] = 0x100u;                                 // (no vector here: whoever asks reads memory)
+      }
+    }
     c += __popc(m[it]);
+  }
+  if (VALIDATE) {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const uint32_t next = __shfl_down(behind[it], 1, 64);
+      behind[it] = lane_id() == 63 ? 0x100u : next;            // (lane 63: the first byte of another wavefront's chunk)
+    }
   }
   int wave_total = wave_reduce_sum(c);
   if (lane_id() == 0) smem[wave_id()] = wave_total;
   __syncthreads();
-  int64_t rank = first;
+  int rank = 0;                                                        // (ranks and positions relative to the tile: 32 bits)
   for (int w = 0; w < wave_id(); ++w) rank += smem[w];
+  const int lim = (int)min(limit - first, (int64_t)1 << 30);
+  int64_t* __restrict__ out_t = out + first;
   const int first_phase = VALIDATE ? (int)(first % lpe) : 0;           // (line index modulo lines per entry, in 32 bits from here)
+  const bool pow2 = (lpe & (lpe - 1)) == 0;                            // 4 (FASTQ), 2 (FASTA): a mask instead of a division per newline
   // matches are ordered (wave, iteration, lane, byte): rank the lanes of each iteration with a wave scan
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     int pc = __popc(m[it]);
     int inc = wave_inclusive_scan(pc);
-    int64_t r = rank + inc - pc;
-    int64_t pos = lane_pos(tile_base, it);
+    int r = rank + inc - pc;
+    const int64_t pos = lane_pos(tile_base, it);
     uint32_t mm = m[it];
     while (mm) {
       int j = __ffs(mm) - 1;
       mm &= mm - 1;
-      if (r < limit) {
-        out[r] = pos + j;
+      if (r < lim) {
+        const int64_t p = pos + j;
+        out_t[r] = p;
         if (VALIDATE) {
-          const int64_t p = pos + j;
-          const int phase = (int)((unsigned)(r - first) + (unsigned)first_phase) % lpe;     // of the line this newline ends
-          if (r + 1 < limit) {                               // the line behind it belongs to a complete entry
+          const unsigned ph = (unsigned)r + (unsigned)first_phase;                          // (< 16384 + lpe)
+          const int phase = pow2 ? (int)(ph & (unsigned)(lpe - 1)) : (int)(ph % (unsigned)lpe);  // of the line this newline ends
+          if (r + 1 < lim) {                                 // the line behind it belongs to a complete entry
             const int next = phase + 1 == lpe ? 0 : phase + 1;
-            if (next == 0 && buf[p + 1] != header) atomicMin(&err[0], (unsigned long long)((r + 1) / lpe));
-            if (check_plus && next == 2 && buf[p + 1] != '+') atomicMin(&err[1], (unsigned long long)((r + 1) / lpe));
+            if (next == 0 || (check_plus && next == 2)) {
+              uint32_t b;
+              if (pos + VEC > n) {
+                b = 0x100u;
+              } else if (j < 15) {
+                const int q = (j + 1) >> 2;
+                const uint32_t w = q == 0 ? text[it].x : q == 1 ? text[it].y : q == 2 ? text[it].z : text[it].w;
+                b = (w >> (8 * ((j + 1) & 3))) & 0xffu;
+              } else {
+                b = behind[it];
+              }
+              if (b > 0xffu) b = buf[p + 1];
+              if (next == 0 && b != header) atomicMin(&err[0], (unsigned long long)((first + r + 1) / lpe));
+              if (next == 2 && b != '+') atomicMin(&err[1], (unsigned long long)((first + r + 1) / lpe));
+            }
           }
-          if (phase == 0 && r < (int64_t)lpe * lpe) {        // the header line of one of the first lpe entries
-            if (r == 0 && p == 0) atomicOr(&err[2], 2ull);
+          if (phase == 0 && first + r < (int64_t)lpe * lpe) {   // the header line of one of the first lpe entries
+            if (first + r == 0 && p == 0) atomicOr(&err[2], 2ull);
             if (p >= 1 && buf[p - 1] == '\r') atomicOr(&err[2], 1ull);
           }
         }

@@ -36,22 +36,9 @@ constexpr int FQ_MAXLPE = 4;
 constexpr int FQ_TREC = 1 + FQ_MAXLPE;                       // per-tile census record: first line, payload bytes per phase
 constexpr uint8_t FQ_NL = 10, FQ_CR = 13;
 
-// bit j of the result = byte j of the sixteen bytes is NOT `rep`'s byte.  Per 32-bit word the classic exact zero-byte
-// test leaves 0x7f in a matching byte and 0xff in any other; V_DOT4_U32_U8 against the weights 1,2,4,...,128 then
-// gathers eight flags at a time: sum(w_i * g_i) = 0x7f * 255 + 0x80 * (mask of the non-matching bytes), and the
-// constant goes into the accumulator.
+// (nomatch16: common.h)
 __device__ __forceinline__ uint32_t fq_nomatch16(uint64_t lo, uint64_t hi, uint32_t rep) {
-  const uint32_t w[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-  uint32_t g[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t x = w[q] ^ rep;
-    g[q] = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu;
-  }
-  const uint32_t bias = 0u - 0x7fu * 255u;
-  const uint32_t a = __builtin_amdgcn_udot4(g[1], 0x80402010u, __builtin_amdgcn_udot4(g[0], 0x08040201u, bias, false), false);
-  const uint32_t b = __builtin_amdgcn_udot4(g[3], 0x80402010u, __builtin_amdgcn_udot4(g[2], 0x08040201u, bias, false), false);
-  return (a >> 7) | (b << 1);                                // a, b = 128 * (eight flags)
+  return nomatch16((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), rep);
 }
 __device__ __forceinline__ uint32_t fq_mask16(uint64_t lo, uint64_t hi, uint32_t rep) {   // bit j = byte j matches
   return ~fq_nomatch16(lo, hi, rep) & 0xffffu;
