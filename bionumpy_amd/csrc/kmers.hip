@@ -183,6 +183,20 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_generate_kernel(const uint64_t*
 // k-mers.  These are rolled ONCE, and the eight window minima come from a doubling scheme over them —
 // a[i] = min(a[i], a[i + 2^j]) for j = 0 .. L - 1 turns a[i] into the minimum of 2^L hashes from i on (2^L <= PW), and
 // min(a[q], a[q + PW - 2^L]) is the window's: at PW = 10, 16 rolls and 48 comparisons per lane instead of 80 and 72.
+// (Sixteen positions per lane share the rolls and doubling steps among twice the windows, but at 70 registers and 32 KiB
+// of staging per workgroup the kernel came out slower, 11.0 against 10.4 ms per 50 M reads: it is not the instructions
+// that bound it any more.)
+// The smaller of two hashes in ONE instruction: a hash has at most 62 bits, so as the bit pattern of a double it is a
+// non-negative number that is neither infinite nor NaN (a denormal below 2^52 — the kernels run with FP64 denormals kept,
+// the default), and for those the order of the doubles is the order of the integers.  V_MIN_F64 runs at full rate on
+// gfx950 and hands one of its operands back bit for bit; the integer form is a 64-bit compare and two selects.  (Inline
+// assembly: llvm.minnum would first canonicalize both operands, two instructions more.)
+__device__ __forceinline__ uint64_t min_hash(uint64_t x, uint64_t y) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, x)), "v"(__builtin_bit_cast(double, y)));
+  return __builtin_bit_cast(uint64_t, r);
+}
+
 template <int PW>
 __global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t* __restrict__ W, int64_t n_words,
                                                                   const uint8_t* __restrict__ mask8, int64_t n_bases, int k,
@@ -194,6 +208,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t
   __shared__ uint64_t stage[WF_TILE];
   __shared__ unsigned wsum[BNPK_BLOCK / 64];
   const int64_t o = (int64_t)blockIdx.x * WF_TILE + (int64_t)threadIdx.x * WF_ITEMS;
+  const int64_t run_first = tile_off[blockIdx.x], run_end = tile_off[blockIdx.x + 1];   // (asked for now, needed last)
   const unsigned v = o < n_bases ? mask8[o >> 3] : 0u;
   const unsigned cnt = __popc(v);
   const unsigned inc = wave_inclusive_scan(cnt);
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t
 #pragma unroll
     for (int j = 0; j < L; ++j) {
 #pragma unroll
-      for (int i = 0; i + (1 << j) < H; ++i) a[i] = a[i + (1 << j)] < a[i] ? a[i + (1 << j)] : a[i];
+      for (int i = 0; i + (1 << j) < H; ++i) a[i] = min_hash(a[i + (1 << j)], a[i]);
     }
   }
   __syncthreads();
@@ -223,13 +238,12 @@ __global__ __launch_bounds__(BNPK_BLOCK) void wf_minimizer_kernel(const uint64_t
 #pragma unroll
     for (int q = 0; q < WF_ITEMS; ++q) {
       if ((v >> q) & 1u) {
-        const uint64_t x = a[q], y = a[q + PW - (1 << L)];
-        stage[rank++] = y < x ? y : x;
+        stage[rank++] = min_hash(a[q], a[q + PW - (1 << L)]);
       }
     }
   }
   __syncthreads();
-  wf_store_run(stage, tile_off[blockIdx.x], tile_off[blockIdx.x + 1], out);
+  wf_store_run(stage, run_first, run_end, out);
 }
 
 // match_string (bionumpy/sequence/string_matcher.py:16-55): for every window of m symbols (marked in the start mask)
