@@ -83,7 +83,7 @@ SIGNATURES = {
     "bnpk_kmer_starts_from_ends": (_int, [_p, _p, _i64, _int, _p, _p, _p]),
     "bnpk_row_offsets": (_int, [_p, _p, _i64, _int, _p, _p]),
     "bnpk_packed_rows_slice": (_int, [_p, _p, _i64, _p, _i64, _i64, _i64, _i64, _p, _p, _p]),
-    "bnpk_gather_encode_dna": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _p]),
+    "bnpk_gather_encode_dna": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]),
     "bnpk_gather_rows": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_take_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_encode_dna_flat": (_int, [_p, _p, _i64, _p, _p, _p, _p]),

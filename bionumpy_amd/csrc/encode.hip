@@ -123,7 +123,8 @@ template <bool WRITE_CODES, bool WRITE_PACKED>
 __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
     const uint8_t* __restrict__ buf, int64_t buf_size, const int64_t* __restrict__ starts, const int64_t* __restrict__ offsets,
     int64_t n_rows, int64_t total, const int64_t* __restrict__ tile_rows, int64_t n_tiles,
-    uint8_t* __restrict__ codes, uint64_t* __restrict__ packed, unsigned long long* __restrict__ err) {
+    uint8_t* __restrict__ codes, uint64_t* __restrict__ packed, unsigned* __restrict__ ends32,
+    unsigned long long* __restrict__ err) {
   __shared__ int rel[GE_ROWS + 1];                             // offsets[rr0 + i] - first base of the tile (clamped below)
   __shared__ int64_t st[GE_ROWS];
   __shared__ int64_t first_off;
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
   const int64_t n_alloc = total / BASES_PER_WORD + 2;          // words of `packed`: the pad word(s) are read by the k-mer kernel
   const int64_t w0 = (int64_t)blockIdx.x * (BNPK_BLOCK * GE_WPL);
   if (w0 >= n_words) {
-    if (WRITE_PACKED)
-      for (int64_t w = w0 + threadIdx.x; w < n_alloc; w += BNPK_BLOCK) packed[w] = 0;
+    for (int64_t w = w0 + threadIdx.x; w < n_alloc; w += BNPK_BLOCK) {
+      if (WRITE_PACKED) packed[w] = 0;
+      if (ends32) ends32[w] = 0;
+    }
     return;
   }
   tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, rr[0], rr[1]);
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
   const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
   if (w >= n_words) {
     if (WRITE_PACKED && w < n_alloc) packed[w] = 0;
+    if (ends32 && w < n_alloc) ends32[w] = 0;
     continue;
   }
+  unsigned endbits = 0;                                      // bit i: base i of this word is the last of its row
   int64_t pos = w * BASES_PER_WORD;
   const int64_t end = min(pos + BASES_PER_WORD, total);
   uint64_t word = 0;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
       if (k >= BASES_PER_WORD) {                               // all 32 bases inside the row
         __builtin_memcpy(x, buf + from, 16);
         __builtin_memcpy(x + 4, buf + from + 16, 16);
+        endbits = k == BASES_PER_WORD ? 1u << 31 : 0u;
         done = true;
       } else if (lo + 2 <= n_stage && rel[lo + 2] - row_end >= BASES_PER_WORD - k && from + BASES_PER_WORD <= buf_size &&
                  st[lo + 1] >= k && st[lo + 1] - k + BASES_PER_WORD <= buf_size) {   // one boundary, k bases before it
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
           const uint32_t m = nb == 4 ? ~0u : (1u << (8 * nb)) - 1u;
           x[q] = (x[q] & m) | (y[q] & ~m);
         }
+        endbits = (1u << (k - 1)) | (rel[lo + 2] - row_end == BASES_PER_WORD - k ? 1u << 31 : 0u);
         done = true;
       }
       if (done) {
@@ -243,8 +250,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void gather_encode_kernel(
         word |= compress_codes8(c) << (2 * j);
         j += m; src += m; pos += m; seg -= m;
       }
+      if (pos == row_end) endbits |= 1u << (j - 1);
     }
   }
+  if (ends32) ends32[w] = endbits;
   if (WRITE_PACKED) packed[w] = word;
   if (WRITE_CODES) {
     int64_t p0 = w * BASES_PER_WORD;
@@ -593,7 +602,7 @@ int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_ba
 
 int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t buf_size, const int64_t* d_starts,
                            const int64_t* d_offsets, int64_t n_rows, int64_t total, uint8_t* d_codes,
-                           uint64_t* d_packed, int64_t* d_err_offset, void* stream) {
+                           uint64_t* d_packed, uint64_t* d_row_ends, int64_t* d_err_offset, void* stream) {
   if (!ctx || n_rows < 0 || total < 0 || buf_size < 0 || !d_err_offset) return BNPK_ERR_ARG;
   if (!d_codes && !d_packed) return BNPK_ERR_ARG;
   if (total > 0 && (!d_buf || !d_starts || !d_offsets || n_rows == 0)) return BNPK_ERR_ARG;
@@ -609,19 +618,22 @@ int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t buf_size
   void* table = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "gather_encode_dna", s);
+  unsigned* ends32 = reinterpret_cast<unsigned*>(d_row_ends);
+  if (d_row_ends)                                            // (its last two words: the kernel covers total/32 + 2 halves of them)
+    BNPK_HIP(ctx, hipMemsetAsync(d_row_ends + total / 64, 0, 16, s));
   if (total > 0)
     BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, tile_words * 32, (int64_t*)table, s));
   const int64_t* tr = (const int64_t*)table;
   dim3 g((unsigned)blocks), b(BNPK_BLOCK);
   if (d_codes && d_packed)
     hipLaunchKernelGGL((gather_encode_kernel<true, true>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
-                       total, tr, n_tiles, d_codes, d_packed, err);
+                       total, tr, n_tiles, d_codes, d_packed, ends32, err);
   else if (d_packed)
     hipLaunchKernelGGL((gather_encode_kernel<false, true>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
-                       total, tr, n_tiles, d_codes, d_packed, err);
+                       total, tr, n_tiles, d_codes, d_packed, ends32, err);
   else
     hipLaunchKernelGGL((gather_encode_kernel<true, false>), g, b, 0, s, d_buf, buf_size, d_starts, d_offsets, n_rows,
-                       total, tr, n_tiles, d_codes, d_packed, err);
+                       total, tr, n_tiles, d_codes, d_packed, ends32, err);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -96,8 +96,11 @@ class OneToOneEncoding(Encoding):
             enc = self._encode_gather(data, ragged._starts, ragged.offsets(), ragged._n_rows, ragged.total())
         if self.is_numeric():
             return RaggedArray._from_parts(enc, None, ragged._lens, ragged._offsets, ragged._n_rows, ragged._total)
-        return EncodedRaggedArray._from_parts(enc, None, ragged._lens, ragged._offsets, ragged._n_rows,
-                                              ragged._total, self)
+        out = EncodedRaggedArray._from_parts(enc, None, ragged._lens, ragged._offsets, ragged._n_rows, ragged._total, self)
+        ends = enc.__dict__.pop("_gather_ends", None) if hasattr(enc, "__dict__") else None
+        if ends is not None:
+            out._row_ends = ends                             # (of THIS row layout: sequence/kmers.py:_rolling)
+        return out
 
     def decode(self, data):
         raise NotImplementedError
@@ -192,8 +195,14 @@ class AlphabetEncoding(OneToOneEncoding):
 
     def _encode_gather(self, data, starts, offsets, n_rows, total):
         if self._is_dna():
-            codes, packed = get_ops().gather_encode_dna(data, starts, offsets, n_rows, total, want_codes=False,
-                                                        want_packed=True)
+            ops = get_ops()
+            if getattr(ops, "GATHER_GIVES_ROW_ENDS", False):  # (the kernel knows the rows' last bases as it goes: kept for
+                codes, packed, ends = ops.gather_encode_dna(data, starts, offsets, n_rows, total, want_codes=False,
+                                                            want_packed=True, want_ends=True)   # get_kmers / get_minimizers)
+                out = _PackedDna(packed, total)
+                out._gather_ends = ends
+                return out
+            codes, packed = ops.gather_encode_dna(data, starts, offsets, n_rows, total, want_codes=False, want_packed=True)
             return _PackedDna(packed, total)
         return get_ops().lut_bytes(get_ops().gather_rows(data, starts, offsets, n_rows, total, 0), self._lookup(),
                                    str(self))

@@ -255,14 +255,17 @@ class HipOps:
             raise EncodingError("Error when encoding to AlphabetEncoding('ACGT'): invalid character at flat "
                                 "offset %d" % off, off)
 
-    def gather_encode_dna(self, buf, starts, offsets, n_rows, total, want_codes=False, want_packed=True):
+    def gather_encode_dna(self, buf, starts, offsets, n_rows, total, want_codes=False, want_packed=True, want_ends=False):
+        """-> (codes, packed[, row-end bits: what row_end_mask would make of ``offsets``])"""
         codes = self._empty(total, np.uint8) if want_codes else None
         packed = self._empty(total // 32 + 2, np.int64) if want_packed else None
+        ends = self._empty(total // 64 + 2, np.int64) if want_ends else None
         cell = self._err_cell()
         self._chk(lib.bnpk_gather_encode_dna(self.ctx, ptr(buf.dev()), buf.size, ptr(starts.dev()), ptr(offsets.dev()), n_rows,
-                                             total, ptr(codes), ptr(packed), ptr(cell), self._s()))
+                                             total, ptr(codes), ptr(packed), ptr(ends), ptr(cell), self._s()))
         self._raise_if_bad(cell)
-        return (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)
+        out = (HArray(dev=codes) if want_codes else None, HArray(dev=packed) if want_packed else None)
+        return out + (HArray(dev=ends),) if want_ends else out
 
     def packed_rows_slice(self, packed, n_bases_in, offsets, first_row, n_rows, first_base, n_bases):
         """rows [first_row, first_row + n_rows) of a compact packed ragged array as one of their own (bnpk_packed_rows_slice)
@@ -302,6 +305,7 @@ class HipOps:
 
     # -- A8 / A11 ------------------------------------------------------------------------------------------
     WINDOWS_FLAT_MAX = 26         # k-mers per window the row-lookup-free generator covers
+    GATHER_GIVES_ROW_ENDS = True  # gather_encode_dna(want_ends=True): the rows' end bits as a by-product
 
     def _windows_flat(self, packed, in_offsets, n_rows, n_out, k, window_size, total=None):
         """hashes (window_size == k) / minimizers through the position-flat generator: start mask + ranks"""
@@ -314,6 +318,30 @@ class HipOps:
         self._chk(lib.bnpk_windows_flat(self.ctx, ptr(packed.dev()), ptr(mask.dev()), total, k, window_size - k + 1,
                                         n_out, ptr(out), self._s()))
         return HArray(dev=out)
+
+    def windows_counted(self, packed, in_offsets, n_rows, k, window_size, total, row_ends=None):
+        """(hashes (window_size == k) / minimizers of every window of window_size letters, their number) — the number comes
+        back with the start mask (bnpk_kmer_starts_from_ends counts the bits it sets), so nobody has to scan the trimmed row
+        lengths for it before the output can be allocated.  row_ends: the rows' end bits if somebody has them already
+        (bnpk_gather_encode_dna).  None where the position-flat generator does not reach."""
+        if window_size > 64 or window_size - k + 1 > self.WINDOWS_FLAT_MAX:
+            return None
+        if total == 0:
+            return HArray(dev=self._empty(0, np.int64)), 0
+        if row_ends is None:
+            ends = self._empty(total // 64 + 2, np.int64)
+            self._chk(lib.bnpk_row_end_mask(self.ctx, ptr(in_offsets.dev()), n_rows, total, ptr(ends), self._s()))
+        else:
+            ends = row_ends.dev()
+        mask = self._empty(total // 64 + 2, np.int64)
+        count = self._empty(1, np.int64)
+        self._chk(lib.bnpk_kmer_starts_from_ends(self.ctx, ptr(ends), total, window_size, ptr(mask), ptr(count), self._s()))
+        n_out = self._fetch(count, 1)[0]
+        out = self._empty(n_out, np.int64)
+        if n_out:
+            self._chk(lib.bnpk_windows_flat(self.ctx, ptr(packed.dev()), ptr(mask), total, k, window_size - k + 1, n_out,
+                                            ptr(out), self._s()))
+        return HArray(dev=out), n_out
 
     def windows_from_mask(self, packed, start_mask, n_bases, n_out, k, window_size):
         """hashes (window_size == k) / minimizers of the windows marked in ``start_mask`` (bnpk_windows_flat)"""

@@ -26,14 +26,23 @@ def _as_dna_ragged(sequence):
     return packed_words(sequence._data), sequence.offsets(), sequence._lens, len(sequence), sequence.total()
 
 
-def _rolling(sequence, window, kernel):
+def _rolling(sequence, window, k, kernel):
     """shared skeleton of get_kmers / get_minimizers: trimmed output offsets + one kernel launch"""
     ops = get_ops()
     single = isinstance(sequence, EncodedArray)
     source = None if single else getattr(sequence, "_trim_source", None)
+    row_ends = None if single else getattr(sequence, "_row_ends", None)
     packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
     if source is not None and window >= 1:                   # rows of a reader's batch (io/buffers.py: BatchShare.trimmed)
         n_out, out_off = source[0].trimmed(source[1], window, source[2], source[3])
+    elif hasattr(ops, "windows_counted") and ops.windows_counted is not None:
+        # the number of windows comes back with the start mask; the trimmed row offsets are only scanned if somebody asks
+        counted = ops.windows_counted(packed, in_off, n_rows, k, window, total, row_ends)
+        if counted is not None:
+            from ..device import LazyHArray
+            out_off = LazyHArray(n_rows + 1, lambda: ops.row_offsets(lens, window)[0])
+            return counted[0], out_off, lens, n_rows, counted[1], single
+        out_off, n_out = ops.row_offsets(lens, window)
     else:
         out_off, n_out = ops.row_offsets(lens, window)
     values = kernel(ops, packed, in_off, out_off, n_rows, n_out, total)
@@ -107,7 +116,7 @@ def get_kmers(sequence, k, canonical=False):
     if sequence.encoding.alphabet_size != 4:                 # (kmers.py:82-87: only 4-letter alphabets take the 2-bit path)
         return _get_kmers_generic(sequence, k)
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
-        sequence, k, lambda ops, p, i, o, n, m, t: ops.kmers(p, i, o, n, m, k, total=t))
+        sequence, k, k, lambda ops, p, i, o, n, m, t: ops.kmers(p, i, o, n, m, k, total=t))
     if canonical and n_out:
         hashes = get_ops().canonical_kmers(hashes, k)
     encoding = KmerEncoding(sequence.encoding, k)

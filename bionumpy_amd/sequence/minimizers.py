@@ -38,7 +38,7 @@ def get_minimizers(sequence, k, window_size):
     if sequence.encoding.alphabet_size != 4:             # any AlphabetEncoding (minimizers.py:48-52): the generic hashes
         return _get_minimizers_generic(sequence, k, window_size)
     values, out_off, lens, n_rows, n_out, single = _rolling(
-        sequence, window_size, lambda ops, p, i, o, n, m, t: ops.minimizers(p, i, o, n, m, k, window_size))
+        sequence, window_size, k, lambda ops, p, i, o, n, m, t: ops.minimizers(p, i, o, n, m, k, window_size))
     encoding = KmerEncoding(sequence.encoding, k)
     if single:
         return EncodedArray(values, encoding)

@@ -260,10 +260,12 @@ int bnpk_packed_rows_slice(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_ba
  * d_codes (1 byte/base, the reference layout) and d_packed (2 bits/base, 32 bases per uint64,
  * base i at bits 2*(i%32) of word i/32 == npstructures BitArray.pack(.., bit_stride=2),
  * bionumpy/sequence/kmers.py:121) are both optional; d_packed needs total/32 + 2 words.
- * buf_size: bytes of d_buf (the kernel reads up to 31 bytes either side of a row, never outside [0, buf_size)). */
+ * buf_size: bytes of d_buf (the kernel reads up to 31 bytes either side of a row, never outside [0, buf_size)).
+ * d_row_ends (optional, total/64 + 2 words): bit i set on the last base of every non-empty row — what bnpk_row_end_mask
+ * would compute from d_offsets afterwards with one atomic per row; here the lanes know it as they go. */
 int bnpk_gather_encode_dna(bnpk_ctx* ctx, const uint8_t* d_buf, int64_t buf_size, const int64_t* d_starts,
                            const int64_t* d_offsets, int64_t n_rows, int64_t total,
-                           uint8_t* d_codes, uint64_t* d_packed, int64_t* d_err_offset,
+                           uint8_t* d_codes, uint64_t* d_packed, uint64_t* d_row_ends, int64_t* d_err_offset,
                            void* stream);
 /* A7 for any alphabet: d_out[i] = h_lut256[d_in[i]] — `self._lookup[byte_array]` of AlphabetEncoding._encode
  * (bionumpy/encodings/alphabet_encoding.py:19-46; the table maps both cases of every letter to its code and

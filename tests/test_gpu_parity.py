@@ -66,8 +66,11 @@ def _random_reads(seed, n_rows, max_len, with_empty=True):
 def test_gather_encode_and_kmers(ops, seed, n_rows, max_len):
     text, starts, lengths = _random_reads(seed, n_rows, max_len)
     offsets, total = ops.row_offsets(_h(lengths), 1)
-    codes, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=True,
-                                          want_packed=True)
+    codes, packed, ends = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=True,
+                                                want_packed=True, want_ends=True)
+    end_bits = np.zeros((total // 64 + 2) * 64, dtype=np.uint8)
+    end_bits[np.cumsum(lengths)[lengths > 0] - 1] = 1            # the last base of every non-empty row
+    assert np.array_equal(np.unpackbits(ends.host().view(np.uint8), bitorder="little"), end_bits)
     expect = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
     assert np.array_equal(codes.host(), expect)
     words = oracle.pack_2bit(expect)
@@ -115,10 +118,14 @@ def test_gather_encode_rows_between_other_text(ops, seed, n_rows, lo, hi, shuffl
     offsets, total = ops.row_offsets(_h(lengths), 1)
     expect = oracle.encode_dna(oracle.gather_rows(text, starts, lengths))
     words = oracle.pack_2bit(expect)
+    end_bits = np.zeros((total // 64 + 2) * 64, dtype=np.uint8)
+    end_bits[np.cumsum(lengths)[lengths > 0] - 1] = 1
     for want_codes in (False, True):
-        codes, packed = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=want_codes)
+        codes, packed, ends = ops.gather_encode_dna(_h(text), _h(starts), offsets, n_rows, total, want_codes=want_codes,
+                                                    want_ends=True)
         assert np.array_equal(packed.host().view(np.uint64)[:words.size], words)
         assert packed.host()[words.size:].max(initial=0) == 0
+        assert np.array_equal(np.unpackbits(ends.host().view(np.uint8), bitorder="little"), end_bits)   # == bnpk_row_end_mask
         if want_codes:
             assert np.array_equal(codes.host(), expect)
     off = offsets.host()
