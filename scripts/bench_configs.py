@@ -177,4 +177,27 @@ out["stream_file_to_histogram"] = {"reads": n_file, "file_bytes": os.path.getsiz
                                    "seconds": round(dt, 3), "gbases_per_s": round(n_file * 150 / dt / 1e9, 3),
                                    "distinct": len(c), "file_gb_per_s": round(os.path.getsize(path) / dt / 1e9, 2)}
 os.remove(path)
+
+# ---- the API-path kernels against the HBM peak: algorithmic bytes (what the kernel has to read and write once) per launch ----
+F, NL, NB, NR = 316 * reads, 4 * reads, 150 * reads, reads          # file bytes, lines, bases, reads of the synthetic FASTQ
+c3, mt, pw = out["config3_minimizers"]["kernels_ms"], out["match_string_packed"]["kernels_ms"], out["pwm_scores_12"]["kernels_ms"]
+flt, rw = out["quality_filter_compaction"], out["reverse_complement_rewrite_fastq"]
+n_min = out["config3_minimizers"]["n_minimizers"]
+table = {
+    "byte_census": (c3["byte_census"], F),
+    "line_positions": (c3["line_positions"], F + 8 * NL),
+    "field_table": (c3["field_table"], 16 * NR + 16 * NR),
+    "gather_encode_dna": (c3["gather_encode_dna"], NB + NB // 4 + NB // 8 + 16 * NR),
+    "kmer_starts_from_ends": (c3["kmer_starts_from_ends"], 2 * (NB // 8)),
+    "minimizers_flat": (c3["minimizers_flat"], 8 * n_min + NB // 4 + NB // 8),
+    "match_windows_packed": (mt["match_windows_packed"], NB // 4 + NB // 8 + (NB - 6 * NR)),
+    "pwm_scores": (pw["pwm_scores"], NB // 4 + NB // 8 + 8 * (NB - 11 * NR)),
+    "reverse_complement_packed": (out["reverse_complement_packed"]["kernel_ms"], 2 * (NB // 4) + 8 * NR),
+    "reverse_complement_bytes": (rw["kernels_ms"]["reverse_complement_bytes"], 2 * NB + 8 * NR),
+    "gather_rows (kept entries)": (flt["kernels_ms"]["gather_rows"], 2 * flt["bytes_out"] + 16 * flt["kept"]),
+    "row_reduce_u8": (flt["kernels_ms"]["row_reduce_u8"], NB + 16 * NR),
+    "join_lines": (rw["kernels_ms"]["join_lines"], 2 * rw["bytes_out"]),
+}
+out["api_kernels"] = {name: {"ms": ms, "algorithmic_gb": round(b / 1e9, 2), "gb_per_s": round(b / (ms * 1e-3) / 1e9, 1),
+                             "frac_of_8_tb_per_s": round(b / (ms * 1e-3) / 8e12, 3)} for name, (ms, b) in table.items() if ms}
 print(json.dumps(out))
