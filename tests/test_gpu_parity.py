@@ -395,12 +395,16 @@ def test_row_reductions(ops, seed, n_rows, max_len):
     lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
     lens[rng.integers(0, n_rows, size=max(1, n_rows // 8))] = 0
     total = int(lens.sum())
-    data = rng.integers(0, 94, size=total).astype(np.uint8)
+    data = rng.integers(0, 94 if seed % 2 else 256, size=total).astype(np.uint8)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     got = ops.row_reduce_u8(_h(data if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, want=("sum", "min", "max"))
     es, emn, emx = oracle.row_reduce(data, lens)
     assert np.array_equal(got["sum"].host(), es)
     assert np.array_equal(got["min"].host(), emn) and np.array_equal(got["max"].host(), emx)
+    if total:                                                   # the same rows inside a larger buffer, at an odd address
+        shifted = HArray(dev=_h(np.concatenate([np.full(3, 200, np.uint8), data, np.full(9, 201, np.uint8)])).dev()[3:3 + total])
+        again = ops.row_reduce_u8(shifted, _h(offsets), n_rows, want=("sum", "min", "max"))
+        assert all(np.array_equal(again[w].host(), got[w].host()) for w in ("sum", "min", "max"))
     # per-column sums / counts (axis=0): rows longer than the LDS table take the global-atomic path
     cs, cc = oracle.col_sums(data, lens)
     gs, gc = ops.col_sums_u8(_h(data if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, total, cs.size)
