@@ -72,21 +72,29 @@ __device__ __forceinline__ uint32_t ascii_complement(uint32_t b) {
   return b == 'A' ? 'T' : b == 'T' ? 'A' : b == 'C' ? 'G' : b == 'G' ? 'C' : b == 'N' ? 'N' : 0u;
 }
 
-// the same table on eight bytes at once: A (0x41) <-> T (0x54) differ by 0x15, C (0x43) <-> G (0x47) by 0x04, N stays;
-// a byte that is none of the five becomes 0.  Exact SWAR byte tests (no carries between bytes).
-__device__ __forceinline__ uint64_t swar_eq(uint64_t x, unsigned c) {          // 0xff in every byte of x that equals c
-  const uint64_t y = x ^ (0x0101010101010101ull * c);
-  const uint64_t t = ~(((y & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | y | 0x7f7f7f7f7f7f7f7full);   // 0x80 where y == 0
-  return (t >> 7) * 0xffull;
-}
-__device__ __forceinline__ uint64_t ascii_complement8(uint64_t x) {
-  const uint64_t at = swar_eq(x, 'A') | swar_eq(x, 'T'), cg = swar_eq(x, 'C') | swar_eq(x, 'G'), n = swar_eq(x, 'N');
-  return (x ^ (at & 0x1515151515151515ull) ^ (cg & 0x0404040404040404ull)) & (at | cg | n);
+// The table on four bytes in a few instructions: the letters A C G T N differ in their low three bits (1 3 7 4 6), so
+// V_PERM_B32 with the selector x & 7 looks both the letter that OUGHT to stand there and its complement up in 8-byte
+// tables; a byte that is not the letter its low bits promise becomes 0 (rare: fixed up behind a branch).  The SWAR form
+// this replaces — five exact byte compares with a 64-bit multiply each — was ~110 instructions per eight bytes, run twice
+// per wavefront (lanes inside a row, lanes over a row boundary): what bounded the kernel, 6.2 ms per 50 M reads.
+__device__ __forceinline__ uint32_t ascii_complement4(uint32_t x) {
+  const uint32_t idx = x & 0x07070707u;
+  const uint32_t expect = __builtin_amdgcn_perm(0x474E0054u, 0x43004100u, idx);     // . A . C | T . N G
+  uint32_t c = __builtin_amdgcn_perm(0x434E0041u, 0x47005400u, idx);                // . T . G | A . N C
+  const uint32_t z = expect ^ x;
+  if (z) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((z >> (8 * j)) & 0xffu) c &= ~(0xffu << (8 * j));
+  }
+  return c;
 }
 
-// 16 output bytes per lane.  A lane whose bytes all lie in one row (19 in 20 for reads of 150 bases) takes them with ONE
-// unaligned 16-byte load — the row read backwards is a contiguous run — reverses them with two byte swaps and complements
-// eight bytes at a time; the others walk their rows byte by byte as before.
+// 16 output bytes per lane, every lane the same way: out[p0 + i] = complement(in[s + e - 1 - p0 - i]) while the row lasts,
+// i.e. the 16 bytes that END at in[s + k - 1] (k = e - p0 bytes of the row left), reversed.  A lane with k < 16 — one in
+// ten for reads of 150 bases — loads the 16 bytes that end k bytes BEHIND the next row's end as well, reverses them too
+// and takes byte i from the first for i < k: one select per dword, then ONE complement for everybody.  Lanes over rows
+// shorter than that, or whose loads would leave the buffer, walk byte by byte as before.
 __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __restrict__ in,
                                                               const int64_t* __restrict__ off, int64_t n_rows,
                                                               int64_t total, const int64_t* __restrict__ tile_rows,
@@ -118,42 +126,47 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
   }
   const int64_t p1 = min(p0 + RC_BYTES_PER_LANE, total);
   int64_t s = staged ? srow[r - lo] : off[r], e = staged ? srow[r - lo + 1] : off[r + 1];
-  uint64_t word[2] = {0, 0};                                  // the lane's sixteen output bytes, stored once
-  if (p0 + RC_BYTES_PER_LANE <= e) {                          // (then p1 == p0 + 16 too)
-    uint64_t a[2];
-    __builtin_memcpy(a, in + (s + e - RC_BYTES_PER_LANE - p0), 16);
-    word[0] = ascii_complement8(__builtin_bswap64(a[1]));
-    word[1] = ascii_complement8(__builtin_bswap64(a[0]));
-  } else {
-    // ONE row boundary inside the chunk, k bytes before it, both rows at least 16 bytes long (every boundary chunk of
-    // 150-base reads): the first 16 bytes of this row and the last 16 of the next one, two independent loads, reversed
-    // and shifted together — instead of sixteen dependent single-byte loads that the other lanes of the wavefront wait for
-    const int64_t k = e - p0;
-    const int64_t e2 = (r + 2 <= n_rows && p1 - p0 == RC_BYTES_PER_LANE) ? ((staged && r + 2 <= hi + 1) ? srow[r + 2 - lo] : off[r + 2]) : e;
-    if (k > 0 && e - s >= RC_BYTES_PER_LANE && e2 - e >= RC_BYTES_PER_LANE) {
-      uint64_t a[2], b[2];
-      __builtin_memcpy(a, in + s, 16);
-      __builtin_memcpy(b, in + e2 - RC_BYTES_PER_LANE, 16);
-      const uint64_t ra[2] = {__builtin_bswap64(a[1]), __builtin_bswap64(a[0])};      // the 16 bytes reversed
-      const uint64_t rb[2] = {__builtin_bswap64(b[1]), __builtin_bswap64(b[0])};
-      const int sr = 8 * (int)(RC_BYTES_PER_LANE - k), sl = 8 * (int)k;                // out = (RA >> 8 (16 - k)) | (RB << 8 k)
-      uint64_t lo = sr >= 64 ? (ra[1] >> (sr - 64)) : ((ra[0] >> sr) | (ra[1] << (64 - sr)));
-      uint64_t hi = sr >= 64 ? 0ull : (ra[1] >> sr);
-      lo |= sl >= 64 ? 0ull : (rb[0] << sl);
-      hi |= sl >= 64 ? (rb[0] << (sl - 64)) : ((rb[1] << sl) | (rb[0] >> (64 - sl)));
-      word[0] = ascii_complement8(lo);
-      word[1] = ascii_complement8(hi);
+  uint32_t w[4] = {0, 0, 0, 0};                               // the lane's sixteen output bytes, stored once
+  const int64_t k = e - p0;                                   // bytes of row r from p0 on (>= 1)
+  const int64_t from = s + k - RC_BYTES_PER_LANE;             // the 16 bytes that end with the row's byte for p0
+  bool done = false;
+  if (p1 - p0 == RC_BYTES_PER_LANE && from >= 0) {
+    uint32_t a[4];
+    if (k >= RC_BYTES_PER_LANE) {
+      __builtin_memcpy(a, in + from, 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_perm(0u, a[3 - q], 0x00010203u);       // the 16 bytes reversed
+      done = true;
     } else {
-      for (int64_t p = p0; p < p1; ++p) {
-        while (e <= p) { ++r; s = e; e = off[r + 1]; }
-        word[(p - p0) >> 3] |= (uint64_t)ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 7));
+      const int64_t e2 = r + 2 <= n_rows ? ((staged && r + 2 <= hi + 1) ? srow[r + 2 - lo] : off[r + 2]) : e;
+      if (e2 - e >= RC_BYTES_PER_LANE - k && e2 + k <= total) {        // one boundary: the rest of the chunk lies in row r + 1
+        uint32_t b[4];
+        __builtin_memcpy(a, in + from, 16);
+        __builtin_memcpy(b, in + (e2 + k - RC_BYTES_PER_LANE), 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t ra = __builtin_amdgcn_perm(0u, a[3 - q], 0x00010203u), rb = __builtin_amdgcn_perm(0u, b[3 - q], 0x00010203u);
+          const int nb = min(max((int)k - 4 * q, 0), 4);      // bytes of this dword that come from row r
+          const uint32_t m = nb == 4 ? ~0u : (1u << (8 * nb)) - 1u;
+          w[q] = (ra & m) | (rb & ~m);
+        }
+        done = true;
       }
     }
   }
-  if (p1 - p0 == RC_BYTES_PER_LANE) {                         // (p0 is a multiple of 16, the buffer 16-byte aligned)
-    *reinterpret_cast<uint4*>(out + p0) = make_uint4((uint32_t)word[0], (uint32_t)(word[0] >> 32), (uint32_t)word[1], (uint32_t)(word[1] >> 32));
+  if (done) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = ascii_complement4(w[q]);
   } else {
-    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(word[j >> 3] >> (8 * (j & 7)));
+    for (int64_t p = p0; p < p1; ++p) {
+      while (e <= p) { ++r; s = e; e = off[r + 1]; }
+      w[(p - p0) >> 2] |= ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 3));
+    }
+  }
+  if (p1 - p0 == RC_BYTES_PER_LANE) {                         // (p0 is a multiple of 16, the buffer 16-byte aligned)
+    *reinterpret_cast<uint4*>(out + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    for (int j = 0; j < (int)(p1 - p0); ++j) out[p0 + j] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
   }
 }
 

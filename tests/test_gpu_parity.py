@@ -381,6 +381,11 @@ def test_reverse_complement_kernels(ops, seed, n_rows, max_len):
     text = np.frombuffer(b"ACGTNacgtX", dtype=np.uint8)[rng.integers(0, 10, size=total)]
     got = ops.reverse_complement_bytes(_h(text), _h(offsets), n_rows, total).host()
     assert np.array_equal(got, oracle.reverse_complement(text, lens, ascii_bytes=True))
+    # any byte at all between the letters (the kernel looks a byte up by its low three bits: 0x49, 0x00, 0xC1 ... must not pass for A;
+    # the reference's table has 128 entries)
+    noisy = np.where(rng.random(total) < 0.1, rng.integers(0, 128, size=total), np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=total)]).astype(np.uint8)
+    got = ops.reverse_complement_bytes(_h(noisy), _h(offsets), n_rows, total).host()
+    assert np.array_equal(got, oracle.reverse_complement(noisy, lens, ascii_bytes=True))
     for k in (1, 5, 16, 31):
         h = rng.integers(0, 1 << (2 * k), size=1000, dtype=np.int64)
         assert np.array_equal(ops.canonical_kmers(_h(h.copy()), k).host(), oracle.canonical_kmers(h, k))
