@@ -104,6 +104,7 @@ SIGNATURES = {
     "bnpk_join_lines": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _u8, _p, _i64, _p, _p]),
     "bnpk_col_sums_u8": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "bnpk_row_reduce_u8": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
+    "bnpk_row_reduce_u8_view": (_int, [_p, _p, _i64, _p, _p, _i64, _int, _p, _p, _p, _p]),
     "bnpk_row_reduce_wide": (_int, [_p, _p, _int, _p, _i64, _p, _p, _p, _p]),
     "bnpk_vec_ratio_rows": (_int, [_p, _p, _p, _i64, _p, _p]),
     "bnpk_vec_compare": (_int, [_p, _p, _i64, _int, _int, C.c_double, _i64, _p, _p]),

@@ -19,8 +19,17 @@ constexpr int RR_ROWS_PER_BLOCK = BNPK_BLOCK / RR_GROUP, RR8_ROWS_PER_BLOCK = BN
 // text may cost before it, not HBM, sets the pace: 3.3 ms for the 7.5 GB of quality values of 50 M reads.)
 typedef unsigned short rr_u16x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_u8_kernel(const uint8_t* __restrict__ data,
-                                                                   const int64_t* __restrict__ off, int64_t n_rows,
+// starts: the rows need not lie back to back — row r is data[starts[r] .. + off[r + 1] - off[r]) (a field of a text chunk
+// that nobody gathered); subtract: a constant taken off every byte first, with the wrap-around of uint8 arithmetic (the
+// offset of a DigitEncoding: bionumpy/encodings/__init__.py:15-16).
+__device__ __forceinline__ uint64_t rr_subtract(uint64_t x, uint64_t sub) {   // per-byte wrap-around subtraction, no borrows
+  constexpr uint64_t H = 0x8080808080808080ull;
+  return ((x | H) - (sub & ~H)) ^ ((x ^ ~sub) & H);
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_u8_kernel(const uint8_t* __restrict__ data, int64_t data_size,
+                                                                   const int64_t* __restrict__ starts,
+                                                                   const int64_t* __restrict__ off, int64_t n_rows, int subtract,
                                                                    int64_t* __restrict__ sums, uint8_t* __restrict__ mins,
                                                                    uint8_t* __restrict__ maxs) {
   const int g = threadIdx.x & (RR8_GROUP - 1);
@@ -29,10 +38,11 @@ __global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_u8_kernel(const uint8_t
   // (a buffer that does not start on a 16-byte boundary — a view into a larger one — is indexed from the boundary in front of it)
   const int64_t skew = (int64_t)(reinterpret_cast<uintptr_t>(data) & 15);
   data -= skew;
-  const int64_t total = off[n_rows] + skew;
+  const int64_t total = (data_size >= 0 ? data_size : off[n_rows]) + skew;
   const bool extremes = mins != nullptr || maxs != nullptr;              // (uniform)
+  const uint64_t sub = (uint64_t)(subtract & 0xff) * 0x0101010101010101ull;
   for (; row < n_rows; row += stride) {                                  // (the lanes of a group stay together)
-    const int64_t s = off[row] + skew, e = off[row + 1] + skew;
+    const int64_t s = (starts ? starts[row] : off[row]) + skew, e = s + (off[row + 1] - off[row]);
     unsigned long long sum = 0;
     unsigned mn0 = 0x00ff00ffu, mn1 = 0x00ff00ffu, mx0 = 0u, mx1 = 0u;   // even / odd bytes as 16-bit fields
     for (int64_t b0 = ((s >> 4) + g) << 4; b0 < e; b0 += 16 * RR8_GROUP) {
@@ -45,6 +55,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void row_reduce_u8_kernel(const uint8_t
         v[0] = v[1] = 0;
         for (int j = 0; b0 + j < total; ++j) v[j >> 3] |= (uint64_t)data[b0 + j] << (8 * (j & 7));
       }
+      if (subtract) { v[0] = rr_subtract(v[0], sub); v[1] = rr_subtract(v[1], sub); }      // (uniform)
       const bool inside = b0 >= s && b0 + 16 <= e;                       // all sixteen bytes belong to the row
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -150,16 +161,23 @@ int bnpk_row_reduce_wide(bnpk_ctx* ctx, const void* d_data, int is_f64, const in
   return BNPK_OK;
 }
 
-int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t* d_sums,
-                       uint8_t* d_mins, uint8_t* d_maxs, void* stream) {
-  if (!ctx || n_rows < 0 || (n_rows > 0 && !d_offsets)) return BNPK_ERR_ARG;
+int bnpk_row_reduce_u8_view(bnpk_ctx* ctx, const uint8_t* d_data, int64_t data_size, const int64_t* d_starts,
+                            const int64_t* d_offsets, int64_t n_rows, int subtract, int64_t* d_sums, uint8_t* d_mins,
+                            uint8_t* d_maxs, void* stream) {
+  if (!ctx || n_rows < 0 || (n_rows > 0 && !d_offsets) || subtract < 0 || subtract > 255) return BNPK_ERR_ARG;
+  if (d_starts && data_size < 0) return BNPK_ERR_ARG;
   if (n_rows == 0 || (!d_sums && !d_mins && !d_maxs)) return BNPK_OK;
   hipStream_t s = (hipStream_t)stream;
   bnpk_timer t(ctx, "row_reduce_u8", s);
   hipLaunchKernelGGL(row_reduce_u8_kernel, dim3(grid_for(ceil_div(n_rows, RR8_ROWS_PER_BLOCK))), dim3(BNPK_BLOCK), 0, s,
-                     d_data, d_offsets, n_rows, d_sums, d_mins, d_maxs);
+                     d_data, data_size, d_starts, d_offsets, n_rows, subtract, d_sums, d_mins, d_maxs);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
+}
+
+int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows, int64_t* d_sums,
+                       uint8_t* d_mins, uint8_t* d_maxs, void* stream) {
+  return bnpk_row_reduce_u8_view(ctx, d_data, -1, nullptr, d_offsets, n_rows, 0, d_sums, d_mins, d_maxs, stream);
 }
 
 }  // extern "C"

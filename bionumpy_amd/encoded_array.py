@@ -153,6 +153,14 @@ class DigitEncodingFactory(NumericEncoding):
     def _encode_gather(self, data, starts, offsets, n_rows, total):
         return get_ops().gather_rows(data, starts, offsets, n_rows, total, self._min_code)
 
+    def _encode_ragged(self, ragged):
+        if not ragged.is_compact() and hasattr(get_ops(), "row_reduce_u8_view"):
+            # a column of a text chunk: left where it lies until somebody needs the values (ragged.py: _DeferredRows)
+            from .ragged import _DeferredRows
+            return _DeferredRows._defer(ragged._flat_data(), ragged._starts, ragged._lens, ragged._offsets, ragged._n_rows,
+                                        ragged._total, self._min_code)
+        return super()._encode_ragged(ragged)
+
     def __repr__(self):
         return "DigitEncoding(min_code=%d)" % self._min_code
 

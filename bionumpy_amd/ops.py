@@ -462,6 +462,16 @@ class HipOps:
                                          ptr(outs["min"]), ptr(outs["max"]), self._s()))
         return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
 
+    def row_reduce_u8_view(self, data, starts, offsets, n_rows, subtract, want=("sum",)):
+        """row_reduce_u8 over rows data[starts[r] .. + offsets[r+1] - offsets[r]) with ``subtract`` taken off every byte (uint8
+        wrap-around) — the reductions of a column nobody gathered (bnpk_row_reduce_u8_view)"""
+        outs = {"sum": self._empty(n_rows, np.int64) if "sum" in want else None,
+                "min": self._empty(n_rows, np.uint8) if "min" in want else None,
+                "max": self._empty(n_rows, np.uint8) if "max" in want else None}
+        self._chk(lib.bnpk_row_reduce_u8_view(self.ctx, ptr(data.dev()), data.size, ptr(starts.dev()), ptr(offsets.dev()), n_rows,
+                                              subtract, ptr(outs["sum"]), ptr(outs["min"]), ptr(outs["max"]), self._s()))
+        return {k: HArray(dev=v) for k, v in outs.items() if v is not None}
+
     def row_reduce_wide(self, data, offsets, n_rows, want=("sum",)):
         """{name: HArray} for name in want ⊆ {sum, min, max} over ragged int64 / float64 rows (bnpk_row_reduce_wide)"""
         dtype = np.dtype(data.dtype)

@@ -362,6 +362,47 @@ class RaggedArray:
                 and np.array_equal(np.asarray(self.ravel()), np.asarray(other.ravel())))
 
 
+class _DeferredRows(RaggedArray):
+    """uint8 rows of another buffer minus a constant, not gathered yet: a column of a text chunk under a DigitEncoding
+    (``chunk.quality``: io/file_buffers.py:426-440 + encodings/__init__.py:15-16,26).  Per-row sums / means / minima / maxima
+    are taken straight from the text (``bnpk_row_reduce_u8_view``) — ``np.mean(chunk.quality, axis=1) > 30`` of a read filter
+    (scripts/small_example.py:36-46) never needs the 7.5 GB copy per 50 M reads that gathering the column costs.  Anything else
+    that looks at the values gathers them first, transparently: ``_data`` is a property."""
+
+    @classmethod
+    def _defer(cls, base, starts, lens, offsets, n_rows, total, subtract):
+        obj = cls.__new__(cls)
+        obj._pending = (base, starts, int(subtract))
+        obj._real = None
+        obj._init(None, None, lens, offsets, n_rows, total)
+        return obj
+
+    @property
+    def _data(self):
+        if self._pending is not None:
+            base, starts, subtract = self._pending
+            self._real = get_ops().gather_rows(base, starts, self.offsets(), self._n_rows, self.total(), subtract)
+            self._pending = None
+        return self._real
+
+    @_data.setter
+    def _data(self, value):
+        self._real = value
+        if value is not None:
+            self._pending = None
+
+    @property
+    def dtype(self):
+        return np.dtype(np.uint8)
+
+    def _row_reduce(self, what, as_float=False):
+        if self._pending is None:
+            return RaggedArray._row_reduce(self, what, as_float)
+        base, starts, subtract = self._pending
+        from .device_vector import DeviceVector
+        return DeviceVector(get_ops().row_reduce_u8_view(base, starts, self.offsets(), self._n_rows, subtract, want=(what,))[what])
+
+
 class RaggedShape:
     """row layout of a RaggedArray: (starts | None, lens, offsets | None, n_rows, total)"""
 

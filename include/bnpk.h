@@ -306,6 +306,14 @@ int bnpk_kmers(bnpk_ctx* ctx, const uint64_t* d_packed, const int64_t* d_in_offs
  * sum 0, min 255, max 0 (the caller raises, as numpy does for a reduction without identity). */
 int bnpk_row_reduce_u8(bnpk_ctx* ctx, const uint8_t* d_data, const int64_t* d_offsets, int64_t n_rows,
                        int64_t* d_sums, uint8_t* d_mins, uint8_t* d_maxs, void* stream);
+/* the same over rows that were never gathered: row r = d_data[d_starts[r] .. + d_offsets[r+1] - d_offsets[r]) (d_starts NULL:
+ * back to back, as above; data_size: bytes of d_data, needed with d_starts), every byte minus `subtract` (0..255, uint8
+ * wrap-around) first — np.mean(chunk.quality, axis=1) straight from the text of the chunk: the quality column is a view of it
+ * with 33 subtracted (bionumpy/encodings/__init__.py:15-16,26; io/file_buffers.py:426-440), and a reduction does not need
+ * the 7.5 GB copy per 50 M reads that materialising it costs. */
+int bnpk_row_reduce_u8_view(bnpk_ctx* ctx, const uint8_t* d_data, int64_t data_size, const int64_t* d_starts,
+                            const int64_t* d_offsets, int64_t n_rows, int subtract, int64_t* d_sums, uint8_t* d_mins,
+                            uint8_t* d_maxs, void* stream);
 
 /* the same for 8-byte elements — int64 (k-mer hashes: Minimizers.__call__ is kmer_hashes.raw().min(axis=-1),
  * bionumpy/sequence/minimizers.py:15-17) or float64 (is_f64: motif scores): sums / mins / maxs of the element type, any of

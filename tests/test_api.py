@@ -776,6 +776,36 @@ def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     assert sparse["CGGTAGCCAGCTGCGTTCAGTATGGAAGATT"] >= 1
 
 
+def test_quality_reductions_before_and_after_the_column_is_gathered(bnp):
+    """np.sum / mean / min / max(chunk.quality, axis=1) straight from the chunk's text ([hip]: ragged.py _DeferredRows — the
+    column is only gathered when somebody looks at the values) == the same on the gathered column == numpy on the bytes minus
+    33, uint8 wrap-around included (a quality byte below '!' is not valid FASTQ, but it is what uint8 arithmetic gives)"""
+    rng = np.random.default_rng(5)
+    n = 700
+    lens = rng.integers(1, 130, size=n)
+    quals = [bytes(rng.integers(34, 127, size=l).astype(np.uint8)) for l in lens]
+    quals[3] = b" " + quals[3][1:]                               # a byte below '!': (32 - 33) mod 256 = 255
+    quals[4] = b"\x22" * len(quals[4])
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"A" * l, q) for i, (l, q) in enumerate(zip(lens, quals)))
+    expect = [(np.frombuffer(q, dtype=np.uint8) - np.uint8(33)) for q in quals]
+
+    def check(q):
+        assert np.array_equal(np.asarray(np.sum(q, axis=1)), [int(e.astype(np.int64).sum()) for e in expect])
+        assert np.array_equal(np.asarray(np.min(q, axis=1)), [e.min() for e in expect])
+        assert np.array_equal(np.asarray(np.max(q, axis=-1)), [e.max() for e in expect])
+        assert np.allclose(np.asarray(np.mean(q, axis=1)), [e.astype(np.int64).sum() / e.size for e in expect], rtol=0, atol=0)
+
+    chunk = _reader(bnp, text, bnp.FastQBuffer).read()
+    q = chunk.quality
+    check(q)                                                     # nothing has looked at the values yet
+    assert q[3].tolist() == expect[3].tolist() and q.dtype == np.uint8
+    assert [r.tolist() for r in q[10:13]] == [e.tolist() for e in expect[10:13]]
+    check(q)                                                     # ... and now the column has been gathered
+    assert q.tolist() == [e.tolist() for e in expect]
+    keep = np.mean(chunk.quality, axis=1) > 40
+    assert [r.tolist() for r in chunk[keep].quality] == [e.tolist() for e in expect if e.astype(np.int64).sum() / e.size > 40]
+
+
 def test_filtering_rows(bnp, big_fq_gz):
     # scripts/small_example.py:26-32 style: boolean row mask on a chunk
     chunk = bnp.open(big_fq_gz).read()
