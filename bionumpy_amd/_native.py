@@ -101,7 +101,7 @@ SIGNATURES = {
     "bnpk_lut_bytes": (_int, [_p, _p, _i64, _p, _p, _p, _p]),
     "bnpk_kmer_start_mask": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_row_end_mask": (_int, [_p, _p, _i64, _i64, _p, _p]),
-    "bnpk_join_lines": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _u8, _p, _i64, _p, _p]),
+    "bnpk_join_lines": (_int, [_p, _i64, _int, _p, _p, _p, _p, _p, _p, _p, _u8, _p, _i64, _p, _p]),
     "bnpk_col_sums_u8": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p, _p]),
     "bnpk_row_reduce_u8": (_int, [_p, _p, _p, _i64, _p, _p, _p, _p]),
     "bnpk_row_reduce_u8_view": (_int, [_p, _p, _i64, _p, _p, _i64, _int, _p, _p, _p, _p]),
@@ -115,6 +115,7 @@ SIGNATURES = {
     "bnpk_join_line_lens": (_int, [_p, _i64, _int, _p, _p, _p, _p]),
     "bnpk_reverse_complement_packed": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_reverse_complement_bytes": (_int, [_p, _p, _p, _i64, _i64, _p, _p]),
+    "bnpk_reverse_complement_rows": (_int, [_p, _p, _i64, _p, _p, _i64, _i64, _p, _p]),
     "bnpk_canonical_kmers": (_int, [_p, _p, _i64, _int, _p]),
     "bnpk_windows_flat": (_int, [_p, _p, _p, _i64, _int, _int, _i64, _p, _p]),
     "bnpk_match_windows_packed": (_int, [_p, _p, _p, _i64, _int, C.c_uint64, _i64, _p, _p]),

@@ -95,7 +95,10 @@ __device__ __forceinline__ uint32_t ascii_complement4(uint32_t x) {
 // ten for reads of 150 bases — loads the 16 bytes that end k bytes BEHIND the next row's end as well, reverses them too
 // and takes byte i from the first for i < k: one select per dword, then ONE complement for everybody.  Lanes over rows
 // shorter than that, or whose loads would leave the buffer, walk byte by byte as before.
-__global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __restrict__ in,
+// in_starts (optional): the input rows were never gathered — row r lies at in[in_starts[r] ..), in a buffer of in_size bytes;
+// the output is compact either way (off).
+__global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __restrict__ in, int64_t in_size,
+                                                              const int64_t* __restrict__ in_starts,
                                                               const int64_t* __restrict__ off, int64_t n_rows,
                                                               int64_t total, const int64_t* __restrict__ tile_rows,
                                                               int64_t n_tiles, uint8_t* __restrict__ out) {
@@ -104,14 +107,21 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
   // lane in front of the first byte of data.  Tiles of many tiny rows keep the search over global memory.
   constexpr int RC_LDS_ROWS = 254;
   __shared__ int64_t srow[RC_LDS_ROWS + 2];
+  __shared__ int64_t sstart[RC_LDS_ROWS + 2];
   const int64_t p0 = ((int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x) * RC_BYTES_PER_LANE;
   int64_t lo, hi;
   tile_row_range(tile_rows, blockIdx.x, n_tiles, n_rows, lo, hi);
   const bool staged = hi - lo + 2 <= RC_LDS_ROWS + 2;          // (uniform) offsets lo .. hi + 1
   if (staged) {
-    if ((int64_t)threadIdx.x <= hi - lo + 1) srow[threadIdx.x] = off[lo + threadIdx.x];
+    if ((int64_t)threadIdx.x <= hi - lo + 1) {
+      srow[threadIdx.x] = off[lo + threadIdx.x];
+      if (in_starts && lo + threadIdx.x < n_rows) sstart[threadIdx.x] = in_starts[lo + threadIdx.x];
+    }
     __syncthreads();
   }
+  auto row_in = [&](int64_t row, int64_t row_off) {            // where row `row` (output offset row_off) begins in `in`
+    return !in_starts ? row_off : (staged && row <= hi + 1) ? sstart[row - lo] : in_starts[row];
+  };
   if (p0 >= total) return;
   int64_t r;
   if (staged) {
@@ -128,9 +138,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
   int64_t s = staged ? srow[r - lo] : off[r], e = staged ? srow[r - lo + 1] : off[r + 1];
   uint32_t w[4] = {0, 0, 0, 0};                               // the lane's sixteen output bytes, stored once
   const int64_t k = e - p0;                                   // bytes of row r from p0 on (>= 1)
-  const int64_t from = s + k - RC_BYTES_PER_LANE;             // the 16 bytes that end with the row's byte for p0
+  int64_t is = row_in(r, s);                                  // (== s for back-to-back rows)
+  const int64_t from = is + k - RC_BYTES_PER_LANE;            // the 16 bytes that end with the row's byte for p0
   bool done = false;
-  if (p1 - p0 == RC_BYTES_PER_LANE && from >= 0) {
+  if (p1 - p0 == RC_BYTES_PER_LANE && from >= 0 && from + RC_BYTES_PER_LANE <= in_size) {
     uint32_t a[4];
     if (k >= RC_BYTES_PER_LANE) {
       __builtin_memcpy(a, in + from, 16);
@@ -139,10 +150,11 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
       done = true;
     } else {
       const int64_t e2 = r + 2 <= n_rows ? ((staged && r + 2 <= hi + 1) ? srow[r + 2 - lo] : off[r + 2]) : e;
-      if (e2 - e >= RC_BYTES_PER_LANE - k && e2 + k <= total) {        // one boundary: the rest of the chunk lies in row r + 1
+      const int64_t ie2 = e2 > e ? row_in(r + 1, e) + (e2 - e) : 0;     // where row r + 1 ends in `in`
+      if (e2 - e >= RC_BYTES_PER_LANE - k && ie2 + k <= in_size && ie2 + k >= RC_BYTES_PER_LANE) {   // one boundary: the rest lies in row r + 1
         uint32_t b[4];
         __builtin_memcpy(a, in + from, 16);
-        __builtin_memcpy(b, in + (e2 + k - RC_BYTES_PER_LANE), 16);
+        __builtin_memcpy(b, in + (ie2 + k - RC_BYTES_PER_LANE), 16);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t ra = __builtin_amdgcn_perm(0u, a[3 - q], 0x00010203u), rb = __builtin_amdgcn_perm(0u, b[3 - q], 0x00010203u);
@@ -159,8 +171,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_bytes_kernel(const uint8_t* __r
     for (int q = 0; q < 4; ++q) w[q] = ascii_complement4(w[q]);
   } else {
     for (int64_t p = p0; p < p1; ++p) {
-      while (e <= p) { ++r; s = e; e = off[r + 1]; }
-      w[(p - p0) >> 2] |= ascii_complement(in[s + e - 1 - p]) << (8 * (int)((p - p0) & 3));
+      while (e <= p) { ++r; s = e; e = off[r + 1]; is = in_starts ? in_starts[r] : s; }
+      w[(p - p0) >> 2] |= ascii_complement(in[is + (e - 1 - p)]) << (8 * (int)((p - p0) & 3));
     }
   }
   if (p1 - p0 == RC_BYTES_PER_LANE) {                         // (p0 is a multiple of 16, the buffer 16-byte aligned)
@@ -205,7 +217,13 @@ int bnpk_reverse_complement_packed(bnpk_ctx* ctx, const uint64_t* d_packed, cons
 
 int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets, int64_t n_rows,
                                   int64_t total, uint8_t* d_out, void* stream) {
-  if (!ctx || n_rows < 0 || total < 0 || !d_offsets || (total > 0 && (!d_bytes || !d_out)) || (total > 0 && d_out == d_bytes))
+  return bnpk_reverse_complement_rows(ctx, d_bytes, total, nullptr, d_offsets, n_rows, total, d_out, stream);
+}
+
+int bnpk_reverse_complement_rows(bnpk_ctx* ctx, const uint8_t* d_bytes, int64_t in_size, const int64_t* d_in_starts,
+                                 const int64_t* d_offsets, int64_t n_rows, int64_t total, uint8_t* d_out, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || in_size < 0 || !d_offsets || (total > 0 && (!d_bytes || !d_out)) ||
+      (total > 0 && d_out == d_bytes))
     return BNPK_ERR_ARG;
   if (total == 0 || n_rows == 0) return BNPK_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -215,8 +233,8 @@ int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const i
   BNPK_CHECK(bnpk_scratch(ctx, tile_rows_bytes(n_tiles), &table, (hipStream_t)stream));
   bnpk_timer t(ctx, "reverse_complement_bytes", s);
   BNPK_CHECK(build_tile_rows(ctx, d_offsets, n_rows, RC_TILE_BYTES, (int64_t*)table, s));
-  hipLaunchKernelGGL(rc_bytes_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_bytes, d_offsets, n_rows, total,
-                     (const int64_t*)table, n_tiles, d_out);
+  hipLaunchKernelGGL(rc_bytes_kernel, dim3((unsigned)n_tiles), dim3(BNPK_BLOCK), 0, s, d_bytes, in_size, d_in_starts, d_offsets,
+                     n_rows, total, (const int64_t*)table, n_tiles, d_out);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -361,6 +361,8 @@ constexpr int64_t JL_TILE = 16384;                      // output bytes a workgr
 struct jl_line {
   const uint8_t* data;         // flat bytes of the field (nullptr: a one-byte constant line)
   const int64_t* off;          // its row offsets
+  const int64_t* starts;       // nullptr: row r lies at off[r]; else at starts[r] (a view of a larger buffer, never gathered)
+  int64_t size;                // bytes of `data` (what a 16-byte read must stay inside)
   int add;                     // added to every byte of the field
   int prefix;                  // header bytes in front of the field (0 or 1)
   uint8_t fill;                // the constant byte of a line without a field
@@ -411,7 +413,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int64_t field_end[JL_MAX_LINES];                             // sixteen bytes can be read at `at` iff at + 16 <= field_end
 #pragma unroll
-  for (int l = 0; l < JL_MAX_LINES; ++l) field_end[l] = (l < n_lines && lines.l[l].data) ? lines.l[l].off[n_rows] : 0;
+  for (int l = 0; l < JL_MAX_LINES; ++l)
+    field_end[l] = (l < n_lines && lines.l[l].data) ? (lines.l[l].starts ? lines.l[l].size : lines.l[l].off[n_rows]) : 0;
   const unsigned tile_base = (unsigned)(size_t)tile;           // (LDS addresses are 32-bit)
   auto put = [&](int64_t q, uint8_t v) { if (q >= 0 && q < tile_n) tile[q] = v; };
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -433,8 +436,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
         if (!L.data) {
           put(o, L.fill);
         } else {
-          const int64_t fs = L.off[r];
-          flen = L.off[r + 1] - fs;
+          const int64_t fs = L.starts ? L.starts[r] : L.off[r];
+          flen = L.off[r + 1] - L.off[r];
           // the 16-byte words of the field that overlap the tile
           const int64_t w_lo = o < 0 ? (-o) >> 4 : 0;
           const int64_t w_hi = min((flen + 15) >> 4, ((int64_t)tile_n - o + 15) >> 4);
@@ -596,7 +599,8 @@ __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, 
 }  // namespace
 
 extern "C" int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const uint8_t* const* d_field_data,
-                               const int64_t* const* d_field_offsets, const int* add, const int* prefix,
+                               const int64_t* const* d_field_offsets, const int64_t* const* d_field_starts,
+                               const int64_t* field_sizes, const int* add, const int* prefix,
                                const uint8_t* fill, uint8_t header, const int64_t* d_entry_offsets, int64_t total,
                                uint8_t* d_out, void* stream) {
   if (!ctx || n_rows < 0 || n_lines < 1 || n_lines > JL_MAX_LINES || total < 0 || !d_field_data || !d_field_offsets || !add ||
@@ -609,7 +613,9 @@ extern "C" int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const
   for (int i = 0; i < n_lines; ++i) {
     if (d_field_data[i] && !d_field_offsets[i]) return BNPK_ERR_ARG;
     if (prefix[i] < 0 || prefix[i] > 1) return BNPK_ERR_ARG;
-    lines.l[i] = jl_line{d_field_data[i], d_field_offsets[i], add[i], prefix[i], fill[i]};
+    const int64_t* starts = d_field_starts ? d_field_starts[i] : nullptr;
+    if (starts && (!field_sizes || field_sizes[i] < 0)) return BNPK_ERR_ARG;
+    lines.l[i] = jl_line{d_field_data[i], d_field_offsets[i], starts, starts ? field_sizes[i] : 0, add[i], prefix[i], fill[i]};
   }
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_tiles = ceil_div(total, JL_TILE);

@@ -218,6 +218,10 @@ class OneLineBuffer(FileBuffer):
         """(flat ASCII bytes, offsets) of a field: names / ASCII sequences as they are, encoded DNA decoded"""
         if not isinstance(column, EncodedRaggedArray):
             column = as_encoded_array(column)
+        if column.encoding == BaseEncoding and not column.is_compact():
+            # a column of the chunk's own text (the names of a chunk whose sequences were replaced): joined from where it
+            # lies, not gathered first (bnpk_join_lines: d_field_starts)
+            return column._flat_data(), column.offsets(), 0, column._starts
         column._compact()
         if column.encoding == BaseEncoding:
             return column._flat_data(), column.offsets(), 0
@@ -239,8 +243,8 @@ class OneLineBuffer(FileBuffer):
             if col is None:
                 lines.append((None, None, 0, cls._line_offsets[i], ord("+")))
             else:
-                data, off, add = col
-                lines.append((data, off, add, cls._line_offsets[i], 0))
+                data, off, add = col[:3]
+                lines.append((data, off, add, cls._line_offsets[i], 0) + tuple(col[3:4]))
         return get_ops().join_lines(len(entries), lines, ord(cls.HEADER))
 
     def entry_bytes(self):
@@ -290,9 +294,14 @@ class FastQBuffer(OneLineBuffer):
     @classmethod
     def _columns(cls, entries):
         quality = entries.quality
-        quality._compact()
-        return [cls._text_column(entries.name), cls._text_column(entries.sequence), None,
-                (quality._data, quality.offsets(), 33)]
+        pending = getattr(quality, "_pending", None)
+        if pending is not None:                              # the quality line of the chunk's own text, never gathered: as it lies
+            base, starts, subtract = pending
+            qcol = (base, quality.offsets(), (33 - subtract) & 0xff, starts)
+        else:
+            quality._compact()
+            qcol = (quality._data, quality.offsets(), 33)
+        return [cls._text_column(entries.name), cls._text_column(entries.sequence), None, qcol]
 
 
 class MultiLineFastaBuffer(FileBuffer):

@@ -436,9 +436,14 @@ class HipOps:
 
     # -- join_fields: record text from fields ------------------------------------------------------
     def join_lines(self, n_rows, lines, header):
-        """lines: per line (data HArray | None, offsets HArray | None, add, prefix, fill byte).  Returns the text
-        (HArray uint8) of all entries: every line = prefix header bytes + field row (+ add) + newline."""
+        """lines: per line (data HArray | None, offsets HArray | None, add, prefix, fill byte[, starts HArray | None: the rows
+        lie at data[starts[r]], not back to back]).  Returns the text (HArray uint8) of all entries: every line = prefix header
+        bytes + field row (+ add) + newline."""
         n = len(lines)
+        view_starts = [(l[5] if len(l) > 5 else None) for l in lines]
+        lines = [l[:5] for l in lines]
+        starts = (C.c_void_p * n)(*[ptr(v.dev()) if v is not None else None for v in view_starts])
+        sizes = (C.c_int64 * n)(*[(d.size if (d is not None and v is not None) else 0) for (d, _, _, _, _), v in zip(lines, view_starts)])
         offs = (C.c_void_p * n)(*[ptr(o.dev()) if o is not None else None for _, o, _, _, _ in lines])
         prefixes = (C.c_int * n)(*[int(p) for _, _, _, p, _ in lines])
         lens = self._empty(n_rows, np.int64)
@@ -448,8 +453,8 @@ class HipOps:
         datas = (C.c_void_p * n)(*[ptr(d.dev()) if d is not None else None for d, _, _, _, _ in lines])
         adds = (C.c_int * n)(*[int(a) for _, _, a, _, _ in lines])
         fills = (C.c_uint8 * n)(*[int(f) for _, _, _, _, f in lines])
-        self._chk(lib.bnpk_join_lines(self.ctx, n_rows, n, datas, offs, adds, prefixes, fills, header, ptr(entry_off.dev()),
-                                      total, ptr(out), self._s()))
+        self._chk(lib.bnpk_join_lines(self.ctx, n_rows, n, datas, offs, starts, sizes, adds, prefixes, fills, header,
+                                      ptr(entry_off.dev()), total, ptr(out), self._s()))
         return HArray(dev=out)
 
     # -- per-row reductions of ragged uint8 data --------------------------------------------------
@@ -547,6 +552,14 @@ class HipOps:
         out = self._empty(total, np.uint8)
         self._chk(lib.bnpk_reverse_complement_bytes(self.ctx, ptr(flat.dev()), ptr(offsets.dev()), n_rows, total,
                                                     ptr(out), self._s()))
+        return HArray(dev=out)
+
+    def reverse_complement_rows(self, buf, starts, offsets, n_rows, total):
+        """reverse_complement_bytes over rows buf[starts[r] .. + offsets[r+1] - offsets[r]) that nobody gathered
+        (bnpk_reverse_complement_rows); the result is compact"""
+        out = self._empty(total, np.uint8)
+        self._chk(lib.bnpk_reverse_complement_rows(self.ctx, ptr(buf.dev()), buf.size, ptr(starts.dev()), ptr(offsets.dev()), n_rows,
+                                                   total, ptr(out), self._s()))
         return HArray(dev=out)
 
     def canonical_kmers(self, hashes, k):

@@ -55,8 +55,14 @@ def get_reverse_complement(sequence):
     """Reverse complement of one or more DNA sequences (sequence/dna.py:47-65)."""
     sequence = as_encoded_array(sequence)
     kind = _check_encoding(sequence.encoding)
-    ragged, single = _as_rows(sequence)
     ops = get_ops()
+    if kind == "ascii" and isinstance(sequence, EncodedRaggedArray) and not sequence.is_compact() and \
+            hasattr(ops, "reverse_complement_rows"):
+        # a column of a text chunk (chunk.sequence): reversed and complemented from where it lies, not gathered first
+        n_rows, total, offsets = len(sequence), sequence.total(), sequence.offsets()
+        out = ops.reverse_complement_rows(sequence._flat_data(), sequence._starts, offsets, n_rows, total)
+        return EncodedRaggedArray._from_parts(out, None, sequence._lens, offsets, n_rows, total, sequence.encoding)
+    ragged, single = _as_rows(sequence)
     n_rows, total, offsets = len(ragged), ragged.total(), ragged.offsets()
     if kind == "dna":
         out = _PackedDna(ops.reverse_complement_packed(packed_words(ragged._data), offsets, n_rows, total), total)

@@ -389,10 +389,15 @@ int bnpk_multiline_wrap(bnpk_ctx* ctx, const uint8_t* d_names, const int64_t* d_
  * entry r is its n_lines <= 4 lines; line i = prefix[i] (0 or 1) bytes `header`, row r of field i
  * (d_field_data[i] / d_field_offsets[i], every byte + add[i]: quality scores are written as score + 33), '\n'.
  * d_field_data[i] == NULL: the line is the constant byte fill[i] ('+').  d_entry_offsets (n_rows+1) = exclusive scan
- * of the entry lengths, total = its last entry.  The pointer arrays live on the host. */
+ * of the entry lengths, total = its last entry.  The pointer arrays live on the host.
+ * d_field_starts (may be NULL; entries may be NULL): field i was never gathered — its row r lies at
+ * d_field_data[i] + d_field_starts[i][r] (a column of the chunk's own text: the name and quality lines of a chunk whose
+ * sequence was replaced), its length is still d_field_offsets[i][r+1] - d_field_offsets[i][r]; field_sizes[i] = bytes of
+ * d_field_data[i] then. */
 int bnpk_join_lines(bnpk_ctx* ctx, int64_t n_rows, int n_lines, const uint8_t* const* d_field_data,
-                    const int64_t* const* d_field_offsets, const int* add, const int* prefix, const uint8_t* fill,
-                    uint8_t header, const int64_t* d_entry_offsets, int64_t total, uint8_t* d_out, void* stream);
+                    const int64_t* const* d_field_offsets, const int64_t* const* d_field_starts, const int64_t* field_sizes,
+                    const int* add, const int* prefix, const uint8_t* fill, uint8_t header,
+                    const int64_t* d_entry_offsets, int64_t total, uint8_t* d_out, void* stream);
 
 /* ---- reverse complement -----------------------------------------------------------
  * replaces get_reverse_complement = complement(sequence)[..., ::-1] (bionumpy/sequence/dna.py:36-65): every row
@@ -406,6 +411,11 @@ int bnpk_reverse_complement_packed(bnpk_ctx* ctx, const uint64_t* d_packed, cons
                                    int64_t n_rows, int64_t total, uint64_t* d_out, void* stream);
 int bnpk_reverse_complement_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const int64_t* d_offsets,
                                   int64_t n_rows, int64_t total, uint8_t* d_out, void* stream);
+/* _bytes over rows that were never gathered: row r is d_bytes[d_in_starts[r] .. + d_offsets[r+1] - d_offsets[r]) of a buffer
+ * of in_size bytes (the sequence column of a text chunk: get_reverse_complement(chunk.sequence)); d_in_starts NULL = _bytes.
+ * The output is compact (d_offsets). */
+int bnpk_reverse_complement_rows(bnpk_ctx* ctx, const uint8_t* d_bytes, int64_t in_size, const int64_t* d_in_starts,
+                                 const int64_t* d_offsets, int64_t n_rows, int64_t total, uint8_t* d_out, void* stream);
 
 /* In place h[i] = min(h[i], rc(h[i])), rc(h) = the hash (layout of bnpk_kmers, first base least significant) of the
  * reverse complement of the k-mer with hash h: strand-independent ("canonical") k-mers.  Not in the reference;

@@ -214,12 +214,16 @@ class OracleOps:
 
     def join_lines(self, n_rows, lines, header):
         fields = []
-        for data, off, add, prefix, fill in lines:
+        for line in lines:
+            data, off, add, prefix, fill = line[:5]
+            starts = line[5] if len(line) > 5 else None          # rows that lie at data[starts[r]], not back to back
             if data is None:
                 fields.append((np.full(n_rows, fill, dtype=np.uint8), np.ones(n_rows, dtype=np.int64)))
             else:
-                fields.append(((data.host()[:int(off.host()[-1])].astype(np.int64) + add).astype(np.uint8), np.diff(off.host())))
-        return _h(oracle.join_fields(fields, header, [p for _, _, _, p, _ in lines]))
+                lens = np.diff(off.host())
+                flat = data.host()[:int(off.host()[-1])] if starts is None else oracle.gather_rows(data.host(), starts.host(), lens)
+                fields.append(((flat.astype(np.int64) + add).astype(np.uint8), lens))
+        return _h(oracle.join_fields(fields, header, [line[3] for line in lines]))
 
     def col_sums_u8(self, data, offsets, n_rows, total, n_cols):
         sums, counts = oracle.col_sums(data.host()[:total], np.diff(offsets.host()))

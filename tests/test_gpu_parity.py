@@ -386,6 +386,16 @@ def test_reverse_complement_kernels(ops, seed, n_rows, max_len):
     noisy = np.where(rng.random(total) < 0.1, rng.integers(0, 128, size=total), np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=total)]).astype(np.uint8)
     got = ops.reverse_complement_bytes(_h(noisy), _h(offsets), n_rows, total).host()
     assert np.array_equal(got, oracle.reverse_complement(noisy, lens, ascii_bytes=True))
+    # the same rows where they lie in a larger text (other bytes between them, any order): bnpk_reverse_complement_rows
+    gaps = rng.integers(0, 7, size=n_rows)
+    starts = np.concatenate([[0], np.cumsum(lens[:-1] + gaps[:-1])]).astype(np.int64)
+    buf = rng.integers(33, 127, size=int(starts[-1] + lens[-1] + (0 if seed % 2 else 5))).astype(np.uint8)
+    for st, ln, row in zip(starts, lens, np.split(noisy, offsets[1:-1])):
+        buf[st:st + ln] = row
+    order = rng.permutation(n_rows)
+    off2 = np.concatenate([[0], np.cumsum(lens[order])]).astype(np.int64)
+    got = ops.reverse_complement_rows(_h(buf), _h(starts[order]), _h(off2), n_rows, total).host()
+    assert np.array_equal(got, oracle.reverse_complement(oracle.gather_rows(buf, starts[order], lens[order]), lens[order], ascii_bytes=True))
     for k in (1, 5, 16, 31):
         h = rng.integers(0, 1 << (2 * k), size=1000, dtype=np.int64)
         assert np.array_equal(ops.canonical_kmers(_h(h.copy()), k).host(), oracle.canonical_kmers(h, k))
