@@ -12,7 +12,8 @@
 
 namespace {
 
-constexpr int RC_TILE_WORDS = BNPK_BLOCK;            // one output word (32 bases) per lane
+constexpr int RCP_WPL = 4;                           // output words (32 bases each) per lane of rc_packed
+constexpr int RC_TILE_WORDS = BNPK_BLOCK * RCP_WPL;
 constexpr int64_t RC_TILE_BASES = (int64_t)RC_TILE_WORDS * 32;
 constexpr int RC_BYTES_PER_LANE = 16;
 constexpr int64_t RC_TILE_BYTES = (int64_t)BNPK_BLOCK * RC_BYTES_PER_LANE;
@@ -39,32 +40,63 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
                                                                const int64_t* __restrict__ off, int64_t n_rows,
                                                                int64_t total, const int64_t* __restrict__ tile_rows,
                                                                int64_t n_tiles, uint64_t* __restrict__ out) {
-  const int64_t w = (int64_t)blockIdx.x * RC_TILE_WORDS + threadIdx.x;
-  const int64_t p0 = w * 32;
-  if (p0 >= total) {
-    if (p0 < total + 64) out[w] = 0;                         // the pad words of the packed layout
+  constexpr int RCP_LDS_ROWS = 1022;
+  __shared__ int64_t srow[RCP_LDS_ROWS + 2];
+  const int64_t w0 = (int64_t)blockIdx.x * RC_TILE_WORDS;
+  if (w0 * 32 >= total) {                                    // (uniform) a tile of pad words only
+    for (int64_t w = w0 + threadIdx.x; w < w0 + RC_TILE_WORDS; w += BNPK_BLOCK)
+      if (w * 32 < total + 64) out[w] = 0;                   // the pad words of the packed layout
     return;
   }
   // (the table has an entry for every tile that starts inside the data; the pad words form tiles of their own)
   const int64_t lo = tile_rows[blockIdx.x];
   const int64_t hi = ((int64_t)(blockIdx.x + 1) * RC_TILE_BASES < total) ? tile_rows[blockIdx.x + 1] : n_rows - 1;
-  int64_t r = row_of(off, lo, hi, p0);
-  const int64_t p1 = min(p0 + 32, total);
-  uint64_t word = 0;
-  int64_t p = p0;
-  while (p < p1) {
-    int64_t s = off[r], e = off[r + 1];
-    while (e <= p) { ++r; s = e; e = off[r + 1]; }           // empty rows, and the step to the next row
-    const int64_t stop = min(e, p1);
-    const int n = (int)(stop - p);
-    // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
-    const uint64_t src = packed_run(in, s + e - stop, n);
-    const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
-    const uint64_t bits = n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
-    word |= bits << (2 * (int)(p - p0));
-    p = stop;
+  // The offsets of the tile's rows (~220 reads of 150 bases) come into LDS with coalesced loads; a lane finds its rows and
+  // the ends of the rows it crosses there, for its four words.  Searched in global memory and one word per lane, as this
+  // kernel did, a lane sat through a chain of eight dependent loads before its first packed word: 3.4 ms per 50 M reads
+  // for 3.8 GB of traffic.
+  const bool staged = hi - lo + 2 <= RCP_LDS_ROWS + 2;        // (uniform) offsets lo .. hi + 1
+  if (staged) {
+    for (int64_t i = threadIdx.x; i <= hi - lo + 1; i += BNPK_BLOCK) srow[i] = off[lo + i];
+    __syncthreads();
   }
-  out[w] = word;
+  auto offset_of = [&](int64_t row) { return (staged && row <= hi + 1) ? srow[row - lo] : off[row]; };
+#pragma unroll
+  for (int it = 0; it < RCP_WPL; ++it) {
+    const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
+    const int64_t p0 = w * 32;
+    if (p0 >= total) {
+      if (p0 < total + 64) out[w] = 0;                       // the pad words behind the last tile's data
+      continue;
+    }
+    int64_t r;
+    if (staged) {
+      int a = 0, b = (int)(hi - lo);
+      while (a < b) {
+        const int mid = a + ((b - a + 1) >> 1);
+        if (srow[mid] <= p0) a = mid; else b = mid - 1;
+      }
+      r = lo + a;
+    } else {
+      r = row_of(off, lo, hi, p0);
+    }
+    const int64_t p1 = min(p0 + 32, total);
+    uint64_t word = 0;
+    int64_t p = p0;
+    while (p < p1) {
+      int64_t s = offset_of(r), e = offset_of(r + 1);
+      while (e <= p) { ++r; s = e; e = offset_of(r + 1); }   // empty rows, and the step to the next row
+      const int64_t stop = min(e, p1);
+      const int n = (int)(stop - p);
+      // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
+      const uint64_t src = packed_run(in, s + e - stop, n);
+      const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
+      const uint64_t bits = n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
+      word |= bits << (2 * (int)(p - p0));
+      p = stop;
+    }
+    out[w] = word;
+  }
 }
 
 // complement table of the reference (bionumpy/sequence/dna.py:10,29-33), as a function
