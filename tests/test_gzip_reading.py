@@ -52,6 +52,17 @@ def read_in_pieces(f, sizes):
     return b"".join(got)
 
 
+@pytest.fixture(params=["libdeflate", "zlib"], autouse=True)
+def inflater(request, monkeypatch):
+    """every test runs with both inflaters of the BGZF members: the system's libdeflate (where there is one) and zlib"""
+    if request.param == "libdeflate":
+        if gz._libdeflate is None:
+            pytest.skip("no libdeflate.so.0 on this host")
+    else:
+        monkeypatch.setattr(gz, "_libdeflate", None)
+    return request.param
+
+
 @pytest.mark.parametrize("n_reads", [0, 1, 3000, 40000])
 def test_bgzf_reader_hands_out_what_gzip_does(tmp_path, n_reads):
     data = fastq_text(n_reads) if n_reads else b""
@@ -95,6 +106,17 @@ def test_damaged_bgzf_member_is_an_error_not_wrong_text(tmp_path):
             f.read()
     with pytest.raises(OSError):
         gzip.open(path, "rb").read()                                 # (the standard library agrees)
+    # the text length in the trailer is wrong / the deflate stream itself is damaged
+    for spoil in ("isize", "stream"):
+        blob = bytearray(bgzf_compress(data))
+        if spoil == "isize":
+            blob[size - 4] ^= 0x01
+        else:
+            blob[size // 2] ^= 0xFF
+        open(path, "wb").write(bytes(blob))
+        with pytest.raises((OSError, zlib.error)):
+            with gz.open_gzip_for_reading(path) as f:
+                f.read()
 
 
 @pytest.mark.parametrize("members", [1, 3])
