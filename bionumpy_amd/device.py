@@ -174,6 +174,12 @@ class HArray:
             self._np = None
 
 
+class SharedSlice(HArray):
+    """a part of a device array that others hold parts of too: whoever wants to write into it makes a copy first"""
+
+    __slots__ = ()
+
+
 class LazyHArray(HArray):
     """An int64 HArray of a known size whose elements are only produced (by ``make() -> HArray``) when somebody reads them: the
     row offsets of a result nobody may ever index by row (a chunk's k-mers that go straight into a histogram)."""

@@ -289,6 +289,28 @@ class _PackedDna:
         return self._unpacked().dev()
 
 
+class _LazyPackedDna(_PackedDna):
+    """packed DNA whose words are only produced (``make() -> HArray``) when somebody reads them: the rows a chunk takes out
+    of its batch's encoded column (io/buffers.py: BatchShare) — the k-mers of the chunk are a slice of the batch's and never
+    look at the chunk's own words"""
+
+    def __init__(self, make, n):
+        self._make = make
+        _PackedDna.__init__(self, None, n)
+
+    @property
+    def packed(self):
+        if self._make is not None:
+            self._words, self._make = self._make(), None
+        return self._words
+
+    @packed.setter
+    def packed(self, value):
+        self._words = value
+        if value is not None:
+            self._make = None
+
+
 def packed_words(flat):
     """packed 2-bit words (HArray int64) of a flat DNA code buffer, packing it on the device if needed"""
     if isinstance(flat, _PackedDna):

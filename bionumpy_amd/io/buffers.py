@@ -103,29 +103,61 @@ class BatchShare:
         whole, base_at = state
         if j0 not in base_at or j1 not in base_at:
             return None
-        from ..encoded_array import _PackedDna, packed_words
+        from ..encoded_array import _LazyPackedDna, packed_words
+        from ..device import LazyHArray
         b0, b1 = base_at[j0], base_at[j1]
-        packed, offsets = get_ops().packed_rows_slice(packed_words(whole._data), whole.total(), whole.offsets(), j0, j1 - j0, b0, b1 - b0)
+        made = []                                            # (packed words, offsets) of the rows: ONE small kernel, on first use
+
+        def part(i):
+            if not made:
+                made.extend(get_ops().packed_rows_slice(packed_words(whole._data), whole.total(), whole.offsets(), j0, j1 - j0,
+                                                        b0, b1 - b0))
+            return made[i]
         lens = HArray(dev=whole._lens.dev()[j0:j1])
-        rows = EncodedRaggedArray._from_parts(_PackedDna(packed, b1 - b0), None, lens, offsets, j1 - j0, b1 - b0, encoding)
-        rows._trim_source = (self, line, j0, j1)            # (sequence/kmers.py:_rolling asks trimmed() below)
+        rows = EncodedRaggedArray._from_parts(_LazyPackedDna(lambda: part(0), b1 - b0), None, lens,
+                                              LazyHArray(j1 - j0 + 1, lambda: part(1)), j1 - j0, b1 - b0, encoding)
+        rows._trim_source = (self, line, j0, j1)            # (sequence/kmers.py:_rolling asks windows() below)
         return rows
+
+    def _window_table(self, line, window):
+        """(trimmed row offsets of the whole field, their values at the cut rows) for windows of ``window`` letters"""
+        key = (line, window)
+        table = self._fields.get(key)
+        if table is None:
+            ops = get_ops()
+            off, _ = ops.row_offsets(self._fields[line][0]._lens, window)
+            at = ops.read_i64(off, self.cut_rows)
+            table = self._fields[key] = (off, dict(zip(self.cut_rows.tolist(), at.tolist())))
+        return table
 
     def trimmed(self, line, window, j0, j1):
         """(n_out, offsets) of rows [j0, j1) of the encoded field after the trim to windows of ``window`` letters (kmers.py:100):
         the number of windows comes from ONE table per (field, window) over the whole batch, read at the cut rows once — a
         chunk's get_kmers then needs no answer from the device; its row offsets are only computed if somebody asks."""
-        whole = self._fields[line][0]
-        key = (line, window)
-        table = self._fields.get(key)
-        if table is None:
-            ops = get_ops()
-            off, _ = ops.row_offsets(whole._lens, window)
-            at = ops.read_i64(off, self.cut_rows)
-            table = self._fields[key] = (off, dict(zip(self.cut_rows.tolist(), at.tolist())))
-        off, at = table
+        off, at = self._window_table(line, window)
         from ..device import LazyHArray
         return at[j1] - at[j0], LazyHArray(j1 - j0 + 1, lambda: HArray(dev=off.dev()[j0:j1 + 1] - off.dev()[j0]))
+
+    def windows(self, line, k, window, j0, j1):
+        """the k-mer hashes (window == k) / minimizers of rows [j0, j1) as a PART of the same values of the whole batch,
+        computed once per (field, k, window): the rows of a chunk are a contiguous run of the batch's and the values are in
+        row order, so a chunk's get_kmers launches nothing.  None where the position-flat generator does not reach."""
+        key = ("values", line, k, window)
+        values = self._fields.get(key)
+        if values is None:
+            from ..encoded_array import packed_words
+            whole = self._fields[line][0]
+            counted = get_ops().windows_counted(packed_words(whole._data), whole.offsets(), len(whole), k, window, whole.total(),
+                                                getattr(whole, "_row_ends", None))
+            values = self._fields[key] = False if counted is None else counted[0]
+        if values is False:
+            return None
+        _, at = self._window_table(line, window)
+        from ..device import SharedSlice
+        part = values.dev()[at[j0]:at[j1]]
+        if part.data_ptr() & 15:                             # (kernels with 16-byte loads want their input aligned: an odd start is copied)
+            return HArray(dev=part.clone())
+        return SharedSlice(dev=part)
 
 
 class OneLineBuffer(FileBuffer):

@@ -32,8 +32,14 @@ def _rolling(sequence, window, k, kernel):
     single = isinstance(sequence, EncodedArray)
     source = None if single else getattr(sequence, "_trim_source", None)
     row_ends = None if single else getattr(sequence, "_row_ends", None)
+    if source is not None and hasattr(ops, "windows_counted"):
+        # rows of a reader's batch (io/buffers.py: BatchShare): their values are a part of the batch's, computed once
+        shared = source[0].windows(source[1], k, window, source[2], source[3])
+        if shared is not None:
+            n_out, out_off = source[0].trimmed(source[1], window, source[2], source[3])
+            return shared, out_off, sequence._lens, len(sequence), n_out, single
     packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
-    if source is not None and window >= 1:                   # rows of a reader's batch (io/buffers.py: BatchShare.trimmed)
+    if source is not None and window >= 1:                   # (... or at least their number is known: BatchShare.trimmed)
         n_out, out_off = source[0].trimmed(source[1], window, source[2], source[3])
     elif hasattr(ops, "windows_counted") and ops.windows_counted is not None:
         # the number of windows comes back with the start mask; the trimmed row offsets are only scanned if somebody asks
@@ -118,6 +124,9 @@ def get_kmers(sequence, k, canonical=False):
     hashes, out_off, lens, n_rows, n_out, single = _rolling(
         sequence, k, k, lambda ops, p, i, o, n, m, t: ops.kmers(p, i, o, n, m, k, total=t))
     if canonical and n_out:
+        from ..device import SharedSlice, HArray
+        if isinstance(hashes, SharedSlice):                  # (canonical_kmers overwrites its argument)
+            hashes = HArray(dev=hashes.dev().clone())
         hashes = get_ops().canonical_kmers(hashes, k)
     encoding = KmerEncoding(sequence.encoding, k)
     if single:
