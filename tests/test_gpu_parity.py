@@ -416,6 +416,19 @@ def test_row_reductions(ops, seed, n_rows, max_len):
     es, emn, emx = oracle.row_reduce(data, lens)
     assert np.array_equal(got["sum"].host(), es)
     assert np.array_equal(got["min"].host(), emn) and np.array_equal(got["max"].host(), emx)
+    if total:                                                   # the same rows where they lie in a larger buffer, a constant subtracted
+        gaps = rng.integers(0, 6, size=n_rows)
+        order = rng.permutation(n_rows)
+        starts = np.zeros(n_rows, dtype=np.int64)
+        starts[order] = np.concatenate([[0], np.cumsum((lens + gaps)[order])[:-1]])
+        buf = rng.integers(0, 256, size=int((lens + gaps).sum()) + (0 if seed % 2 else 2)).astype(np.uint8)
+        for st, ln, row in zip(starts, lens, np.split(data, np.cumsum(lens)[:-1])):
+            buf[st:st + ln] = row
+        for sub in (0, 33, 200):
+            view = ops.row_reduce_u8_view(_h(buf), _h(starts), _h(offsets), n_rows, sub, want=("sum", "min", "max"))
+            ws, wmn, wmx = oracle.row_reduce((data.astype(np.int64) - sub).astype(np.uint8), lens)
+            assert np.array_equal(view["sum"].host(), ws)
+            assert np.array_equal(view["min"].host(), wmn) and np.array_equal(view["max"].host(), wmx)
     if total:                                                   # the same rows inside a larger buffer, at an odd address
         shifted = HArray(dev=_h(np.concatenate([np.full(3, 200, np.uint8), data, np.full(9, 201, np.uint8)])).dev()[3:3 + total])
         again = ops.row_reduce_u8(shifted, _h(offsets), n_rows, want=("sum", "min", "max"))
@@ -494,6 +507,22 @@ def test_join_lines(ops, seed, n_rows, max_len):
     plus = (np.full(n_rows, ord("+"), dtype=np.uint8), np.ones(n_rows, dtype=np.int64))
     expect = oracle.join_fields([name, seq, plus, ((qual[0] + 33).astype(np.uint8), qual[1])], ord("@"), (1, 0, 0, 0))
     assert np.array_equal(got, expect)
+    # the same fields as rows of larger buffers that nobody gathered (other bytes between the rows, any order): row starts
+    def scattered(f):
+        flat, lens = f
+        gaps = rng.integers(0, 9, size=n_rows)
+        order = rng.permutation(n_rows)
+        starts = np.zeros(n_rows, dtype=np.int64)
+        starts[order] = np.concatenate([[0], np.cumsum((lens + gaps)[order])[:-1]])
+        buf = rng.integers(0, 256, size=int((lens + gaps).sum()) + (0 if seed % 2 else 3)).astype(np.uint8)
+        for st, ln, row in zip(starts, lens, np.split(flat, np.cumsum(lens)[:-1])):
+            buf[st:st + ln] = row
+        return _h(buf if buf.size else np.zeros(4, np.uint8)), _h(starts)
+    (nb, ns), (qb, qs) = scattered(name), scattered(qual)
+    lines = [(nd, no, 0, 1, 0, None), (sd, so, 0, 0, 0), (None, None, 0, 0, ord("+")), (qb, qo, 33, 0, 0, qs)]
+    assert np.array_equal(ops.join_lines(n_rows, lines, ord("@")).host(), expect)
+    lines = [(nb, no, 0, 1, 0, ns), (sd, so, 0, 0, 0), (None, None, 0, 0, ord("+")), (qd, qo, 33, 0, 0)]
+    assert np.array_equal(ops.join_lines(n_rows, lines, ord("@")).host(), expect)
 
 
 @pytest.fixture(params=[1, 0], ids=["fast-encoder", "general-encoder"])
