@@ -8,15 +8,16 @@ reached through the C-ABI in include/bnpk.h; there is no CPU fallback.
 from . import _native  # noqa: F401  (fails loudly if libbnpk.so is missing)
 from .encoded_array import (EncodedArray, EncodedRaggedArray, as_encoded_array, change_encoding, BaseEncoding,
                             DNAEncoding, ACGTEncoding, AlphabetEncoding, QualityEncoding, ACTGEncoding, ACTGnEncoding,
-                            ACGTnEncoding, DigitEncoding, ACUGEncoding, RNAENcoding, AminoAcidEncoding, BamEncoding)
-from .ragged import RaggedArray
+                            ACGTnEncoding, DigitEncoding, ACUGEncoding, RNAENcoding, AminoAcidEncoding, BamEncoding,
+                            OneToOneEncoding)
+from .ragged import RaggedArray, RaggedShape
 from .exceptions import FormatException, EncodingError
 from . import encodings, io, sequence, streams
 from .encodings import KmerEncoding
 from .io import bnp_open, count_entries, FastQBuffer, TwoLineFastaBuffer, MultiLineFastaBuffer
 from .sequence.debruin import DeBruijnGraph, ColoredDeBruijnGraph
 from .sequence import (match_string, get_motif_scores, get_reverse_complement, get_kmers, count_kmers, get_minimizers, count_encoded, EncodedCounts, SparseKmerCounts,
-                       KmerIndex, KmerLookup)
+                       KmerIndex, KmerLookup, KmerEncoder, Minimizers, PositionWeightMatrix, PWM)
 from .streams import streamable
 from .memory_mapping import MemMapEncodedRaggedArray
 from .datatypes import SequenceEntry, SequenceEntryWithQuality, replace

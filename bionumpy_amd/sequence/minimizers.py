@@ -44,3 +44,26 @@ def get_minimizers(sequence, k, window_size):
         return EncodedArray(values, encoding)
     return EncodedRaggedArray._from_parts(values, None, _trimmed_lens(out_off, lens, window_size), out_off, n_rows,
                                           n_out, encoding)
+
+
+class Minimizers:
+    """Minimizers (sequence/minimizers.py:8-17): the rollable form — ``Minimizers(n_kmers, KmerEncoder(k, encoding))`` is the
+    minimum over windows of n_kmers consecutive k-mers; ``rolling_window`` gives what ``get_minimizers(sequence, k,
+    n_kmers + k - 1)`` gives, a call the minimizer of ONE window of window_size letters (tests/test_minimizers.py:43-46)."""
+
+    def __init__(self, n_kmers, kmer_encoding):
+        self._n_kmers = n_kmers
+        self._kmer_encoding = kmer_encoding
+        self.window_size = n_kmers + kmer_encoding.window_size - 1
+        self._encoding = kmer_encoding._encoding
+
+    def rolling_window(self, sequence):
+        from ..encoded_array import as_encoded_array
+        return get_minimizers(as_encoded_array(sequence, self._encoding), self._kmer_encoding.window_size, self.window_size)
+
+    def __call__(self, sequence):
+        from ..encoded_array import as_encoded_array
+        sequence = as_encoded_array(sequence, self._encoding)
+        assert sequence.size == self.window_size, (sequence.size, self.window_size)
+        return self.rolling_window(sequence)
+

@@ -95,3 +95,20 @@ def get_motif_scores(sequence, pwm):
         return values
     new_lens = np.maximum(ragged.lengths - (pwm.window_size - 1), 0)
     return RaggedArray(values, new_lens)
+
+
+class PositionWeightMatrix:
+    """PositionWeightMatrix (sequence/position_weight_matrix.py:13-25): the rollable form of a PWM — a call scores one window
+    of window_size symbols, ``rolling_window`` every window of every row (== get_motif_scores)."""
+
+    def __init__(self, pwm):
+        self._pwm = pwm
+        self._encoding = pwm._encoding
+        self.window_size = pwm.window_size
+
+    def __call__(self, sequence):
+        return self._pwm.calculate_score(sequence)
+
+    def rolling_window(self, sequence):
+        return get_motif_scores(sequence, self._pwm)
+

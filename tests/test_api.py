@@ -210,6 +210,29 @@ def test_minimizers_numeric(bnp):
     assert minimizers.raw().tolist() == [[7, 7, 6, 1], [7, 7, 6], [7, 7], [7]]
 
 
+def test_rollable_forms_minimizers_and_position_weight_matrix(bnp):
+    # tests/test_minimizers.py:36-46 (Minimizers(3, KmerEncoder(2, DNAEncoding)) on the window [0, 3, 1, 2] -> [7]) and
+    # tests/test_position_weight_matrix.py:54-63 (PositionWeightMatrix(pwm)(window), .rolling_window(sequence))
+    encoding = bnp.Minimizers(3, bnp.KmerEncoder(2, bnp.DNAEncoding))
+    assert encoding.window_size == 4
+    window = bnp.EncodedArray(np.array([0, 3, 1, 2], dtype=np.uint8), bnp.DNAEncoding)
+    minimizer = encoding(window)
+    assert minimizer.encoding == bnp.KmerEncoding(bnp.DNAEncoding, 2) and np.asarray(minimizer.raw()).tolist() == [7]
+    sequence = bnp.EncodedArray(np.array([0, 3, 1, 2, 2, 1, 0], dtype=np.uint8), bnp.DNAEncoding)
+    assert np.asarray(encoding.rolling_window(sequence).raw()).tolist() == [7, 7, 6, 1]
+    rows = bnp.as_encoded_array(["ATCGGCA", "ATCGGC", "ATCG"], bnp.DNAEncoding)
+    assert [np.asarray(r).tolist() for r in encoding.rolling_window(rows).raw()] == \
+        [np.asarray(r).tolist() for r in bnp.get_minimizers(rows, 2, 4).raw()]
+    with np.errstate(divide="ignore"):
+        matrix = np.log([[0.4, 0.25], [0.1, 0.25], [0.4, 0.25], [0.1, 0.25]])
+    pwm = bnp.PWM(matrix, "ACGT")
+    scorer = bnp.PositionWeightMatrix(pwm)
+    assert scorer.window_size == 2
+    assert np.allclose(np.exp(scorer(bnp.EncodedArray(np.array([0, 1], dtype=np.uint8), bnp.DNAEncoding))), 0.4 * 0.25)
+    acgt = bnp.EncodedArray(np.array([0, 1, 2, 3], dtype=np.uint8), bnp.DNAEncoding)
+    assert np.allclose(np.exp(scorer.rolling_window(acgt)), [0.4 * 0.25, 0.025, 0.4 * 0.25])
+
+
 def test_minimizer_strings(bnp):
     # tests/test_minimizers.py:65-80, bionumpy/sequence/minimizers.py:39-46
     sequences = bnp.as_encoded_array(["CCCAAACCCC", "TTTTCCCTTT"], bnp.DNAEncoding)
