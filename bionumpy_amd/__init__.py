@@ -18,7 +18,7 @@ from .io import bnp_open, count_entries, FastQBuffer, TwoLineFastaBuffer, MultiL
 from .sequence.debruin import DeBruijnGraph, ColoredDeBruijnGraph
 from .sequence import (match_string, get_motif_scores, get_reverse_complement, get_kmers, count_kmers, get_minimizers, count_encoded, EncodedCounts, SparseKmerCounts,
                        KmerIndex, KmerLookup, KmerEncoder, Minimizers, PositionWeightMatrix, PWM)
-from .streams import streamable
+from .streams import streamable, bincount, histogram, mean, quantile
 from .memory_mapping import MemMapEncodedRaggedArray
 from .datatypes import SequenceEntry, SequenceEntryWithQuality, replace
 

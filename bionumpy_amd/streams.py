@@ -4,6 +4,8 @@ chunks (or chunk fields) and reduces the per-chunk results, e.g. ``sum`` of k-me
 import functools
 import types
 
+import numpy as np
+
 
 class BnpStream:
     def __init__(self, stream, first_buffer=None):
@@ -106,3 +108,59 @@ class streamable:
             return reduction(results())
 
         return wrapped
+
+
+# ---- streamable numpy reductions (bionumpy/streams/reductions.py:1-63): per chunk, then joined ---------------------------------
+def _join_bincounts(parts):
+    total = None
+    for part in parts:
+        part = np.asarray(part)
+        if total is None:
+            total = part.copy()
+        elif total.size >= part.size:
+            total[:part.size] += part
+        else:
+            part = part.copy()
+            part[:total.size] += total
+            total = part
+    return total
+
+
+def _join_histograms(parts):
+    hist, edges = next(parts)
+    hist = np.asarray(hist).copy()
+    for h, _ in parts:                                   # (the caller gives explicit bins / range, or the edges would differ)
+        hist += h
+    return hist, edges
+
+
+bincount = streamable(_join_bincounts)(np.bincount)
+histogram = streamable(_join_histograms)(np.histogram)
+
+
+@streamable(sum)
+def _sum_and_n(array, axis=None):
+    n = array.size if axis is None else len(array)
+    return np.append(np.asarray(np.sum(array, axis=axis), dtype=np.float64), n)
+
+
+@streamable()
+def _row_mean(array, axis=None):
+    return np.mean(array, axis=axis)
+
+
+def mean(array, axis=None):
+    """np.mean over an array or a stream of chunks: sums and counts per chunk, one division at the end (axis None / 0); along
+    the rows (axis 1 / -1) every chunk gives its own means (reductions.py:41-57)"""
+    if axis is not None and axis != 0:
+        return _row_mean(array, axis)
+    t = _sum_and_n(array, axis=axis)
+    return t[:-1] / t[-1] if axis == 0 else t[0] / t[1]
+
+
+def quantile(array, quantiles, axis=None):
+    """the values below which the given fractions of a stream of small non-negative integers lie, from its bincount
+    (reductions.py:60-66)"""
+    cumulative = np.cumsum(bincount(array))
+    return np.searchsorted(cumulative, np.asarray(quantiles) * cumulative[-1])
+

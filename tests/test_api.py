@@ -210,6 +210,28 @@ def test_minimizers_numeric(bnp):
     assert minimizers.raw().tolist() == [[7, 7, 6, 1], [7, 7, 6], [7, 7], [7]]
 
 
+def test_streamable_numpy_reductions(bnp, big_fq_gz):
+    # bionumpy/streams/reductions.py:1-66: bincount / histogram / mean / quantile of an array or of a stream of chunks
+    from bionumpy_amd.streams import BnpStream
+    chunks = [np.array([1, 2, 2, 5]), np.array([0, 2, 7, 7, 7]), np.array([3])]
+    whole = np.concatenate(chunks)
+    assert np.array_equal(bnp.bincount(BnpStream(iter(chunks))), np.bincount(whole))
+    assert np.array_equal(bnp.bincount(whole), np.bincount(whole))
+    hist, edges = bnp.histogram(BnpStream(iter(chunks)), bins=4, range=(0, 8))
+    assert np.array_equal(hist, np.histogram(whole, bins=4, range=(0, 8))[0]) and edges[-1] == 8
+    assert bnp.mean(BnpStream(iter(chunks))) == whole.mean() and bnp.mean(whole) == whole.mean()
+    blocks = [np.arange(6, dtype=float).reshape(2, 3), np.ones((4, 3))]
+    assert np.allclose(bnp.mean(BnpStream(iter(blocks)), axis=0), np.concatenate(blocks).mean(axis=0))
+    assert np.array_equal(bnp.quantile(BnpStream(iter(chunks)), np.array([0.5, 0.9])), [2, 7])
+    # over the chunks of a file: read lengths, and the mean base quality of every read (one array per chunk)
+    lengths = bnp.open(big_fq_gz).read().sequence.lengths
+    stream = bnp.open(big_fq_gz).read_chunks(100000)
+    assert np.array_equal(bnp.bincount(BnpStream(chunk.sequence.lengths for chunk in stream)), np.bincount(lengths))
+    per_chunk = list(bnp.mean(bnp.open(big_fq_gz).read_chunks(100000).quality, axis=1))
+    assert len(per_chunk) > 1 and np.allclose(np.concatenate([np.asarray(m) for m in per_chunk]),
+                                               np.asarray(np.mean(bnp.open(big_fq_gz).read().quality, axis=1)))
+
+
 def test_rollable_forms_minimizers_and_position_weight_matrix(bnp):
     # tests/test_minimizers.py:36-46 (Minimizers(3, KmerEncoder(2, DNAEncoding)) on the window [0, 3, 1, 2] -> [7]) and
     # tests/test_position_weight_matrix.py:54-63 (PositionWeightMatrix(pwm)(window), .rolling_window(sequence))
