@@ -61,7 +61,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
     __syncthreads();
   }
   auto offset_of = [&](int64_t row) { return (staged && row <= hi + 1) ? srow[row - lo] : off[row]; };
-#pragma unroll
+  // (not unrolled: hipcc 7.2 -O3 gets the unrolled form of this loop wrong — rows of workgroups from the 257th on came out
+  // garbled, per lane or per wavefront, with the row offsets in LDS or in global memory alike; the rolled loop is as fast.
+  // tests/test_gpu_parity.py::test_reverse_complement_kernels has a case of 12 M bases for it.)
+#pragma unroll 1
   for (int it = 0; it < RCP_WPL; ++it) {
     const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
     const int64_t p0 = w * 32;

@@ -361,7 +361,8 @@ def test_finishing_kernel_edges(ops, key_bits, n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 1), (2, 50, 40), (3, 3000, 151), (4, 7, 20000), (5, 200_000, 33)])
+@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 1), (2, 50, 40), (3, 3000, 151), (4, 7, 20000), (5, 200_000, 33),
+                                                 (287332572, 40000, 700)])
 def test_reverse_complement_kernels(ops, seed, n_rows, max_len):
     """packed 2-bit and ASCII reverse complement vs the oracle on ragged rows (empty rows, rows longer than a tile,
     word-boundary lengths); canonical k-mer hashes vs the oracle"""
