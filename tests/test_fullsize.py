@@ -50,6 +50,56 @@ def test_config3_minimizers_at_full_size(ops):
     assert done["minimizers"] == n_reads * (read_len - window + 1) and done["sampled_minimizers_vs_oracle"] >= 3000 * 111 - 111
 
 
+def test_chunk_objects_at_full_size(ops):
+    """The API objects on a chunk of 10 M reads (3.2 GB of FASTQ, 1.5e9 bases: far beyond the shapes of tests/test_api.py and
+    of the kernels' parity tests): size-independent properties — the reverse complement is an involution in all three forms
+    (2-bit, ASCII, ASCII read where it lies in the text), the per-read mean quality straight from the text equals the one of
+    the gathered column, the rewritten chunk parses back to the fields it was written from, the k-mers of the decoded reads
+    are those of the fused pipeline — and sampled reads against the oracle."""
+    import bionumpy_amd as bnp
+    from bionumpy_amd import synth
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    n_reads, read_len, seed = 10_000_000, 150, 99
+    text = ops.synth_fastq(n_reads, read_len, seed, 0, 0, 0)
+    chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+    import torch
+    same = lambda a, b: bool(torch.equal(a.dev(), b.dev()))
+    # reverse complement: packed, bytes, rows of the text
+    dna = bnp.change_encoding(chunk.sequence, bnp.DNAEncoding)
+    rc = bnp.get_reverse_complement(dna)
+    from bionumpy_amd.encoded_array import packed_words
+    assert same(packed_words(bnp.get_reverse_complement(rc)._data), packed_words(dna._data))
+    rc_rows = bnp.get_reverse_complement(chunk.sequence)                       # (a view of the text: bnpk_reverse_complement_rows)
+    seq_bytes = bnp.get_reverse_complement(rc_rows)                            # (compact now: bnpk_reverse_complement_bytes)
+    assert same(ops.unpack_codes(packed_words(dna._data), dna.total(), to_ascii=True), seq_bytes._flat_data())
+    assert same(ops.unpack_codes(packed_words(rc._data), rc.total(), to_ascii=True), rc_rows._flat_data())
+    codes = synth.read_codes(n_reads, read_len, seed, 0, 0, 0)
+    for r in (0, 1, n_reads // 2, n_reads - 1):
+        assert rc[r].to_string() == "".join("TGCA"[c] for c in codes[r][::-1])
+    # the quality column: reductions from the text == reductions of the gathered column
+    q = chunk.quality
+    means = np.mean(q, axis=1)
+    mins = np.min(q, axis=1)
+    assert getattr(q, "_pending", None) is not None                            # nothing has gathered it yet
+    q._compact()
+    assert same(np.mean(q, axis=1).harray(), means.harray()) and same(np.min(q, axis=1).harray(), mins.harray())
+    # the rewritten chunk (names and qualities joined from the text, sequences replaced) parses back to the same fields
+    out = bnp.FastQBuffer.from_data(bnp.replace(chunk, sequence=rc_rows))
+    assert out.size == text.size
+    back = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(out))
+    assert same(bnp.get_reverse_complement(back.sequence)._flat_data(), seq_bytes._flat_data())
+    bq = back.quality
+    bq._compact()
+    assert same(bq._flat_data(), q._flat_data())
+    bn, cn = back.name, chunk.name
+    bn._compact(); cn._compact()
+    assert same(bn._flat_data(), cn._flat_data())
+    # k-mers of the decoded reads == the fused pipeline's histogram
+    (keys, counts), stats = fastq_kmer_histogram(text, 31)
+    hist = bnp.count_kmers(dna, 31)
+    assert same(HArray(dev=hist._keys.dev()), keys) and same(HArray(dev=hist._counts.dev()), counts)
+
+
 @pytest.mark.parametrize("canonical,n_reads,genome_len", [(False, 1_000_000, 2_000_000), (True, 300_000, 600_000)])
 def test_genome_reads_whole_histogram_equals_the_oracle(ops, canonical, n_reads, genome_len):
     from bionumpy_amd.pipeline import fastq_kmer_histogram
