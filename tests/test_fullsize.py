@@ -100,6 +100,37 @@ def test_chunk_objects_at_full_size(ops):
     assert same(HArray(dev=hist._keys.dev()), keys) and same(HArray(dev=hist._counts.dev()), counts)
 
 
+def test_filter_and_match_at_full_size(ops):
+    """a read filter with write-back and match_string on 10 M reads, checked by what must hold at any size: the kept entries
+    parse back to exactly the rows the mask selects (names, sequences, qualities, in order), and the windows that match a
+    7-letter pattern are the 7-mers with the pattern's hash (two different kernels)"""
+    import torch
+    import bionumpy_amd as bnp
+    n_reads, read_len, seed = 10_000_000, 150, 123
+    text = ops.synth_fastq(n_reads, read_len, seed, 1, 50_000_000, 0)
+    chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+    same = lambda a, b: bool(torch.equal(a.dev(), b.dev()))
+    keep = np.mean(chunk.quality, axis=1) >= 0.0
+    keep[::3] = False
+    keep[5::7] = False
+    n_keep = int(keep.sum())
+    assert 0 < n_keep < n_reads
+    kept = chunk[keep]
+    back = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(kept.get_buffer().entry_bytes()))
+    assert len(back) == n_keep
+    for field in ("name", "sequence", "quality"):
+        a, b = getattr(back, field), getattr(kept, field)
+        a._compact(); b._compact()
+        assert same(a._flat_data(), b._flat_data()) and same(a.offsets(), b.offsets()), field
+    dna = bnp.change_encoding(chunk.sequence, bnp.DNAEncoding)
+    hits = bnp.match_string(dna, "GATTACA")
+    kmers = bnp.get_kmers(dna, 7)
+    want = int(bnp.get_kmers(bnp.as_encoded_array("GATTACA", bnp.DNAEncoding), 7).raw()[0])
+    flags = hits._flat_data().dev().to(torch.bool)
+    assert flags.numel() == kmers.total() and bool(torch.equal(flags, kmers._flat_data().dev() == want))
+    assert int(flags.sum().item()) > 1000
+
+
 @pytest.mark.parametrize("canonical,n_reads,genome_len", [(False, 1_000_000, 2_000_000), (True, 300_000, 600_000)])
 def test_genome_reads_whole_histogram_equals_the_oracle(ops, canonical, n_reads, genome_len):
     from bionumpy_amd.pipeline import fastq_kmer_histogram
