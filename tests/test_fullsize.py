@@ -100,6 +100,48 @@ def test_chunk_objects_at_full_size(ops):
     assert same(HArray(dev=hist._keys.dev()), keys) and same(HArray(dev=hist._counts.dev()), counts)
 
 
+def test_the_reference_loop_over_a_file_of_several_batches(ops, tmp_path):
+    """scripts/kmer_counting_example.py:4-17 over a 0.5 GB FASTQ file (four device batches of 128 MB, a hundred chunks of 5 MB
+    cut out of them by the windowed reader, the sequence column and the k-mers shared per batch): the sum of the per-chunk
+    histograms, in the example's form, the library's form, the stream form and with 7-mers (dense counts), equals the
+    histogram of the whole text; the chunks hold every entry once, in order"""
+    import torch
+    import bionumpy_amd as bnp
+    from bionumpy_amd.pipeline import fastq_kmer_histogram
+    n_reads, k = 1_600_000, 31
+    text = ops.synth_fastq(n_reads, 150, 7, 1, 20_000_000, 0)
+    path = str(tmp_path / "reads.fq")
+    text.host().tofile(path)
+    (keys, counts), _ = fastq_kmer_histogram(text, k)
+    same = lambda a, b: bool(torch.equal(a.dev(), b.dev()))
+
+    def per_chunk(chunk, kk):
+        return bnp.count_encoded(bnp.get_kmers(bnp.as_encoded_array(chunk.sequence, bnp.DNAEncoding), k=kk), axis=None)
+    n_chunks, n_entries, first_names = 0, 0, []
+    def counted(kk):
+        nonlocal n_chunks, n_entries
+        for c in bnp.open(path).read_chunks():                               # (the reference's default: 5 000 000 bytes)
+            n_chunks += 1
+            n_entries += len(c)
+            if n_chunks in (1, 40, 90):
+                first_names.append(c.name[0].to_string())
+            yield per_chunk(c, kk)
+    total = sum(counted(k))
+    assert n_entries == n_reads and 95 <= n_chunks <= 110
+    assert first_names[0] == bnp.open(path).read_chunk(1000).name[0].to_string() and len(set(first_names)) == 3
+    assert same(HArray(dev=total._keys.dev()), keys) and same(HArray(dev=total._counts.dev()), counts)
+    library = None
+    for c in bnp.open(path).read_chunks():
+        h = bnp.count_kmers(c.sequence, k)
+        library = h if library is None else library + h
+    assert same(HArray(dev=library._keys.dev()), keys) and same(HArray(dev=library._counts.dev()), counts)
+    streamed = bnp.count_kmers(bnp.open(path).read_chunks().sequence, k)
+    assert same(HArray(dev=streamed._keys.dev()), keys) and same(HArray(dev=streamed._counts.dev()), counts)
+    dense = sum(counted(7))
+    whole7, _ = fastq_kmer_histogram(text, 7)
+    assert np.array_equal(np.asarray(dense.counts).ravel(), whole7.host())
+
+
 def test_filter_and_match_at_full_size(ops):
     """a read filter with write-back and match_string on 10 M reads, checked by what must hold at any size: the kept entries
     parse back to exactly the rows the mask selects (names, sequences, qualities, in order), and the windows that match a
