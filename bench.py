@@ -229,6 +229,50 @@ def extras(args, ops, dev, main_stats, copy_rate):
                                      "kernels_ms": {n: round(v["total_ms"] / steps, 2) for n, v in prof.items()},
                                      "parity": True, "parity_detail": dict(checked, compared_with="bnpk_minimizers (row-lookup kernel) element for "
                                                                             "element on 3 x %d reads; the numpy oracle on sampled reads" % per)}
+        # ---- the same reads through the API objects (what a user of the reference's functions runs): minimizers, a read filter
+        # with write-back, a reverse-complement rewrite — parity by what must hold at any size
+        try:
+            def api_minimizers():
+                buf = bnp.FastQBuffer.from_raw_buffer(text)
+                return bnp.get_minimizers(bnp.change_encoding(buf.get_field_by_number(1), bnp.DNAEncoding), 31, 40)
+            m, dt, prof = timed(api_minimizers, 2)
+            fused, _ = fastq_minimizers(text, 31, 40)
+            same = bool(torch.equal(m._flat_data().dev(), fused.dev()))
+            del m, fused
+            out["config3_api_objects"] = {"workload": "FastQBuffer.from_raw_buffer + change_encoding + get_minimizers(31, 40) on the same reads",
+                                          "ms_per_step": round(dt * 1e3, 2), "steps": 2, "kernels_ms": {n: round(v["total_ms"] / 2, 2) for n, v in prof.items()},
+                                          "parity": same, "parity_detail": "every minimizer == the fused pipeline's"}
+
+            def read_filter():
+                chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+                keep = np.mean(chunk.quality, axis=1) >= 0.0
+                keep[::3] = False
+                return chunk[keep].get_buffer().entry_bytes(), int(keep.sum())
+            (kept_text, n_keep), dt, prof = timed(read_filter, 2)
+            back = bnp.FastQBuffer.from_raw_buffer(kept_text)
+            ok = len(back) == n_keep and n_keep == args.reads - (args.reads + 2) // 3
+            out["read_filter_write_back"] = {"workload": "np.mean(chunk.quality, axis=1) mask, every third read dropped, chunk[mask] as text",
+                                             "ms_per_step": round(dt * 1e3, 2), "steps": 2, "kept": n_keep, "bytes_out": int(kept_text.size),
+                                             "kernels_ms": {n: round(v["total_ms"] / 2, 2) for n, v in prof.items()},
+                                             "parity": bool(ok), "parity_detail": "the kept text parses back to exactly the kept entries"}
+            del kept_text, back
+
+            def rewrite():
+                chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+                rc = bnp.get_reverse_complement(chunk.sequence)
+                return bnp.FastQBuffer.from_data(bnp.replace(chunk, sequence=rc))
+            new_text, dt, prof = timed(rewrite, 2)
+            again = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(new_text))
+            orig = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text)).sequence
+            orig._compact()
+            ok = new_text.size == text.size and bool(torch.equal(bnp.get_reverse_complement(again.sequence)._flat_data().dev(), orig._flat_data().dev()))
+            out["reverse_complement_rewrite"] = {"workload": "get_reverse_complement(chunk.sequence) + the chunk's text rebuilt from its fields",
+                                                 "ms_per_step": round(dt * 1e3, 2), "steps": 2, "bytes_out": int(new_text.size),
+                                                 "kernels_ms": {n: round(v["total_ms"] / 2, 2) for n, v in prof.items()},
+                                                 "parity": bool(ok), "parity_detail": "the rewritten text parses back; its sequences reverse-complemented are the original ones"}
+            del new_text, again, orig
+        except AssertionError as e:
+            out["config3_api_objects"] = {"parity": False, "error": str(e)}
         del text
     except AssertionError as e:
         out["config3_minimizers"] = {"parity": False, "error": str(e)}
