@@ -76,11 +76,11 @@ class BatchShare:
     """What the chunks that a reader cut out of ONE device batch have in common (io/parser.py:_cut_windows): the batch's
     buffer and, computed once on first request, a field of ALL its entries encoded as DNA.  The reference's loop encodes the
     sequence column of every 5 MB chunk on its own (``as_encoded_array(chunk.sequence, DNAEncoding)``,
-    scripts/kmer_counting_example.py:5): here that is the gather + 2-bit encode of the whole batch, once, and a chunk takes
-    its rows out of the packed result with one small kernel and no round trip to the host (``bnpk_packed_rows_slice``) —
-    the rows of a chunk are a contiguous run of the batch's.  An invalid base anywhere in the batch switches the
-    shortcut off for the batch: every chunk then encodes itself and the EncodingError comes from the chunk that holds the base,
-    with its own offset."""
+    scripts/kmer_counting_example.py:5): here that is the gather + 2-bit encode of the whole batch, once; the rows of a chunk
+    are a contiguous run of the batch's, so its k-mers (``windows``) are a part of the batch's, computed once per k, and its
+    own packed words are cut out of the packed column (``bnpk_packed_rows_slice``: one small kernel, no round trip to the
+    host) only if somebody asks for them.  An invalid base anywhere in the batch switches the shortcut off for the batch:
+    every chunk then encodes itself and the EncodingError comes from the chunk that holds the base, with its own offset."""
 
     def __init__(self, big, cut_rows):
         self.big = big
