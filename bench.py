@@ -357,6 +357,97 @@ def virtual_ranks_mode(args, ops, dev, mode):
                                 "key ranges disjoint and ascending"}))
 
 
+def from_file_mode(args, ops, dev, mode, rank, world):
+    """--from-file PATH: BASELINE config 4's shape from an actual FASTQ file.  Every rank calls the reference's stream form
+
+        count_kmers(bnp.open(PATH).read_chunks().sequence, k)
+
+    and nothing else: under torch.distributed ``bnp.open`` gives every rank its part of the file (byte ranges cut at record
+    starts, io/sharding.py) and the reduction finishes with the merge over the ranks.  The file is written first (rank 0,
+    outside the timed region: world x --reads synthetic reads) unless it exists.  Exits 4 if the ranks' read counts do not add
+    up to the reads of the file, and checks the merged histogram against the k-mers of all parts in read order (checksums,
+    all-reduced).  One JSON line; host-fed by construction (file -> pinned RAM -> HBM), so never the headline `value`."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize
+    import bionumpy_amd as bnp
+    path = args.from_file
+    total_reads = world * args.reads
+    if rank == 0 and not os.path.exists(path):
+        piece = 4_000_000
+        with open(path + ".tmp", "wb") as f:
+            for first in range(0, total_reads, piece):
+                t = ops.synth_fastq(min(piece, total_reads - first), args.read_len, args.seed, mode, args.genome_len, first)
+                f.write(t.host().tobytes())
+                del t
+        os.replace(path + ".tmp", path)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    file_bytes = os.path.getsize(path)
+    chunk = args.file_chunk_mb << 20
+
+    def step():
+        return bnp.count_kmers(bnp.open(path).read_chunks(min_chunk_size=chunk).sequence, args.k)
+
+    for _ in range(args.warmup):
+        h = step(); h._keys; del h
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        h = step()
+        h._keys                                              # (sparse counts are lazy: the timed region ends with a counted result)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    # ---- what was read and counted, outside the timed region -------------------------------------------------------
+    n_reads = n_bases = 0
+    flat = [0, 0, 0, 0]
+    for c in bnp.open(path).read_chunks(min_chunk_size=chunk):
+        n_reads += len(c)
+        seqs = bnp.change_encoding(c.sequence, bnp.DNAEncoding)
+        n_bases += int(seqs.total())
+        km = bnp.get_kmers(seqs, args.k)
+        km._compact()
+        hd = km._flat_data().dev()
+        s = fullsize._sums(torch, hd)
+        flat = [flat[0] + hd.numel()] + [(a + b) & ((1 << 64) - 1) for a, b in zip(flat[1:], s)]
+        del km, hd, seqs
+    hs = fullsize.histogram_sums(h._keys, h._counts) if isinstance(h, bnp.SparseKmerCounts) else None
+    wrap = lambda v: [x - (1 << 64) if x >= (1 << 63) else x for x in v]
+    both = torch.tensor([wrap(hs) if hs is not None else [0] * 4, wrap(flat), [n_reads, n_bases, len(h) if hs is not None else 0, 0]],
+                        dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(both)
+    reads_seen = int(both[2][0].item())
+    ok_reads = reads_seen * fullsize.synth.record_bytes(args.read_len) == file_bytes if args.from_file_synthetic else True
+    parity = hs is None or bool((both[0] == both[1]).all().item())
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        from bionumpy_amd import parallel
+        print(json.dumps({
+            "mode": "from-file (count_kmers(bnp.open(f).read_chunks().sequence, k) on every rank; file -> pinned RAM -> HBM: never the headline value)",
+            "file": path, "file_bytes": file_bytes, "n_gpus": world, "k": args.k, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(float(tmax.item()) * 1e3, 2),
+            "gbases_per_s": round(int(both[2][1].item()) / float(tmax.item()) / 1e9, 3),
+            "file_gb_per_s": round(file_bytes / float(tmax.item()) / 1e9, 2),
+            "reads_seen_by_all_ranks": reads_seen, "reads_add_up": bool(ok_reads), "distinct_keys": int(both[2][2].item()),
+            "collectives": parallel.collectives().name if world > 1 else None,
+            "parity_fullsize": bool(parity),
+            "parity": "count / sum / sum of squares / mixed sum of all ranks' (key, count) == those of the k-mers of every part in read order (all-reduced)"}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok_reads or not parity:
+        sys.exit(4)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +465,10 @@ def main():
                     help="play the N-GPU sparse path on this one GPU: the batch is sharded N ways, the exchange is replaced "
                          "by its result, every rank's key range is counted (functional check of the N > 1 kernels, "
                          "not a scaling measurement)")
+    ap.add_argument("--from-file", default=None, metavar="PATH",
+                    help="count the k-mers of this FASTQ file through the reader, every rank its part (written first — world x "
+                         "--reads synthetic reads — if it does not exist); exits 4 if the ranks' reads do not add up")
+    ap.add_argument("--file-chunk-mb", type=int, default=256, help="--from-file: chunk size the reader is asked for")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the host-fed (pinned RAM -> HBM) measurement")
     ap.add_argument("--host-fed-batches", type=int, default=2)
     ap.add_argument("--allow-fallback", action="store_true",
@@ -405,6 +500,11 @@ def main():
     ops = get_ops()
     dev = Device.get()
     mode = 0 if args.mode == "uniform" else 1
+
+    if args.from_file:
+        args.from_file_synthetic = not os.path.exists(args.from_file)       # (a file we write ourselves: its size says how many reads)
+        from_file_mode(args, ops, dev, mode, rank, world)
+        return
 
     # ---- input: generated on the device, resident in HBM before the timed region ------------------------
     text = ops.synth_fastq(args.reads, args.read_len, args.seed, mode, args.genome_len, first_read=rank * args.reads)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "bnpk_copy_peak": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_copy_rates": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_set_option": (_int, [_p, C.c_char_p, _i64]),
+    "bnpk_comm_available": (_int, []),
     "bnpk_comm_unique_id": (_int, [_p]),
     "bnpk_comm_init": (_int, [_p, _p, _int, _int, C.POINTER(C.c_void_p)]),
     "bnpk_comm_destroy": (_int, [_p]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "bnpk_copy_h2d_async": (_int, [_p, _p, C.c_size_t, _p]),
     "bnpk_copy_d2h_async": (_int, [_p, _p, C.c_size_t, _p]),
     "bnpk_pread_parallel": (_int, [_p, _int, _i64, _p, _i64, _int, _i64, _p, _p, C.POINTER(_i64)]),
+    "bnpk_count_byte_file": (_int, [_int, _i64, _i64, _u8, _int, C.POINTER(_i64)]),
     "bnpk_stream_sync": (_int, [_p]),
     "bnpk_fetch_i64": (_int, [_p, _p, _i64, C.POINTER(_i64), _p]),
     "bnpk_scan_tiles": (_i64, [_i64]),

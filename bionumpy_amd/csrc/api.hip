@@ -205,6 +205,49 @@ int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst,
   return BNPK_OK;
 }
 
+// How many times `byte` occurs in [file_offset, file_offset + bytes) of the open file: pread into a buffer per thread and a
+// counting loop the compiler vectorises.  What a reader that begins in the middle of a file needs to say which LINE of the
+// file it is at (FormatException.line_number counts from the start of the file: bionumpy/io/parser.py:141-143).
+int bnpk_count_byte_file(int fd, int64_t file_offset, int64_t bytes, uint8_t byte, int n_threads, int64_t* h_count) {
+  if (fd < 0 || file_offset < 0 || bytes < 0 || n_threads < 1 || !h_count) return BNPK_ERR_ARG;
+  *h_count = 0;
+  if (bytes == 0) return BNPK_OK;
+  const int64_t piece = 4 << 20;
+  n_threads = (int)std::min<int64_t>(n_threads, std::max<int64_t>(1, bytes / piece));
+  const int64_t step = ceil_div(ceil_div(bytes, (int64_t)n_threads), (int64_t)4096) * 4096;
+  std::vector<int64_t> found(n_threads, 0);
+  std::vector<int> status(n_threads, BNPK_OK);
+  auto work = [&](int t) {
+    std::vector<uint8_t> buf((size_t)std::min(piece, step));
+    int64_t a = (int64_t)t * step;
+    const int64_t b = std::min(a + step, bytes);
+    int64_t c = 0;
+    while (a < b) {
+      const int64_t want = std::min<int64_t>(b - a, (int64_t)buf.size());
+      const ssize_t n = pread(fd, buf.data(), (size_t)want, (off_t)(file_offset + a));
+      if (n < 0 && errno == EINTR) continue;
+      if (n <= 0) { status[t] = BNPK_ERR_ARG; return; }      // the range reaches behind the end of the file
+      const uint8_t* p = buf.data();
+      int64_t k = 0;
+      for (ssize_t i = 0; i < n; ++i) k += p[i] == byte;
+      c += k;
+      a += n;
+    }
+    found[t] = c;
+  };
+  std::vector<std::thread> threads;
+  for (int t = 1; t < n_threads; ++t) threads.emplace_back(work, t);
+  work(0);
+  for (auto& th : threads) th.join();
+  int64_t total = 0;
+  for (int t = 0; t < n_threads; ++t) {
+    if (status[t] != BNPK_OK) return status[t];
+    total += found[t];
+  }
+  *h_count = total;
+  return BNPK_OK;
+}
+
 int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stream) {
   if (bytes == 0) return BNPK_OK;
   if (!h_dst || !d_src) return BNPK_ERR_ARG;

@@ -110,6 +110,10 @@ extern "C" {
 
 const char* bnpk_last_comm_error(void) { return g_last_rccl_error; }
 
+// whether RCCL can be loaded here at all — dlopen + dlsym, nothing made: ncclGetUniqueId would start a bootstrap root (a
+// listening socket and a thread) on every rank that merely asks
+int bnpk_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 int bnpk_comm_unique_id(uint8_t* id128) {
   if (!id128) return BNPK_ERR_ARG;
   const rccl_api& a = rccl();

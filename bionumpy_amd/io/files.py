@@ -34,18 +34,47 @@ def _split_suffix(filename):
     return suffix, is_gzip
 
 
-def bnp_open(filename, mode=None, buffer_type=None, lazy=None):
-    """Open a sequence file for chunked reading (io/files.py:85-182)."""
+def _file_reader(filename, buffer_type, is_gzip, shard=None):
+    """NumpyFileReader over the whole file, or over one rank's part of it (io/sharding.py):
+    plain file -> a byte range cut at record starts; BGZF -> members of a range of the compressed file, cut at record starts
+    of the text; any other gzip stream -> the whole stream, of whose chunks this rank keeps every world-th"""
+    from .sharding import RecordRule, plain_byte_range
+    from .gzip_reading import is_bgzf
+    import os
+    if shard is None:
+        reader = NumpyFileReader(open_gzip_for_reading(filename) if is_gzip else open(filename, "rb"), buffer_type)
+    elif not is_gzip:
+        f = open(filename, "rb")
+        start, stop = plain_byte_range(f.fileno(), os.fstat(f.fileno()).st_size, shard, RecordRule.of(buffer_type))
+        reader = NumpyFileReader(f, buffer_type, byte_range=(start, stop))
+    elif is_bgzf(filename):
+        text = open_gzip_for_reading(filename, shard=shard, rule=RecordRule.of(buffer_type))
+        reader = NumpyFileReader(text, buffer_type, lines_before=text.lines_before)
+    else:
+        reader = NumpyFileReader(open_gzip_for_reading(filename), buffer_type, chunk_modulo=(shard.rank, shard.world))
+    if is_gzip:
+        reader.set_prepend_mode()
+    return reader
+
+
+def bnp_open(filename, mode=None, buffer_type=None, lazy=None, shard=None):
+    """Open a sequence file for chunked reading (io/files.py:85-182).
+
+    shard (extension): which part of the file this process reads when several ranks read it together.
+    None / "auto" — under an initialised ``torch.distributed`` job with more than one rank, rank r's part (so that
+    ``count_kmers(bnp.open(f).read_chunks().sequence, k)`` launched with torchrun reads the file ONCE and returns the
+    histogram of the whole file: dense counts summed on every rank, sparse counts partitioned by key range over the ranks);
+    otherwise the whole file.  ``False`` — the whole file on every rank (a reference genome every rank indexes).
+    ``(rank, world)`` — that part, whatever the job is (no merge is attempted without a process group)."""
+    from .sharding import resolve_shard
     suffix, is_gzip = _split_suffix(filename)
     open_func = gzip.open if is_gzip else open
     if buffer_type is None:
         buffer_type = _get_buffer_type(suffix)
     if mode in ("w", "write", "wb", "a", "append", "ab"):
         return NpBufferedWriter(open_func(filename, "ab" if mode in ("a", "append", "ab") else "wb"), buffer_type)
-    file_reader = NumpyFileReader(open_gzip_for_reading(filename) if is_gzip else open(filename, "rb"), buffer_type)
-    if is_gzip:
-        file_reader.set_prepend_mode()
-    return NpDataclassReader(file_reader, lazy=lazy)
+    shard = resolve_shard(shard)
+    return NpDataclassReader(_file_reader(filename, buffer_type, is_gzip, shard), lazy=lazy, shard=shard)
 
 
 class NpBufferedWriter:
@@ -85,13 +114,11 @@ class NpBufferedWriter:
         self._file_obj.write(text.host().tobytes())
 
 
-def count_entries(filename, buffer_type=None):
-    """io/files.py:185-227"""
+def count_entries(filename, buffer_type=None, shard=False):
+    """io/files.py:185-227 (shard: as in ``bnp_open`` — the entries of this rank's part; default: of the whole file)"""
+    from .sharding import resolve_shard
     suffix, is_gzip = _split_suffix(filename)
-    open_func = gzip.open if is_gzip else open
     if buffer_type is None:
         buffer_type = _get_buffer_type(suffix)
-    file_reader = NumpyFileReader(open_gzip_for_reading(filename) if is_gzip else open(filename, "rb"), buffer_type)
-    if is_gzip:
-        file_reader.set_prepend_mode()
+    file_reader = _file_reader(filename, buffer_type, is_gzip, resolve_shard(shard))
     return sum(chunk.count_entries() for chunk in file_reader.read_chunks(min_chunk_size=500000))

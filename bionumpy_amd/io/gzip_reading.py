@@ -58,6 +58,7 @@ class _LibDeflate:
         lib.libdeflate_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
         lib.libdeflate_crc32.restype = C.c_uint32
         self._C, self._lib, self._local = C, lib, threading.local()
+        self._by_thread, self._lock = {}, threading.Lock()     # thread ident -> its decompressor (freed when its pool closes)
 
     def _decompressor(self):
         d = getattr(self._local, "d", None)
@@ -65,6 +66,8 @@ class _LibDeflate:
             d = self._local.d = self._lib.libdeflate_alloc_decompressor()
             if not d:
                 raise MemoryError("libdeflate_alloc_decompressor")
+            with self._lock:
+                self._by_thread[threading.get_ident()] = d
         return d
 
     def inflate_members(self, blob, members, total):
@@ -73,18 +76,36 @@ class _LibDeflate:
         out = bytearray(total)
         if total == 0:
             return out
-        src = (C.c_char * len(blob)).from_buffer_copy(blob) if not isinstance(blob, bytearray) else (C.c_char * len(blob)).from_buffer(blob)
+        if isinstance(blob, bytearray):
+            src = (C.c_char * len(blob)).from_buffer(blob)
+            src_at = C.addressof(src)
+        else:                                              # bytes: its own buffer, not a copy of it (``blob`` outlives the loop)
+            src = C.c_char_p(blob)
+            src_at = C.cast(src, C.c_void_p).value
         dst = (C.c_char * total).from_buffer(out)
-        src_at, dst_at = C.addressof(src), C.addressof(dst)
+        dst_at = C.addressof(dst)
         d, got = self._decompressor(), C.c_size_t(0)
         for p_off, p_size, t_off, t_size, crc, at in members:
             if t_size == 0:
                 continue
             rc = self._lib.libdeflate_deflate_decompress(d, src_at + p_off, p_size, dst_at + t_off, t_size, C.byref(got))
-            if rc != 0 or got.value != t_size or self._lib.libdeflate_crc32(0, dst_at + t_off, t_size) != crc:
+            if rc != 0:                                    # LIBDEFLATE_BAD_DATA 1, SHORT_OUTPUT 2, INSUFFICIENT_SPACE 3
+                what = {1: "invalid deflate data", 2: "less text than its trailer claims", 3: "more text than its trailer claims"}
+                raise gzip.BadGzipFile("%s in a BGZF member at compressed offset %d" % (what.get(rc, "inflate error %d" % rc), at))
+            if got.value != t_size:
+                raise gzip.BadGzipFile("a BGZF member at compressed offset %d inflated to %d bytes, its trailer says %d"
+                                       % (at, got.value, t_size))
+            if self._lib.libdeflate_crc32(0, dst_at + t_off, t_size) != crc:
                 raise gzip.BadGzipFile("CRC check failed in a BGZF member at compressed offset %d" % at)
         del src, dst
         return out
+
+    def free_threads(self, idents):
+        """frees the decompressors of threads that have ended (a closed reader's inflate pool)"""
+        with self._lock:
+            found = [self._by_thread.pop(i) for i in list(idents) if i in self._by_thread]
+        for d in found:
+            self._lib.libdeflate_free_decompressor(d)
 
 
 def _load_libdeflate():
@@ -183,10 +204,13 @@ class BgzfReader(_AheadReader):
     def __init__(self, raw, name, n_threads):
         super().__init__(name)
         self._raw = raw
-        self._pool = ThreadPoolExecutor(max_workers=max(1, n_threads), thread_name_prefix="bnpk-inflate")
+        self._thread_ids = set()
+        self._pool = ThreadPoolExecutor(max_workers=max(1, n_threads), thread_name_prefix="bnpk-inflate",
+                                        initializer=lambda: self._thread_ids.add(threading.get_ident()))
         self._tasks = collections.deque()
         self._pending = b""
         self._raw_done = False
+        self._closed = False
         self._fill_tasks()
 
     def _fill_tasks(self):
@@ -229,7 +253,139 @@ class BgzfReader(_AheadReader):
         for t in self._tasks:
             t.cancel()
         self._pool.shutdown(wait=True)
+        if _libdeflate is not None and not self._closed:   # the pool's threads are gone: their decompressors go too
+            _libdeflate.free_threads(self._thread_ids)
+        self._closed = True
         self._raw.close()
+
+
+class _LimitedRaw:
+    """bytes [start, stop) of a file as a raw stream of their own (``read`` only)"""
+
+    def __init__(self, filename, start, stop):
+        self._f = open(filename, "rb")
+        self._f.seek(start)
+        self._left = max(0, stop - start)
+
+    def read(self, n=-1):
+        n = self._left if n is None or n < 0 else min(n, self._left)
+        data = self._f.read(n) if n else b""
+        self._left -= len(data)
+        return data
+
+    def close(self):
+        self._f.close()
+
+
+class BgzfShardReader(_AheadReader):
+    """One rank's part of the text of a BGZF file (io/sharding.py).  The compressed file is cut at the first member that
+    starts at or behind byte r * S / N (m_lo) and (r + 1) * S / N (m_hi); C(m) = the first record that starts in the text at
+    or behind the first text byte of member m, found by scanning forwards from there (the byte in front of it is not
+    known, so the member's first byte is not taken for the start of a line); this reader's text is [C(m_lo), C(m_hi)).
+    Both neighbours compute C at the same member with the same scan, so every record is read by exactly one rank."""
+
+    def __init__(self, filename, n_threads, shard, rule):
+        super().__init__(filename)
+        from .sharding import bgzf_member_at_or_after, first_record_start
+        self._rule, self._first_record_start = rule, first_record_start
+        size = os.path.getsize(filename)
+        with open(filename, "rb") as probe:
+            read_at = lambda off, n: os.pread(probe.fileno(), n, off)
+            lo, hi = size * shard.rank // shard.world, size * (shard.rank + 1) // shard.world
+            self._m_lo = bgzf_member_at_or_after(read_at, size, lo, _bgzf_block_size)
+            self._m_hi = size if shard.rank == shard.world - 1 else \
+                max(self._m_lo, bgzf_member_at_or_after(read_at, size, hi, _bgzf_block_size))
+        self._size, self._n_threads = size, n_threads
+        self._head_newlines = 0
+        self._lines_before = None
+        self._body = None
+        self._tail = b""
+        if self._m_hi > self._m_lo:
+            # the text this rank reads BEHIND member m_hi: up to C(m_hi) (found now: a few lines of one member, usually)
+            if self._m_hi < size:
+                self._tail, _ = self._scan_from(self._m_hi)
+            self._body = BgzfReader(_LimitedRaw(filename, self._m_lo, self._m_hi), filename, n_threads)
+        self._state = "head" if self._m_lo > 0 else "body"
+        if self._body is None:
+            self._state = "done"
+
+    def _scan_from(self, member):
+        """(the text between the first byte of ``member`` and C(member), whether a record starts there at all)"""
+        reader = BgzfReader(_LimitedRaw(self.name, member, self._size), self.name, min(2, self._n_threads))
+        try:
+            acc = bytearray()
+            while True:
+                piece = reader._next_piece()
+                acc += piece
+                import numpy as np
+                cut = self._first_record_start(np.frombuffer(acc, dtype=np.uint8), False, self._rule, not piece)
+                if cut is not None:
+                    return (bytes(acc), False) if cut < 0 else (bytes(acc[:cut]), True)
+        finally:
+            reader.close()
+
+    def _stream_piece(self):
+        """the next piece of body ++ tail (b"" at the end)"""
+        if self._body is not None:
+            piece = self._body._next_piece()
+            if piece:
+                return piece
+            self._body.close()
+            self._body = None
+            tail, self._tail = self._tail, b""
+            return tail
+        return b""
+
+    def _next_piece(self):
+        if self._state == "done":
+            return b""
+        if self._state == "body":
+            piece = self._stream_piece()
+            if not piece:
+                self._state = "done"
+            return piece
+        # "head": drop the text in front of C(m_lo)
+        import numpy as np
+        acc = bytearray()
+        while True:
+            piece = self._stream_piece()
+            acc += piece
+            cut = self._first_record_start(np.frombuffer(acc, dtype=np.uint8), False, self._rule, not piece)
+            if cut is None:
+                continue
+            if cut < 0:                                    # no record starts in this rank's part: it reads nothing
+                self._head_newlines = acc.count(b"\n")
+                self._state = "done"
+                return b""
+            self._head_newlines = acc[:cut].count(b"\n")
+            self._state = "body"
+            rest = bytes(acc[cut:])
+            return rest if rest else self._next_piece()
+
+    def lines_before(self):
+        """lines of the file's text in front of this reader's first record (inflates the members in front of m_lo: only
+        somebody who reports a line number asks)"""
+        if self._lines_before is None:
+            n = self._head_newlines
+            if self._m_hi == self._m_lo and 0 < self._m_lo < self._size:     # an empty part lies at C(m_lo) like any other
+                n = self._scan_from(self._m_lo)[0].count(b"\n")
+            if self._m_lo > 0:
+                reader = BgzfReader(_LimitedRaw(self.name, 0, self._m_lo), self.name, self._n_threads)
+                try:
+                    while True:
+                        piece = reader._next_piece()
+                        if not piece:
+                            break
+                        n += piece.count(b"\n")
+                finally:
+                    reader.close()
+            self._lines_before = n
+        return self._lines_before
+
+    def close(self):
+        if self._body is not None:
+            self._body.close()
+            self._body = None
 
 
 class AheadGzipReader(_AheadReader):
@@ -294,10 +450,19 @@ class AheadGzipReader(_AheadReader):
         self._raw.close()
 
 
-def open_gzip_for_reading(filename, n_threads=None):
-    """``gzip.open(filename, "rb")`` for the chunk reader: BGZF -> thread pool, anything else -> one thread ahead"""
+def is_bgzf(filename):
+    with open(filename, "rb") as raw:
+        return _bgzf_block_size(raw.read(64)) is not None
+
+
+def open_gzip_for_reading(filename, n_threads=None, shard=None, rule=None):
+    """``gzip.open(filename, "rb")`` for the chunk reader: BGZF -> thread pool, anything else -> one thread ahead.
+    shard, rule: (BGZF only) one rank's part of the text (io/sharding.py: Shard, RecordRule)."""
     if n_threads is None:
         n_threads = int(os.environ.get("BNPK_INFLATE_THREADS", min(16, os.cpu_count() or 1)))
+    if shard is not None:
+        assert is_bgzf(filename), "only BGZF files can be entered in the middle"
+        return BgzfShardReader(filename, n_threads, shard, rule)
     raw = open(filename, "rb")
     head = raw.read(64)
     raw.seek(0)

@@ -4,9 +4,10 @@ from ..streams import NpDataclassStream
 
 
 class NpDataclassReader:
-    def __init__(self, numpyfilereader, lazy=None):
+    def __init__(self, numpyfilereader, lazy=None, shard=None):
         self._reader = numpyfilereader
         self._lazy = lazy
+        self._shard = shard                # io.sharding.Shard: this reader reads one rank's part of the file
 
     def __enter__(self):
         return self
@@ -31,7 +32,7 @@ class NpDataclassReader:
 
     def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
         """all complete entries of the next >= min_chunk_size bytes (npdataclassreader.py:60-92)"""
-        n_lines_read = self._reader.n_lines_read
+        n_lines_read = self._reader.lines_before_chunk()
         chunk = self._reader.read_chunk(min_chunk_size, max_chunk_size)
         if chunk is None:
             return self._reader._buffer_type.dataclass.empty()
@@ -44,7 +45,7 @@ class NpDataclassReader:
     def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
         def chunks():                                  # the file reader's own generator: it reads ahead for big batches
             for chunk in self._reader.read_chunks(min_chunk_size, max_chunk_size):
-                n_lines_read = self._reader.n_lines_read - chunk.n_lines
+                n_lines_read = self._reader.lines_before_chunk(chunk.n_lines)
                 try:
                     wrapped = self._wrap(chunk, n_lines_read)
                 except FormatException as e:
@@ -56,7 +57,7 @@ class NpDataclassReader:
         def again(bigger):                                # (streams.NpDataclassStream._coalesced: before anything was read)
             return self.read_chunks(max(bigger, min_chunk_size), max_chunk_size)._stream
         return NpDataclassStream(chunks(), dataclass=self._reader._buffer_type.dataclass,
-                                 rebatch=again if max_chunk_size is None else None)
+                                 rebatch=again if max_chunk_size is None else None, shard=self._shard)
 
     def __iter__(self):
         return self.read_chunks()

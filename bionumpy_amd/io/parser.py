@@ -156,8 +156,34 @@ class _EarlyUpload:
         return HArray(dev=t)
 
 
+class _LinesBefore:
+    """the lines of the file in front of a chunk — those this reader has read so far (known) plus those in front of the part
+    of the file it reads (counted, once, if anybody ever adds this to a line number: only exceptions do)"""
+
+    def __init__(self, local, reader):
+        self._local, self._reader = int(local), reader
+
+    def __int__(self):
+        return self._local + self._reader.lines_before_range()
+
+    __index__ = __int__
+
+    def __radd__(self, other):
+        return other + int(self)
+
+    __add__ = __radd__
+
+
 class NumpyFileReader:
-    def __init__(self, file_obj, buffer_type, has_header=False):
+    _start, _stop, _chunk_modulo, _lines_before, _lines_before_value = 0, None, None, None, None     # (a reader of a whole file)
+
+    def __init__(self, file_obj, buffer_type, has_header=False, byte_range=None, chunk_modulo=None, lines_before=None):
+        """byte_range: (start, stop) — the reader's file is bytes [start, stop) of the plain file ``file_obj`` (a rank's part
+        of a sharded file, cut at record starts: io/sharding.py); behind ``stop`` the file is over for this reader.
+        chunk_modulo: (r, n) — ``read_chunks`` yields only the chunks i with i % n == r (the shard of a stream that cannot
+        be entered in the middle: a single-member gzip); the others are read and skipped.
+        lines_before: () -> lines of the file in front of this reader's part, for readers of other things than plain byte
+        ranges (BGZF shards); evaluated at most once, and only if a line number is asked for."""
         self._file_obj = file_obj
         self._buffer_type = buffer_type
         self._has_header = has_header
@@ -173,7 +199,48 @@ class NumpyFileReader:
         self._ahead_threads = []
         self._window_held = 0              # windowed read_chunks: bytes the reference's reader would hold behind the last chunk
         self.n_bytes_read = 0
-        self.n_lines_read = 0
+        self._n_lines_local = 0            # lines of the chunks this reader has handed out
+        self._start, self._stop = 0, None
+        self._chunk_modulo = chunk_modulo
+        self._lines_before = lines_before
+        self._lines_before_value = None
+        if byte_range is not None:
+            self._start, self._stop = int(byte_range[0]), int(byte_range[1])
+            self._file_obj.seek(self._start)
+
+    # -- the part of the file this reader reads (io/sharding.py) ---------------------------------------------------------
+    def lines_before_range(self):
+        """lines of the file in front of this reader's first byte (0 for a reader of the whole file); counted on first use"""
+        if self._lines_before_value is None:
+            if self._lines_before is not None:
+                self._lines_before_value = int(self._lines_before())
+            elif self._start > 0:
+                import ctypes as C
+                from .._native import lib, check
+                found = C.c_int64(0)
+                check(lib.bnpk_count_byte_file(self._file_obj.fileno(), 0, self._start, NEWLINE, max(1, _READ_THREADS), C.byref(found)))
+                self._lines_before_value = int(found.value)
+            else:
+                self._lines_before_value = 0
+        return self._lines_before_value
+
+    @property
+    def n_lines_read(self):
+        """lines of the file up to the end of the last chunk handed out — counted from the start of the FILE, also by a reader
+        of a part of it (parser.py:141-143: what FormatException.line_number is relative to)"""
+        return self._n_lines_local + self.lines_before_range()
+
+    def lines_before_chunk(self, chunk_lines=0):
+        """the line number of the first line of the chunk handed out last (``chunk_lines`` = its lines), as a number that is
+        only worked out when somebody adds it to something"""
+        if self._start == 0 and self._lines_before is None:
+            return self._n_lines_local - chunk_lines
+        return _LinesBefore(self._n_lines_local - chunk_lines, self)
+
+    def _end_of_data(self):
+        """first byte this reader does not read (plain files)"""
+        size = os.fstat(self._file_obj.fileno()).st_size
+        return size if self._stop is None else min(size, self._stop)
 
     # -- the reference's surface ---------------------------------------------------------------------------------
     def __enter__(self):
@@ -215,7 +282,7 @@ class NumpyFileReader:
 
     def read(self):
         """the whole file as one buffer (parser.py:89-94)"""
-        raw = self._file_obj.read()
+        raw = self._file_obj.read() if self._stop is None else self._file_obj.read(max(0, self._stop - self._file_obj.tell()))
         if len(raw) == 0:
             return None
         batch = np.empty(len(raw) + 2, dtype=np.uint8)
@@ -224,6 +291,15 @@ class NumpyFileReader:
         return self._buffer_type.from_raw_buffer(batch[:n], header_data=self._header_data)
 
     def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
+        if self._chunk_modulo is not None:
+            r, n = self._chunk_modulo
+            for i, chunk in enumerate(self._read_chunks(min_chunk_size, max_chunk_size)):
+                if i % n == r:
+                    yield chunk
+            return
+        yield from self._read_chunks(min_chunk_size, max_chunk_size)
+
+    def _read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
         if _READ_AHEAD and min_chunk_size >= _BIG and self._plain_file() and not self._stream_mode:
             yield from self._read_chunks_ahead(min_chunk_size, max_chunk_size)
             return
@@ -272,7 +348,7 @@ class NumpyFileReader:
         depth = min(2, _READ_DEPTH) if placed else 1
         f = self._file_obj
         next_pos = f.tell()
-        file_size = os.fstat(f.fileno()).st_size if placed else 0
+        file_size = self._end_of_data() if placed else 0
 
         def start():
             # the staging buffer is taken here, by the caller's thread: making sure that no copy out of it is in flight
@@ -356,7 +432,7 @@ class NumpyFileReader:
                     # what lies behind the piece is the left-over from now on: a caller who stops here finds it again
                     held = batch[end:]
                     self.n_bytes_read += buff.size
-                    self.n_lines_read += buff.n_lines
+                    self._n_lines_local += buff.n_lines
                     yield buff
                 if self._is_finished:                        # (a finished file's tail without a complete entry is dropped)
                     held = np.zeros(0, dtype=np.uint8)
@@ -475,7 +551,7 @@ class NumpyFileReader:
         if not self._is_finished:
             self._left_over = batch[buff.size:]
         self.n_bytes_read += buff.size
-        self.n_lines_read += buff.n_lines
+        self._n_lines_local += buff.n_lines
         return buff
 
     # -- mechanism ---------------------------------------------------------------------------------------------------
@@ -512,7 +588,7 @@ class NumpyFileReader:
             return None
         f = self._file_obj
         fd, pos = f.fileno(), f.tell()
-        want = min(target.size, os.fstat(fd).st_size - pos)
+        want = min(target.size, self._end_of_data() - pos)
         if want <= 0:
             return 0
         import ctypes as C
@@ -554,6 +630,8 @@ class NumpyFileReader:
         got = self._fill_parallel(target, upload)
         if got is not None:
             return -got if upload is not None else got
+        if self._stop is not None:                           # (a part of a plain file: it ends at ``stop``)
+            target = target[:max(0, min(target.size, self._stop - self._file_obj.tell()))]
         if not hasattr(self._file_obj, "readinto"):
             raw = self._file_obj.read(target.size)
             target[:len(raw)] = np.frombuffer(raw, dtype=np.uint8)
@@ -573,5 +651,5 @@ class NumpyFileReader:
         except IncompleteEntryException:
             return None
         except FormatException as e:
-            e.line_number += self.n_lines_read
+            e.line_number += self.n_lines_read               # (counted from the start of the file, also for a part of it)
             raise

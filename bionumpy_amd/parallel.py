@@ -35,6 +35,7 @@ from .ops import get_ops
 FINE_BITS = 8          # partition granularity: 256 fine buckets, contiguous groups of them per rank
 KEY_GROUPS = 4         # plan "keys": steps the exchange is cut into (the parts of a rank's key range), overlapped with the counting
 PROBE_KEYS = 4 << 20              # keys of one fine bucket that a rank counts to estimate the ratio
+PROBE_LOG = __import__("os").environ.get("BNPK_PLAN_LOG", "0") != "0"     # the probe and the plan it chose, on stderr
 
 
 def _dist():
@@ -179,13 +180,18 @@ class AbiCollectives:
             if int(probe.item()) != self.world:
                 raise RuntimeError("bnpk_allreduce_hist over %d ranks returned %d" % (self.world, int(probe.item())))
 
-        def can_make():                                  # (loads RCCL: bnpk_comm_unique_id needs nothing else)
-            return lib.bnpk_comm_unique_id((C.c_uint8 * 128)()) == 0
+        def can_make():                                  # (RCCL loads: dlopen + dlsym — an id is only ever taken by rank 0, once)
+            return lib.bnpk_comm_available() == 1
 
         agree_on_communicator(group, take_id, make, self.close, self.dev.tdev if dist.get_backend(group) == "nccl" else "cpu",
                               can_make=can_make)
         import atexit
-        atexit.register(self.close)
+        import weakref
+        ref = weakref.ref(self)                          # (the hook must not keep every communicator ever made alive)
+        atexit.register(lambda: ref() is not None and ref().close())
+
+    def __del__(self):
+        self.close()
 
     def close(self):
         """ncclCommDestroy of the communicator this object made (at exit, or when the ranks agree not to use it)"""
@@ -256,6 +262,48 @@ def collectives(group=None):
     return _collectives[key]
 
 
+def group_is_up():
+    """a torch.distributed process group with more than one rank has been initialised in this process"""
+    try:
+        dist = _dist()
+        return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    except Exception:                                    # noqa: BLE001
+        return False
+
+
+def all_gather_objects(obj, group=None):
+    """[every rank's ``obj``] in rank order (small host objects: torch.distributed.all_gather_object)"""
+    dist = _dist()
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def allgather_runs(keys, counts, group=None):
+    """every rank's (keys, counts) run, one behind the other in rank order, on every rank (torch.distributed.all_gather of
+    runs padded to the longest: the gather of a range-partitioned histogram — not on the counting path)"""
+    import torch
+    ops, dist = get_ops(), _dist()
+    world = dist.get_world_size(group)
+    host = getattr(ops, "host_only", False) or dist.get_backend(group) != "nccl"
+    as_t = (lambda h: torch.from_numpy(np.ascontiguousarray(h.host()))) if host else (lambda h: h.dev())
+    n = torch.tensor([keys.size], dtype=torch.int64, device="cpu" if host else as_t(keys).device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(x.item()) for x in sizes]
+    longest = max(max(sizes), 1)
+    out = []
+    for h in (keys, counts):
+        t = as_t(h)
+        padded = torch.zeros(longest, dtype=torch.int64, device=t.device)
+        padded[:t.numel()] = t
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+        joined = torch.cat([p[:m] for p, m in zip(parts, sizes)])
+        out.append(HArray(host=joined.numpy()) if host else HArray(dev=joined))
+    return out[0], out[1]
+
+
 def allreduce_dense(hist, group=None):
     """sum of dense histograms over all ranks (EncodedCounts.__add__ across GPUs)"""
     return collectives(group).allreduce_sum(hist)
@@ -281,18 +329,23 @@ SKETCH_SAMPLE = 256               # ... over the distinct keys whose mixed hash 
 _MIX = np.uint64(0x9E3779B97F4A7C15)
 
 
-def probe_ratio(part, cuts, key_bits, rank=0):
-    """(distinct, total, sketch) of one fine bucket of this rank's k-mers (at most PROBE_KEYS of them) — the SAME bucket on
-    every rank, so that what the ranks found can be put together: the sketch marks, for a hash-chosen 1/SKETCH_SAMPLE of the
-    distinct keys, one of SKETCH_SLOTS slots each; summed over the ranks, the number of marked slots gives the number of
-    distinct keys of the bucket in the whole job (linear counting), i.e. how far the runs of the "counts" plan shrink when
-    they are merged"""
+def probe_bucket(sizes_sum):
+    """the fine bucket every rank probes: the fullest one of the job (``sizes_sum`` = the ranks' bucket sizes added up), so
+    that all sketches cover the same key range and can be summed"""
+    return int(np.argmax(sizes_sum))
+
+
+def probe_ratio(part, cuts, key_bits, bucket):
+    """(distinct, total, sketch) of fine bucket ``bucket`` of this rank's k-mers (at most PROBE_KEYS of them) — the SAME
+    bucket on every rank (probe_bucket), so that what the ranks found can be put together: the sketch marks, for a
+    hash-chosen 1/SKETCH_SAMPLE of the distinct keys, one of SKETCH_SLOTS slots each; summed over the ranks, the number of
+    marked slots gives the number of distinct keys of the bucket in the whole job (linear counting), i.e. how far the runs
+    of the "counts" plan shrink when they are merged.  A rank that holds nothing of the bucket contributes (0, 0, empty)."""
     ops = get_ops()
     sketch = np.zeros(SKETCH_SLOTS, dtype=np.int64)
-    sizes = np.diff(cuts)
-    if sizes.sum() == 0:
+    b = int(bucket)
+    if cuts[b + 1] == cuts[b]:
         return 0, 0, sketch
-    b = int(np.argmax(sizes > 0)) if sizes[37 % sizes.size] == 0 else 37 % sizes.size   # (bucket 37 unless this rank has nothing there)
     a, e = int(cuts[b]), int(min(cuts[b + 1], cuts[b] + PROBE_KEYS))
     sample = _slice(part, a, e)
     sample = HArray(dev=sample.dev().clone()) if sample.on_device else HArray(host=sample.host().copy())
@@ -507,10 +560,16 @@ def count_sparse_distributed(hashes, key_bits, group=None, cuts=None, plan="auto
         hashes, cuts_np = ops.partition_by_top_bits(hashes, key_bits, FINE_BITS)
         cuts = HArray(host=np.asarray(cuts_np, dtype=np.int64))
     if plan == "auto":
-        d, t, sketch = probe_ratio(hashes, np.asarray(cuts.host(), dtype=np.int64), key_bits, coll.rank)
+        cuts_np = np.asarray(cuts.host(), dtype=np.int64)
+        sizes = coll.allreduce_sum(HArray(host=np.diff(cuts_np).astype(np.int64))).host()     # which bucket: agreed by all ranks
+        bucket = probe_bucket(sizes)
+        d, t, sketch = probe_ratio(hashes, cuts_np, key_bits, bucket)
         both = coll.allreduce_sum(HArray(host=np.concatenate([[d, t], sketch]).astype(np.int64))).host()
         plan = choose_plan(int(both[0]), int(both[1]), coll.world, global_distinct(both[2:]))
-        last["probe"] = {"distinct_local_sum": int(both[0]), "total": int(both[1]), "distinct_global_estimate": float(global_distinct(both[2:]))}
+        last["probe"] = {"bucket": bucket, "distinct_local_sum": int(both[0]), "total": int(both[1]),
+                         "distinct_global_estimate": float(global_distinct(both[2:]))}
+        if PROBE_LOG:
+            sys.stderr.write("bionumpy_amd.parallel: probe %r -> plan %s\n" % (last["probe"], plan))
     last["plan"], last["collectives"] = plan, coll.name
     if plan == "counts":
         keys, counts = ops.count_sparse(hashes, key_bits=key_bits, consume=True, partition=(cuts, FINE_BITS))
@@ -540,11 +599,13 @@ def count_sparse_virtual(shards, key_bits, plan="auto", groups=None):
     if plan == "auto":
         d = t = 0
         sketch = np.zeros(SKETCH_SLOTS, dtype=np.int64)
-        for r, ((part, _), c) in enumerate(zip(shards, cuts)):
-            dr, tr, sr = probe_ratio(part, c, key_bits, r)
+        bucket = probe_bucket(sum(np.diff(c) for c in cuts))
+        for (part, _), c in zip(shards, cuts):
+            dr, tr, sr = probe_ratio(part, c, key_bits, bucket)
             d, t, sketch = d + dr, t + tr, sketch + sr
         plan = choose_plan(d, t, world, global_distinct(sketch))
-        last["probe"] = {"distinct_local_sum": int(d), "total": int(t), "distinct_global_estimate": float(global_distinct(sketch))}
+        last["probe"] = {"bucket": bucket, "distinct_local_sum": int(d), "total": int(t),
+                         "distinct_global_estimate": float(global_distinct(sketch))}
     out, received = [], []
     if plan == "counts":
         local = [ops.count_sparse(part, key_bits=key_bits, partition=(c, FINE_BITS)) for part, c in shards]   # (c: the HArray)

@@ -56,6 +56,25 @@ class EncodedCounts:
         kwargs = {k: v.counts if isinstance(v, EncodedCounts) else v for k, v in kwargs.items()}
         return self.__class__(self.alphabet, ufunc(*arrays, **kwargs))
 
+    def _merge_descriptor(self):
+        """what a rank that read nothing needs to join the merge with an empty result of this kind (streams._merged_over_ranks)"""
+        return (self.__class__, list(self.alphabet), tuple(np.shape(self.counts)), str(np.asarray(self.counts).dtype))
+
+    @classmethod
+    def _empty_like_descriptor(cls, d):
+        return cls(d[1], np.zeros(d[2], dtype=d[3]))
+
+    def _merged_over_ranks(self, shard):
+        """the sum of every rank's counts, on every rank (``+`` across the GPUs of a job whose ranks each read a part of the
+        file: SURVEY §8e — one all-reduce of the bins over RCCL, bnpk_allreduce_hist).  Without a process group (a shard
+        given by hand) the counts stay this rank's own."""
+        from .. import parallel
+        if not parallel.group_is_up():
+            return self
+        counts = np.ascontiguousarray(self.counts, dtype=np.int64)
+        total = parallel.allreduce_dense(HArray(host=counts.reshape(-1).copy()), shard.group).host().reshape(counts.shape)
+        return self.__class__(self.alphabet, total.astype(self.counts.dtype, copy=False), self.row_names)
+
     @property
     def proportions(self):
         s = self.counts.sum(axis=-1, keepdims=True)
@@ -104,8 +123,12 @@ class SparseKmerCounts:
     PENDING_LIMIT = 1 << 29            # uncounted hashes a histogram holds at most (4 GiB)
     LAZY_MAX = 1 << 26                 # inputs up to this many hashes are counted lazily (larger ones: at once)
 
-    def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=62, n_pending=None):
+    def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=None, n_pending=None, key_range=None):
         self.encoding = encoding
+        self.key_range = key_range         # (lo, hi): this object holds the keys of [lo, hi) only — one rank's part of a histogram
+                                           # that is partitioned by key range over the ranks of a job (_merged_over_ranks)
+        if key_bits is None:               # what the encoding's hashes need (2k for the 2-bit alphabets), not the widest key
+            key_bits = _key_bits_of(encoding)
         as_h = lambda x: x if isinstance(x, HArray) else HArray(host=np.asarray(x, dtype=np.int64))
         self._k = None if keys is None else as_h(keys)
         self._c = None if counts is None else as_h(counts)
@@ -170,8 +193,9 @@ class SparseKmerCounts:
                 k, c = get_ops().merge_add(self._k, self._c, other._k, other._c)
             else:
                 k, c = (self._k, self._c) if (self._k is not None and self._k.size) else (other._k, other._c)
-            out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, max(self._key_bits, other._key_bits),
-                                   self._n_pend + other._n_pend)
+            # (the width of the keys comes from the operands that still have hashes to count)
+            bits = max([x._key_bits for x in (self, other) if x._pending])
+            out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, bits, self._n_pend + other._n_pend)
             if out._n_pending() >= self.PENDING_LIMIT:
                 out._force()
             return out
@@ -179,6 +203,38 @@ class SparseKmerCounts:
         return SparseKmerCounts(self.encoding, keys, counts)
 
     __radd__ = __add__
+
+    def _merge_descriptor(self):
+        return (self.__class__, self.encoding, self._key_bits)
+
+    @classmethod
+    def _empty_like_descriptor(cls, d):
+        return cls(d[1], key_bits=d[2])
+
+    def _merged_over_ranks(self, shard):
+        """this rank's part of the histogram of ALL ranks' k-mers: the 2k-bit key space is cut into one range per rank and
+        rank r returns the sorted distinct keys of range r with their counts summed over the job (``key_range`` says which) —
+        the ranks' results, one behind the other, are the histogram of the whole file (the result stays
+        range-partitioned; ``gathered()`` puts it together where somebody needs it in one place).  What crosses the links is
+        what this rank counted (16 bytes per locally distinct key: parallel.exchange_counted), summed on arrival by a tree
+        of merges.  Without a process group (a shard given by hand) nothing is exchanged."""
+        from .. import parallel
+        if not parallel.group_is_up():
+            return self
+        self._force()
+        coll = parallel.collectives(shard.group)
+        keys, counts = parallel.exchange_counted(self._k, self._c, self._key_bits, shard.group)
+        return SparseKmerCounts(self.encoding, keys, counts, key_bits=self._key_bits,
+                                key_range=parallel.key_range_of(coll.rank, coll.world, self._key_bits))
+
+    def gathered(self, group=None):
+        """the whole histogram on every rank, from the ranks' parts (an all-gather of the (key, count) runs in rank order:
+        the ranges ascend with the ranks, so the concatenation is sorted)"""
+        from .. import parallel
+        if self.key_range is None or not parallel.group_is_up():
+            return self
+        keys, counts = parallel.allgather_runs(self._keys, self._counts, group)
+        return SparseKmerCounts(self.encoding, keys, counts, key_bits=self._key_bits)
 
     def __eq__(self, other):
         return self.encoding == other.encoding and np.array_equal(self.keys, other.keys) \
@@ -195,6 +251,15 @@ class SparseKmerCounts:
 
     def __repr__(self):
         return "SparseKmerCounts(%s, %d distinct)" % (self.encoding, len(self))
+
+
+def _key_bits_of(encoding):
+    """bits a hash of ``encoding`` (a KmerEncoding) occupies: 2k for 4-letter alphabets; 62 where it cannot be told"""
+    k = getattr(encoding, "k", None)
+    letters = getattr(getattr(encoding, "_alphabet_encoding", None), "alphabet_size", None)
+    if k is None or letters is None:
+        return 62
+    return min(62, 2 * k if letters == 4 else max(1, (letters ** k - 1).bit_length()))
 
 
 def count_encoded(values, weights=None, axis=-1):

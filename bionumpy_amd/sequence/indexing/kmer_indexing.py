@@ -54,19 +54,34 @@ class KmerIndex:
         hi = ops.search_sorted(self._keys, q, upper=True)
         return lo, hi
 
+    def count_hits(self, kmers):
+        """number of indexed sequences that contain each of many int k-mers (0 for an unseen one): hi - lo of
+        ``get_indices_batch``, on the device for device queries.  With the index built on every rank from a file opened with
+        ``shard=False`` and the queries taken from a file every rank reads its own part of (``bnp.open``'s default in a
+        torchrun job), this is SURVEY §8e's "replicate the index, shard the lookups": no exchange at all."""
+        lo, hi = self.get_indices_batch(kmers)
+        if lo.on_device:
+            return HArray(dev=hi.dev() - lo.dev())
+        return hi.host() - lo.host()
+
+    @staticmethod
+    def _part(h, lo, hi):
+        """h[lo:hi] on the host — only those elements cross the link"""
+        return HArray(dev=h.dev()[lo:hi]).host() if h.on_device else h.host()[lo:hi]
+
     def get_indices(self, kmer):
         lo, hi = self.get_indices_batch(np.array([self._encode_query(kmer)], dtype=np.int64))
         lo, hi = int(lo.host()[0]), int(hi.host()[0])
         if hi == lo:
             return []
-        return self._rows.host()[lo:hi]
+        return self._part(self._rows, lo, hi)
 
     def get_indices_with_repeats(self, kmer):
         """the row of every occurrence of the k-mer, in row order (needs ``multiplicities=True``)"""
         assert self._counts is not None, "create_index(..., multiplicities=True)"
         lo, hi = self.get_indices_batch(np.array([self._encode_query(kmer)], dtype=np.int64))
         lo, hi = int(lo.host()[0]), int(hi.host()[0])
-        return np.repeat(self._rows.host()[lo:hi], self._counts.host()[lo:hi])
+        return np.repeat(self._part(self._rows, lo, hi), self._part(self._counts, lo, hi))
 
 
 class KmerLookup:

@@ -26,11 +26,12 @@ class NpDataclassStream(BnpStream):
     entries, usable while nothing has been taken from this stream.  A reduction that does not depend on where the chunks
     are cut (``streamable(sum)`` over histograms) asks for batches sized for the device instead of the reference's 5 MB."""
 
-    def __init__(self, stream, dataclass=None, rebatch=None):
+    def __init__(self, stream, dataclass=None, rebatch=None, shard=None):
         super().__init__(stream)
         self.dataclass = dataclass
         self._rebatch = rebatch
         self._started = False
+        self._shard = shard                # io.sharding.Shard: the chunks are ONE rank's part of a file read by several ranks
 
     def __next__(self):
         self._started = True
@@ -41,7 +42,7 @@ class NpDataclassStream(BnpStream):
         if self._rebatch is None or self._started:
             return self
         self._started = True                                 # (the entries are handed out through the new stream from now on)
-        return NpDataclassStream(self._rebatch(min_chunk_size), self.dataclass)
+        return NpDataclassStream(self._rebatch(min_chunk_size), self.dataclass, shard=self._shard)
 
     def __getattr__(self, name):
         if name.startswith("_"):
@@ -55,6 +56,7 @@ class _FieldStream(BnpStream):
     def __init__(self, parent, name):
         super().__init__(getattr(chunk, name) for chunk in parent)
         self._parent, self._name = parent, name
+        self._shard = getattr(parent, "_shard", None)
 
     def _coalesced(self, min_chunk_size):
         again = self._parent._coalesced(min_chunk_size)
@@ -105,9 +107,32 @@ class streamable:
 
             if reduction is None:
                 return BnpStream(results())
-            return reduction(results())
+            reduced = reduction(results())
+            # the stream was one rank's part of a file that several ranks read (bnp.open(..., shard=...), io/sharding.py): what
+            # the ranks reduced is put together — the sum of the chunks' histograms of ALL ranks is what the reference's loop
+            # over the whole file returns (EncodedCounts.__add__ across GPUs: SURVEY §8e)
+            shards = [v._shard for v in list(args) + list(kwargs.values()) if getattr(v, "_shard", None) is not None]
+            if shards:
+                reduced = _merged_over_ranks(reduced, shards[0])
+            return reduced
 
         return wrapped
+
+
+def _merged_over_ranks(reduced, shard):
+    """what every rank reduced from its part of a file, put together (collective: every rank of the shard's group gets here,
+    also one whose part held no entry — its ``sum`` of nothing is the int 0, so the ranks first tell each other what they
+    hold, and a rank without a result joins the merge with an empty one of the others' kind)"""
+    from . import parallel
+    if not parallel.group_is_up():
+        return reduced                                       # (a shard given by hand, no process group: the caller merges)
+    mine = reduced._merge_descriptor() if hasattr(reduced, "_merge_descriptor") else None
+    proto = next((d for d in parallel.all_gather_objects(mine, shard.group) if d is not None), None)
+    if proto is None:
+        return reduced                                       # nothing that merges on any rank (plain numbers, arrays: as they are)
+    if mine is None:
+        reduced = proto[0]._empty_like_descriptor(proto)
+    return reduced._merged_over_ranks(shard)
 
 
 # ---- streamable numpy reductions (bionumpy/streams/reductions.py:1-63): per chunk, then joined ---------------------------------
@@ -155,7 +180,7 @@ def mean(array, axis=None):
     if axis is not None and axis != 0:
         return _row_mean(array, axis)
     t = _sum_and_n(array, axis=axis)
-    return t[:-1] / t[-1] if axis == 0 else t[0] / t[1]
+    return t[:-1] / t[-1]                                  # (a 1-element array for axis=None, as reductions.py:41-57 returns it)
 
 
 def quantile(array, quantiles, axis=None):

@@ -80,6 +80,7 @@ int         bnpk_device_info(bnpk_ctx* ctx, char* name64, int* compute_units, in
  *                               scattered in its partitioned array.  A caller runs step j + 1 on a stream of its own while
  *                               it counts what step j delivered (bionumpy_amd/parallel.py: plan "keys", groups > 1). */
 #define BNPK_COMM_ID_BYTES 128
+int bnpk_comm_available(void);          /* 1 if RCCL loads in this process (dlopen + dlsym; creates nothing), else 0 */
 int bnpk_comm_unique_id(uint8_t* id128);
 int bnpk_comm_init(bnpk_ctx* ctx, const uint8_t* id128, int n_ranks, int rank, void** comm_out);
 int bnpk_comm_destroy(void* comm);
@@ -137,6 +138,10 @@ int bnpk_copy_d2h_async(void* h_dst, const void* d_src, size_t bytes, void* stre
  * `bytes` only at the end of the file).  Synchronous for the reads, asynchronous for the copies. */
 int bnpk_pread_parallel(bnpk_ctx* ctx, int fd, int64_t file_offset, void* h_dst, int64_t bytes, int n_threads, int64_t piece_bytes,
                         void* d_dst, void* stream, int64_t* h_read);
+/* np.count_nonzero(file[file_offset:file_offset + bytes] == byte) straight from the open file `fd` (n_threads preads):
+ * the lines in front of a reader that begins in the middle of a file — what keeps FormatException.line_number and
+ * n_lines_read counted from the start of the file (bionumpy/io/parser.py:141-143) when the file is sharded over ranks. */
+int bnpk_count_byte_file(int fd, int64_t file_offset, int64_t bytes, uint8_t byte, int n_threads, int64_t* h_count);
 int bnpk_stream_sync(void* stream);
 /* the first n (<= 4096) words of a device array, on the host: one hipMemcpyAsync into a page-locked mailbox of the ctx behind
  * everything enqueued on `stream`, one hipStreamSynchronize — how the host scalars of the chunk loop (totals, error cells,

@@ -47,3 +47,14 @@ def test_bench_virtual_ranks_line():
     d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert d["virtual_ranks"] == 4 and len(d["int64_words_received_per_rank"]) == 4 and d["plan"] == "keys"
     assert sum(d["int64_words_received_per_rank"]) == 400000 * 120
+
+
+def test_bench_from_file_line(tmp_path):
+    """--from-file: the reader's stream form over a FASTQ file it writes first; reads add up, checksums match"""
+    path = str(tmp_path / "reads.fq")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--from-file", path, "--reads", "300000", "--steps", "1",
+                          "--warmup", "1", "--file-chunk-mb", "32"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert d["reads_seen_by_all_ranks"] == 300000 and d["reads_add_up"] is True and d["parity_fullsize"] is True
+    assert d["file_bytes"] == 300000 * 316 and d["gbases_per_s"] > 0
