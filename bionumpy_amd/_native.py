@@ -125,6 +125,9 @@ SIGNATURES = {
     "bnpk_pwm_scores": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "bnpk_kmers_partition": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
     "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),
+    "bnpk_count_bytes": (_int, [_p, _p, _i64, _int, _p, _p]),
+    "bnpk_count_packed2": (_int, [_p, _p, _i64, _p, _p]),
+    "bnpk_count_bytes_rows": (_int, [_p, _p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_count_dense": (_int, [_p, _p, _i64, _i64, _p, _p]),
     "bnpk_count_dense_rows": (_int, [_p, _p, _p, _i64, _i64, _i64, _p, _p]),
     "bnpk_count_weighted": (_int, [_p, _p, _p, _int, _i64, _i64, _i64, _i64, _i64, _p, C.POINTER(_int), _p]),

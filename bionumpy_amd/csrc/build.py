@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbnpk.so")
 OBJ_DIR = os.path.join(HERE, "build")
 SOURCES = ["api.hip", "scan.hip", "decode.hip", "multiline.hip", "fastq.hip", "encode.hip", "kmers.hip", "revcomp.hip", "rowops.hip", "radix.hip", "finish.hip", "finish_dup.hip", "finish_wave.hip", "finish_multi.hip", "merge.hip", "count.hip", "synth.hip", "collectives.hip"]
+LINT = os.path.join(HERE, "isa_lint.py")
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"), os.path.join(HERE, "rows.h"),
            os.path.join(HERE, "kmer_gen.h"), os.path.join(HERE, "finish.h"),
            os.path.join(ROOT, "include", "bnpk.h")]
@@ -89,11 +90,27 @@ def build(force=False, verbose=True):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if os.environ.get("BNPK_SKIP_ISA_LINT", "0") == "0":
+        _lint(objs, verbose)                             # (raises: a library with a finding gets no stamp and is rebuilt next time)
     with open(stamp, "w") as f:
         f.write(digest + "\n")
     if verbose:
         print("built", LIB)
     return LIB
+
+
+def _lint(objs, verbose):
+    """the ISA lint over the device code of every object (isa_lint.py: a load's destination touched before its s_waitcnt;
+    an S_CSELECT on the SCC of scalar arithmetic across a 64-bit V_CMP) — a finding fails the build"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bnpk_isa_lint", os.path.join(HERE, "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lint)
+    findings, n_kernels, n_ins = lint.lint_objects(objs, verbose=False)
+    if findings:
+        raise RuntimeError("isa_lint: %d finding(s) in the built kernels:\n%s" % (len(findings), "\n".join(findings)))
+    if verbose:
+        print("isa_lint: %d kernels, %d instructions, 0 findings" % (n_kernels, n_ins))
 
 
 if __name__ == "__main__":

@@ -61,6 +61,167 @@ __global__ __launch_bounds__(BNPK_BLOCK) void hist_rows_kernel(const int64_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------ histograms of LETTERS (uint8 codes)
+// count_encoded / np.bincount over the codes of an encoded array (bionumpy/sequence/count_encoded.py:166-182,
+// encoded_array.py:463-466) without widening them to int64 first.  Few bins (<= 8: every alphabet of the sequence path but
+// amino acids): a lane keeps eight BYTE counters in one 64-bit register — a code c adds 1 << 8c — and spills them into
+// eight 32-bit counters every 15 vectors (15 x 16 = 240 < 256); no atomics, no LDS, ~70 vector instructions per 16 bytes.
+// A word with a byte >= 8 (never in an encoded array; the bound is checked like np.bincount's minlength would) takes the
+// byte-by-byte path.  The wave totals leave as eight 64-bit global atomics per wavefront.
+__device__ __forceinline__ void byte_counters_add(uint64_t& acc, uint32_t x, int n_bins) {
+  if (x & 0xF8F8F8F8u) {                                     // some byte is not a code below 8
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t c = (x >> (8 * j)) & 0xffu;
+      if (c < (uint32_t)n_bins) acc += 1ull << (8 * c);
+    }
+    return;
+  }
+  const uint32_t sh = (x & 0x07070707u) << 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc += 1ull << ((sh >> (8 * j)) & 0xffu);
+}
+
+__device__ __forceinline__ void byte_counters_spill(uint64_t& acc, uint32_t (&cnt)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) cnt[b] += (uint32_t)(acc >> (8 * b)) & 0xffu;
+  acc = 0;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_bytes_small_kernel(const uint8_t* __restrict__ v, int64_t n, int n_bins,
+                                                                      unsigned long long* __restrict__ hist) {
+  // [head | 16-byte vectors | tail]: the vectors start at the first 16-byte boundary of the buffer
+  const int64_t head = min<int64_t>(n, (16 - ((uintptr_t)v & 15)) & 15);
+  const int64_t n_vec = (n - head) >> 4;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t* __restrict__ vec = reinterpret_cast<const u32x4_t*>(v + head);
+  uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t acc = 0;
+  int pending = 0;
+  const int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x; i < n_vec; i += stride) {
+    const u32x4_t q = __builtin_nontemporal_load(vec + i);
+    byte_counters_add(acc, q.x, n_bins);
+    byte_counters_add(acc, q.y, n_bins);
+    byte_counters_add(acc, q.z, n_bins);
+    byte_counters_add(acc, q.w, n_bins);
+    if (++pending == 15) { byte_counters_spill(acc, cnt); pending = 0; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                 // the unaligned ends: at most 30 bytes
+    for (int64_t i = 0; i < head; ++i) {
+      if (++pending == 200) { byte_counters_spill(acc, cnt); pending = 0; }
+      if (v[i] < n_bins) acc += 1ull << (8 * v[i]);
+    }
+    for (int64_t i = head + (n_vec << 4); i < n; ++i) {
+      if (++pending == 200) { byte_counters_spill(acc, cnt); pending = 0; }
+      if (v[i] < n_bins) acc += 1ull << (8 * v[i]);
+    }
+  }
+  byte_counters_spill(acc, cnt);
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const uint32_t t = wave_reduce_sum(cnt[b]);
+    if (lane_id() == 0 && t && b < n_bins) atomicAdd(&hist[b], (unsigned long long)t);
+  }
+}
+
+// up to 256 bins: a histogram per wavefront in LDS
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_bytes_lds_kernel(const uint8_t* __restrict__ v, int64_t n, int n_bins,
+                                                                    unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int bins[BNPK_BLOCK / 64][256];
+  for (int i = threadIdx.x; i < (BNPK_BLOCK / 64) * 256; i += BNPK_BLOCK) (&bins[0][0])[i] = 0;
+  __syncthreads();
+  unsigned int* mine = bins[wave_id()];
+  const int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x; i < n; i += stride) {
+    const uint32_t c = v[i];
+    if (c < (uint32_t)n_bins) atomicAdd(&mine[c], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_bins; i += BNPK_BLOCK) {
+    unsigned long long t = 0;
+#pragma unroll
+    for (int w = 0; w < BNPK_BLOCK / 64; ++w) t += bins[w][i];
+    if (t) atomicAdd(&hist[i], t);
+  }
+}
+
+// the four letters of packed 2-bit DNA (32 bases per word): with l = the low bits and h = the high bits of the codes,
+// #3 = popc(l & h), #1 = popc(l) - #3, #2 = popc(h) - #3, and #0 is what is left of n_bases — 1.9 GB read per 50 M reads
+// instead of the 7.5 GB of their unpacked codes
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_packed2_kernel(const uint64_t* __restrict__ w, int64_t n_bases,
+                                                                  unsigned long long* __restrict__ hist) {
+  const int64_t n_words = (n_bases + 31) >> 5;
+  const int tail = (int)(n_bases & 31);
+  const int64_t stride = (int64_t)gridDim.x * BNPK_BLOCK;
+  uint64_t c1 = 0, c2 = 0, c3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * BNPK_BLOCK + threadIdx.x; i < n_words; i += stride) {
+    uint64_t x = w[i];
+    if (tail && i == n_words - 1) x &= (1ull << (2 * tail)) - 1ull;    // (whatever lies behind the last base)
+    const uint64_t l = x & 0x5555555555555555ull, h = (x >> 1) & 0x5555555555555555ull;
+    const int p3 = __popcll(l & h);
+    c3 += p3;
+    c1 += __popcll(l) - p3;
+    c2 += __popcll(h) - p3;
+  }
+  c1 = wave_reduce_sum(c1);
+  c2 = wave_reduce_sum(c2);
+  c3 = wave_reduce_sum(c3);
+  if (lane_id() == 0) {
+    if (c1) atomicAdd(&hist[1], (unsigned long long)c1);
+    if (c2) atomicAdd(&hist[2], (unsigned long long)c2);
+    if (c3) atomicAdd(&hist[3], (unsigned long long)c3);
+    // hist[0] += this wavefront's bases - c1 - c2 - c3 is added by the host call as n_bases - (the three others): one
+    // subtraction over the finished counters (hist_packed2_zero_kernel)
+  }
+}
+
+__global__ void hist_packed2_zero_kernel(unsigned long long* __restrict__ hist, const unsigned long long* __restrict__ before,
+                                         int64_t n_bases) {
+  // #0 = n_bases - (what this call added to the other three)
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    hist[0] += (unsigned long long)n_bases - ((hist[1] - before[1]) + (hist[2] - before[2]) + (hist[3] - before[3]));
+}
+
+// one histogram PER ROW of ragged uint8 codes (count_encoded(ragged, axis=-1): count_encoded.py:176-182), n_bins <= 8:
+// four lanes per row, 16 bytes per lane and step, the byte counters of the four added up by two DPP steps; the row's
+// counts leave as n_bins 64-bit stores — a row belongs to one group, nothing is atomic
+__global__ __launch_bounds__(BNPK_BLOCK) void hist_bytes_rows_kernel(const uint8_t* __restrict__ v, const int64_t* __restrict__ off,
+                                                                     int64_t n_rows, int64_t total, int n_bins,
+                                                                     int64_t* __restrict__ hist) {
+  const int q = threadIdx.x & 3;
+  const int64_t stride = (int64_t)gridDim.x * (BNPK_BLOCK / 4);
+  for (int64_t r = (int64_t)blockIdx.x * (BNPK_BLOCK / 4) + (threadIdx.x >> 2); r < ((n_rows + 15) & ~(int64_t)15); r += stride) {
+    // (all four lanes of a group — and whole wavefronts — stay in step for the shuffles: rows beyond the end are empty)
+    const int64_t s = r < n_rows ? off[r] : 0, e = r < n_rows ? off[r + 1] : 0;
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t acc = 0;
+    int pending = 0;
+    for (int64_t p = s + 16 * q; p < e; p += 64) {
+      if (p + 16 <= e && p + 16 <= total) {
+        uint4 x;
+        __builtin_memcpy(&x, v + p, 16);
+        byte_counters_add(acc, x.x, n_bins);
+        byte_counters_add(acc, x.y, n_bins);
+        byte_counters_add(acc, x.z, n_bins);
+        byte_counters_add(acc, x.w, n_bins);
+      } else {
+        for (int64_t i = p; i < e; ++i)
+          if (v[i] < n_bins) acc += 1ull << (8 * v[i]);
+      }
+      if (++pending == 15) { byte_counters_spill(acc, cnt); pending = 0; }
+    }
+    byte_counters_spill(acc, cnt);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      uint32_t t = cnt[b];
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      if (q == 0 && b < n_bins && r < n_rows) hist[r * n_bins + b] = (int64_t)t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ runs of equal keys
 constexpr int RUN_ITEMS = 8;
 constexpr int RUN_TILE = BNPK_BLOCK * RUN_ITEMS;
@@ -215,6 +376,56 @@ __global__ __launch_bounds__(BNPK_BLOCK) void hist_weighted_kernel(const int64_t
 }  // namespace
 
 extern "C" {
+
+int bnpk_count_bytes(bnpk_ctx* ctx, const uint8_t* d_values, int64_t n, int n_bins, int64_t* d_hist, void* stream) {
+  if (!ctx || n < 0 || n_bins < 1 || n_bins > 256 || !d_hist) return BNPK_ERR_ARG;
+  if (n == 0) return BNPK_OK;
+  if (!d_values) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  auto* hist = reinterpret_cast<unsigned long long*>(d_hist);
+  bnpk_timer t(ctx, "count_bytes", s);
+  if (n_bins <= 8) {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 16 * BNPK_BLOCK), (int64_t)ctx->compute_units * 8));
+    hipLaunchKernelGGL(hist_bytes_small_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_values, n, n_bins, hist);
+  } else {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n, 8 * BNPK_BLOCK), (int64_t)ctx->compute_units * 8));
+    hipLaunchKernelGGL(hist_bytes_lds_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_values, n, n_bins, hist);
+  }
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_count_packed2(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases, int64_t* d_hist4, void* stream) {
+  if (!ctx || n_bases < 0 || !d_hist4) return BNPK_ERR_ARG;
+  if (n_bases == 0) return BNPK_OK;
+  if (!d_packed) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  void* before = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, 4 * sizeof(int64_t), &before, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(before, d_hist4, 4 * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+  auto* hist = reinterpret_cast<unsigned long long*>(d_hist4);
+  const int64_t n_words = (n_bases + 31) >> 5;
+  const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_words, 4 * BNPK_BLOCK), (int64_t)ctx->compute_units * 8));
+  bnpk_timer t(ctx, "count_packed2", s);
+  hipLaunchKernelGGL(hist_packed2_kernel, dim3((unsigned)blocks), dim3(BNPK_BLOCK), 0, s, d_packed, n_bases, hist);
+  hipLaunchKernelGGL(hist_packed2_zero_kernel, dim3(1), dim3(64), 0, s, hist, (const unsigned long long*)before, n_bases);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+int bnpk_count_bytes_rows(bnpk_ctx* ctx, const uint8_t* d_values, const int64_t* d_offsets, int64_t n_rows, int64_t total,
+                          int n_bins, int64_t* d_hist, void* stream) {
+  if (!ctx || n_rows < 0 || total < 0 || n_bins < 1 || n_bins > 8 || !d_hist || !d_offsets) return BNPK_ERR_ARG;
+  if (n_rows == 0) return BNPK_OK;
+  if (total > 0 && !d_values) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "count_bytes_rows", s);
+  const int64_t blocks = ceil_div(n_rows, BNPK_BLOCK / 4);
+  hipLaunchKernelGGL(hist_bytes_rows_kernel, dim3(grid_for(blocks)), dim3(BNPK_BLOCK), 0, s, d_values, d_offsets, n_rows, total,
+                     n_bins, d_hist);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
 
 int bnpk_count_dense(bnpk_ctx* ctx, const int64_t* d_values, int64_t n, int64_t n_bins, int64_t* d_hist,
                      void* stream) {

@@ -12,6 +12,16 @@
 
 namespace {
 
+// (experiment knobs of scripts/exp/rc_repro.py — the library is built with the defaults)
+#ifndef BNPK_RCP_UNROLL
+#define BNPK_RCP_UNROLL 1                            // 1: the loop over a lane's words stays rolled (see rc_packed_kernel)
+#endif
+#ifndef BNPK_RCP_LDS_PAD
+#define BNPK_RCP_LDS_PAD 0                           // extra LDS bytes per workgroup (limits the workgroups per CU)
+#endif
+#define BNPK_PRAGMA_(x) _Pragma(#x)
+#define BNPK_PRAGMA_UNROLL(n) BNPK_PRAGMA_(unroll n)
+
 constexpr int RCP_WPL = 4;                           // output words (32 bases each) per lane of rc_packed
 constexpr int RC_TILE_WORDS = BNPK_BLOCK * RCP_WPL;
 constexpr int64_t RC_TILE_BASES = (int64_t)RC_TILE_WORDS * 32;
@@ -42,6 +52,10 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
                                                                int64_t n_tiles, uint64_t* __restrict__ out) {
   constexpr int RCP_LDS_ROWS = 1022;
   __shared__ int64_t srow[RCP_LDS_ROWS + 2];
+#if BNPK_RCP_LDS_PAD
+  __shared__ int pad_words[BNPK_RCP_LDS_PAD / 4];
+  if (total < 0) pad_words[threadIdx.x] = 1;                 // (never true: keeps the array)
+#endif
   const int64_t w0 = (int64_t)blockIdx.x * RC_TILE_WORDS;
   if (w0 * 32 >= total) {                                    // (uniform) a tile of pad words only
     for (int64_t w = w0 + threadIdx.x; w < w0 + RC_TILE_WORDS; w += BNPK_BLOCK)
@@ -64,7 +78,7 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
   // (not unrolled: hipcc 7.2 -O3 gets the unrolled form of this loop wrong — rows of workgroups from the 257th on came out
   // garbled, per lane or per wavefront, with the row offsets in LDS or in global memory alike; the rolled loop is as fast.
   // tests/test_gpu_parity.py::test_reverse_complement_kernels has a case of 12 M bases for it.)
-#pragma unroll 1
+BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
   for (int it = 0; it < RCP_WPL; ++it) {
     const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
     const int64_t p0 = w * 32;

@@ -174,6 +174,24 @@ class HArray:
             self._np = None
 
 
+def as_bool(h):
+    """a 0/1 uint8 HArray as a bool one over the same memory (flags stay where the kernel wrote them)"""
+    if h.dtype == np.bool_:
+        return h
+    if h.on_device:
+        return HArray(dev=h.dev().view(torch().bool))
+    return HArray(host=h.host().view(np.bool_))
+
+
+def as_u8(h):
+    """a bool HArray as 0/1 bytes over the same memory"""
+    if h.dtype == np.uint8:
+        return h
+    if h.on_device:
+        return HArray(dev=h.dev().view(torch().uint8))
+    return HArray(host=h.host().view(np.uint8))
+
+
 class SharedSlice(HArray):
     """a part of a device array that others hold parts of too: whoever wants to write into it makes a copy first"""
 

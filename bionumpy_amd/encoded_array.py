@@ -454,9 +454,14 @@ class EncodedArray:
             n_codes = self._n_codes()
             if n_codes and n_codes <= (1 << 26) and len(args) <= 2 and set(kwargs) <= {"minlength"} and self.ndim == 1:
                 store = self._store._unpacked() if isinstance(self._store, _PackedDna) else self._store
-                if store.dtype != np.int64:
-                    store = HArray(host=store.host().astype(np.int64))
-                hist = get_ops().count_dense(store, max(n_codes, minlength)).host()
+                if store.dtype == np.uint8:                  # letters: counted as the bytes they are
+                    hist = get_ops().count_bytes(store, min(256, max(n_codes, minlength))).host()
+                    if hist.size < max(n_codes, minlength):
+                        hist = np.concatenate([hist, np.zeros(max(n_codes, minlength) - hist.size, dtype=hist.dtype)])
+                else:
+                    if store.dtype != np.int64:
+                        store = HArray(host=store.host().astype(np.int64))
+                    hist = get_ops().count_dense(store, max(n_codes, minlength)).host()
                 used = np.flatnonzero(hist)
                 return hist[:max(minlength, int(used[-1]) + 1 if used.size else 0)].copy()     # numpy's length: max(minlength, max + 1)
             return np.bincount(args[0].raw(), *args[1:], **kwargs)
@@ -547,9 +552,15 @@ class EncodedRaggedArray(RaggedArray):
         """elementwise == against a str/EncodedArray scalar (e.g. ``sequence == "G"``) -> ragged bool array"""
         if isinstance(other, (str, EncodedArray)) and not isinstance(other, EncodedRaggedArray):
             code = as_encoded_array(other, self._encoding).raw() if isinstance(other, str) else other.raw()
-            flat = self.ravel().raw() == np.asarray(code).reshape(-1)[0]
-            return RaggedArray._from_parts(HArray(host=flat), None, self._lens, self._offsets, self._n_rows,
-                                           self._total)
+            code = int(np.asarray(code).reshape(-1)[0])
+            self._compact()
+            store = self._as_plain(self._data)
+            if store.dtype == np.uint8 and 0 <= code <= 255:     # one compare kernel; the flags stay in HBM (README.rst:38-42)
+                from .device import as_bool
+                flat = as_bool(get_ops().vec_compare(store, "==", code))
+            else:
+                flat = HArray(host=store.host() == code)
+            return RaggedArray._from_parts(flat, None, self._lens, self._offsets, self._n_rows, self._total)
         if isinstance(other, EncodedRaggedArray):
             return (self.encoding == other.encoding and np.array_equal(self.lengths, other.lengths)
                     and np.array_equal(self.ravel().raw(), other.ravel().raw()))

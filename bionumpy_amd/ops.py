@@ -588,6 +588,29 @@ class HipOps:
         self._chk(lib.bnpk_count_dense(self.ctx, ptr(values.dev()), values.size, n_bins, ptr(hist.dev()), self._s()))
         return hist
 
+    def count_bytes(self, values, n_bins, hist=None):
+        """np.bincount(values, minlength=n_bins)[:n_bins] over uint8 codes where they lie (bnpk_count_bytes)"""
+        if hist is None:
+            hist = HArray(dev=self.device.zeros(n_bins, np.int64))
+        self._chk(lib.bnpk_count_bytes(self.ctx, ptr(values.dev()), values.size, n_bins, ptr(hist.dev()), self._s()))
+        return hist
+
+    def count_packed(self, packed, n_bases, hist=None):
+        """the same over DNA packed 2 bits per base: four bins (bnpk_count_packed2)"""
+        if hist is None:
+            hist = HArray(dev=self.device.zeros(4, np.int64))
+        self._chk(lib.bnpk_count_packed2(self.ctx, ptr(packed.dev()), n_bases, ptr(hist.dev()), self._s()))
+        return hist
+
+    COUNT_BYTES_ROWS_MAX_BINS = 8
+
+    def count_bytes_rows(self, values, offsets, n_rows, total, n_bins):
+        """one histogram per row of ragged uint8 codes, [n_rows * n_bins] int64 (bnpk_count_bytes_rows; n_bins <= 8)"""
+        hist = self._empty(n_rows * n_bins, np.int64)
+        self._chk(lib.bnpk_count_bytes_rows(self.ctx, ptr(values.dev()), ptr(offsets.dev()), n_rows, total, n_bins, ptr(hist),
+                                            self._s()))
+        return HArray(dev=hist)
+
     def count_dense_rows(self, values, offsets, n_rows, n_bins):
         hist = self.device.zeros(n_rows * n_bins, np.int64)
         self._chk(lib.bnpk_count_dense_rows(self.ctx, ptr(values.dev()), ptr(offsets.dev()), n_rows, values.size,

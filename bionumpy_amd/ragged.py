@@ -14,7 +14,7 @@ conveniences that pull what they need.
 """
 import numpy as np
 
-from .device import HArray, as_harray
+from .device import HArray, as_harray, as_u8
 from .ops import get_ops
 
 
@@ -211,10 +211,9 @@ class RaggedArray:
         from .device_vector import DeviceVector             # one value per row, left in HBM (device_vector.py)
         dtype = np.dtype(self.dtype)
         if dtype in (np.dtype(np.uint8), np.dtype(np.bool_)):
-            data = self._data if dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
-            out = get_ops().row_reduce_u8(data, self.offsets(), self._n_rows, want=(what,))[what]
+            out = get_ops().row_reduce_u8(as_u8(self._data), self.offsets(), self._n_rows, want=(what,))[what]
             if dtype == np.bool_ and what != "sum":
-                return out.host().astype(bool)
+                return DeviceVector(out, np.bool_)
             return DeviceVector(out)
         # everything else is reduced as int64 or float64 (k-mer hashes, motif scores): bnpk_row_reduce_wide
         data = self._flat_data()
@@ -248,8 +247,7 @@ class RaggedArray:
             np.add.at(sums, cols, values)
             return sums, np.bincount(cols, minlength=n_cols).astype(np.int64)
         self._compact()
-        data = self._data if self.dtype == np.uint8 else HArray(host=self._data.host().view(np.uint8))
-        sums, counts = get_ops().col_sums_u8(data, self.offsets(), self._n_rows, self.total(), n_cols)
+        sums, counts = get_ops().col_sums_u8(as_u8(self._data), self.offsets(), self._n_rows, self.total(), n_cols)
         return sums.host(), counts.host()
 
     def _flat_values(self):
@@ -263,9 +261,64 @@ class RaggedArray:
         if axis not in (None, 0, 1, -1):
             raise ValueError("axis %r of a ragged (two-dimensional) array" % (axis,))
 
+    def _n_true(self):
+        """number of set flags of a compact bool array, counted on the device (bnpk_byte_census)"""
+        self._compact()
+        return int(get_ops().mask_rows(as_u8(self._data))[1]) if self.total() else 0
+
+    def _any_empty_row(self):
+        """is there a row without an element?  (asked on the device where the lengths live there)"""
+        lens = self._lens
+        if getattr(lens, "on_device", False) and self._n_rows:
+            from .device_vector import DeviceVector
+            d = lens.dev()
+            return bool((DeviceVector(HArray(dev=d)) == 0).any())
+        return bool(np.any(self.lengths == 0))
+
+    def any(self, axis=-1):
+        """np.any: per row (axis -1; an empty row gives False), per column (0) or over everything (None) — flags are
+        reduced where they are (what the reference's callers do with match_string's result: string_matcher.py:16-55)"""
+        self._check_axis(axis)
+        if np.dtype(self.dtype) == np.bool_:
+            if axis is None:
+                return self._n_true() > 0
+            if axis != 0:
+                return self._row_reduce("sum") > 0
+        if axis is None:
+            return bool(self._flat_values().any())
+        if axis == 0:
+            return self._col_sums()[0] > 0 if np.dtype(self.dtype) == np.bool_ else self._nonzero()._col_sums()[0] > 0
+        return self._nonzero()._row_reduce("sum") > 0
+
+    def all(self, axis=-1):
+        """np.all: per row (an empty row gives True), per column or over everything"""
+        self._check_axis(axis)
+        flags = self if np.dtype(self.dtype) == np.bool_ else self._nonzero()
+        if axis is None:
+            return flags._n_true() == flags.total()
+        if axis == 0:
+            sums, counts = flags._col_sums()
+            return sums == counts
+        return ~(flags._negated()._row_reduce("sum") > 0)
+
+    def _nonzero(self):
+        """x != 0 as a bool ragged array of the same rows"""
+        self._compact()
+        values = self._flat_values()
+        return RaggedArray._from_parts(HArray(host=values != 0), None, self._lens, self._offsets, self._n_rows, self._total)
+
+    def _negated(self):
+        """~flags of a compact bool array, on the device"""
+        self._compact()
+        from .device import as_bool
+        flipped = as_bool(get_ops().mask_logic(as_u8(self._data), None, "not"))
+        return RaggedArray._from_parts(flipped, None, self._lens, self._offsets, self._n_rows, self._total)
+
     def sum(self, axis=-1):
         self._check_axis(axis)
         if axis is None:
+            if np.dtype(self.dtype) == np.bool_:             # np.sum(sequence == "G"): counted on the device (README.rst:38-42)
+                return self._n_true()
             return self._flat_values().sum()
         if axis == 0:
             return self._col_sums()[0]
@@ -309,7 +362,7 @@ class RaggedArray:
             return out
         if axis not in (-1, 1):
             raise ValueError("axis %r of a ragged (two-dimensional) array" % (axis,))
-        if np.any(self.lengths == 0):
+        if self._any_empty_row():
             raise ValueError("zero-size row in a reduction which has no identity")
         return self._row_reduce(what)
 
@@ -338,7 +391,11 @@ class RaggedArray:
             if not all(isinstance(a, RaggedArray) for a in arrays) or kwargs.get("axis", 0) != 0:
                 return NotImplemented
             return self._concatenate(arrays)
-        name = {np.sum: "sum", np.mean: "mean", np.min: "min", np.max: "max", np.amin: "min", np.amax: "max"}.get(func)
+        name = {np.sum: "sum", np.mean: "mean", np.min: "min", np.max: "max", np.amin: "min", np.amax: "max", np.any: "any",
+                np.all: "all"}.get(func)
+        if func is np.count_nonzero and args and args[0] is self and np.dtype(self.dtype) == np.bool_ and \
+                kwargs.get("axis", args[1] if len(args) > 1 else None) is None:
+            return self._n_true()
         if name is None or not args or args[0] is not self:
             return NotImplemented
         axis = kwargs.get("axis", args[1] if len(args) > 1 else None)

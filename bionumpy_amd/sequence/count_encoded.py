@@ -285,12 +285,35 @@ def count_encoded(values, weights=None, axis=-1):
     alphabet = encoding.get_alphabet() if hasattr(encoding, "get_alphabet") else encoding.get_labels()
     n_bins = len(alphabet)
     if flat_request:
-        hist = ops.count_dense(_as_int64(_flat_store(values)), n_bins)
-        return EncodedCounts(alphabet, hist.host().copy())
+        return EncodedCounts(alphabet, _flat_histogram(values, n_bins).host().copy())
     assert axis == -1 and isinstance(values, EncodedRaggedArray)
     values._compact()
-    hist = ops.count_dense_rows(_as_int64(values._flat_data()), values.offsets(), len(values), n_bins)
+    store = values._flat_data()
+    store = store._unpacked() if hasattr(store, "_unpacked") else store
+    if store.dtype == np.uint8 and n_bins <= ops.COUNT_BYTES_ROWS_MAX_BINS:       # letters: counted where they lie, as bytes
+        hist = ops.count_bytes_rows(store, values.offsets(), len(values), values.total(), n_bins)
+    else:
+        hist = ops.count_dense_rows(_as_int64(store), values.offsets(), len(values), n_bins)
     return EncodedCounts(alphabet, hist.host().reshape(len(values), n_bins).copy())
+
+
+def _flat_histogram(values, n_bins):
+    """the counts of all codes of an encoded (ragged) array, on the device: k-mer hashes (int64) through the dense histogram,
+    LETTERS as they are stored — uint8 codes as bytes (bnpk_count_bytes), 2-bit packed DNA by popcounts over its words
+    (bnpk_count_packed2) — no host copy, no widening (count_encoded.py:166-176 of the reference calls np.bincount on them)"""
+    ops = get_ops()
+    if isinstance(values, EncodedRaggedArray):
+        values._compact()
+        store, n = values._data, values.total()
+    else:
+        store, n = values._harray(), values.size
+    if hasattr(store, "_unpacked"):                      # packed DNA (encoded_array._PackedDna)
+        if n_bins == 4 and store._codes is None:
+            return ops.count_packed(store.packed, n)
+        store = store._unpacked()
+    if store.dtype == np.uint8 and n_bins <= 256:
+        return ops.count_bytes(store, n_bins)
+    return ops.count_dense(_as_int64(store), n_bins)
 
 
 def _count_weighted(values, weights, axis):

@@ -158,8 +158,21 @@ class _LazyLens:
         return self._np
 
     def dev(self):
+        off = self._offsets
+        if self._np is None and off.on_device:               # the difference of neighbouring offsets, taken where they are
+            d = off.dev()
+            return d[1:] - d[:-1]
         from ..device import HArray
         return HArray(host=self.host()).dev()
+
+    @property
+    def on_device(self):
+        return self._offsets.on_device
+
+    @property
+    def dtype(self):
+        import numpy as np
+        return np.dtype(np.int64)
 
 
 _DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB (pipeline.DENSE_MAX_K)

@@ -53,8 +53,9 @@ class PWM:
         ragged._compact()
         ops = get_ops()
         n_rows, total = len(ragged), ragged.total()
-        _, n_out = ops.row_offsets(ragged._lens, self.window_size)
+        out_off, n_out = ops.row_offsets(ragged._lens, self.window_size)
         scores = ops.pwm_scores(packed_words(ragged._data), ragged.offsets(), n_rows, total, n_out, self._matrix)
+        self._last_offsets = out_off
         return scores, ragged, single
 
     def calculate_score(self, sequence):
@@ -90,11 +91,14 @@ def get_motif_scores(sequence, pwm):
     row r holds max(0, L_r - window_size + 1) scores"""
     scores, ragged, single = pwm._scores(as_encoded_array(sequence) if not isinstance(
         sequence, (EncodedArray, EncodedRaggedArray)) else sequence)
-    values = scores.host()
     if single:
-        return values
-    new_lens = np.maximum(ragged.lengths - (pwm.window_size - 1), 0)
-    return RaggedArray(values, new_lens)
+        return scores.host()
+    # the scores stay in HBM (a float64 per window: 56 GB for 50 M reads would not cross PCIe in the time of a thousand such
+    # kernels); ``.max(axis=-1)`` / ``.sum(axis=-1)`` reduce them there (position_weight_matrix.py:177-196 returns a ragged array)
+    from .kmers import _LazyLens
+    out_off = pwm._last_offsets
+    lens = _LazyLens(out_off) if pwm.window_size > 1 else ragged._lens
+    return RaggedArray._from_parts(scores, None, lens, out_off, len(ragged), scores.size)
 
 
 class PositionWeightMatrix:

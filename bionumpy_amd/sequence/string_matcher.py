@@ -50,15 +50,17 @@ def match_string(sequence, matching_sequence):
     enc = sequence.encoding
     packed = isinstance(enc, AlphabetEncoding) and enc.alphabet_size == 4 and m <= 31 and \
         (isinstance(ragged._data, _PackedDna) or total >= 4096)
+    from ..device import HArray, as_bool
+    from .kmers import _LazyLens
     if packed:
-        hits = ops.match_windows(packed_words(ragged._data), offsets, n_rows, total, n_out, codes, True)
+        flags = as_bool(ops.match_windows(packed_words(ragged._data), offsets, n_rows, total, n_out, codes, True))
     elif m > 64:
-        flags = _match_long(ops, ragged, offsets, n_rows, total, codes, n_out)
+        flags = HArray(host=_match_long(ops, ragged, offsets, n_rows, total, codes, n_out))
     else:
-        hits = ops.match_windows(ragged._flat_data(), offsets, n_rows, total, n_out, codes, False)
-    if m <= 64 or packed:
-        flags = hits.host().astype(bool)
+        flags = as_bool(ops.match_windows(ragged._flat_data(), offsets, n_rows, total, n_out, codes, False))
     if single:
-        return flags
-    new_lens = np.maximum(ragged.lengths - (m - 1), 0)
-    return RaggedArray(flags, new_lens)
+        return flags.host()
+    # the flags stay where the kernel wrote them (bool over the 0/1 bytes), the row lengths come from the trimmed offsets
+    # only if somebody asks: ``match_string(reads, "GATTACA").any(axis=-1)`` is two kernels and no copy (string_matcher.py:16-55
+    # of the reference returns a ragged array the caller reduces)
+    return RaggedArray._from_parts(flags, None, _LazyLens(out_off) if m > 1 else ragged._lens, out_off, n_rows, n_out)

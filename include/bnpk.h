@@ -490,6 +490,15 @@ int bnpk_minimizers_generic(bnpk_ctx* ctx, const uint8_t* d_codes, const int64_t
                             int64_t n_rows, int64_t n_out, int k, int window_size, int alphabet_size, int64_t* d_out,
                             void* stream);
 
+/* count_encoded / np.bincount over the uint8 CODES of an encoded array (bionumpy/sequence/count_encoded.py:166-182;
+ * encoded_array.py:463-466: bincount) without widening them to int64: d_hist[b] += #{i < n: d_values[i] == b} for b < n_bins
+ * (<= 256; other bytes are not counted).  bnpk_count_packed2: the same for DNA packed 2 bits per base (the BitArray layout of
+ * bnpk_gather_encode_dna), four bins.  bnpk_count_bytes_rows: one histogram per row of ragged codes (axis=-1), n_bins <= 8,
+ * d_hist[r * n_bins + b] written (not added to). */
+int bnpk_count_bytes(bnpk_ctx* ctx, const uint8_t* d_values, int64_t n, int n_bins, int64_t* d_hist, void* stream);
+int bnpk_count_packed2(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases, int64_t* d_hist4, void* stream);
+int bnpk_count_bytes_rows(bnpk_ctx* ctx, const uint8_t* d_values, const int64_t* d_offsets, int64_t n_rows, int64_t total,
+                          int n_bins, int64_t* d_hist, void* stream);
 /* ---- A9: counting ---------------------------------------------------------------------------------
  * dense: replaces np.bincount(values, minlength=4^k) of count_encoded
  * (bionumpy/sequence/count_encoded.py:166-177); d_hist (n_bins int64) is ACCUMULATED into, so the

@@ -304,6 +304,22 @@ class OracleOps:
             c = c + hist.host()
         return _h(c)
 
+    def count_bytes(self, values, n_bins, hist=None):
+        v = values.host()
+        c = np.bincount(v[v < n_bins], minlength=n_bins).astype(np.int64)
+        return _h(c if hist is None else c + hist.host())
+
+    def count_packed(self, packed, n_bases, hist=None):
+        c = np.bincount(_unpack(packed, n_bases), minlength=4).astype(np.int64)
+        return _h(c if hist is None else c + hist.host())
+
+    COUNT_BYTES_ROWS_MAX_BINS = 8
+
+    def count_bytes_rows(self, values, offsets, n_rows, total, n_bins):
+        off, v = offsets.host(), values.host()
+        return _h(np.array([np.bincount(v[off[r]:off[r + 1]], minlength=n_bins)[:n_bins] for r in range(n_rows)],
+                           dtype=np.int64).reshape(-1))
+
     def count_dense_rows(self, values, offsets, n_rows, n_bins):
         off = offsets.host()
         v = values.host()

@@ -1020,3 +1020,79 @@ def test_ragged_reductions_of_every_shape(bnp):
     seqs = bnp.as_encoded_array(["ACGTACGTAC", "TTTTGGGGCC", "GATTACAGAT"], bnp.DNAEncoding)
     kmers = bnp.sequence.get_kmers(seqs, 4)
     assert np.array_equal(np.asarray(kmers.raw().min(axis=-1)), bnp.sequence.get_minimizers(seqs, 4, 10).raw().ravel())
+
+
+# ------------------------------------------------------------------------------------ results that stay on the device (round 5)
+def _on_device_never_downloaded(h):
+    """an HArray that lives in HBM and whose host copy nobody has asked for"""
+    return getattr(h, "on_device", False) and getattr(h, "_np", None) is None
+
+
+def test_window_flags_and_scores_are_reduced_where_they_are(bnp, request):
+    """match_string / get_motif_scores return ragged arrays over DEVICE data (string_matcher.py:16-55 and
+    position_weight_matrix.py:177-196 of the reference return ragged arrays the caller reduces): .any / .all / .sum / .max per
+    row, np.any / np.count_nonzero, and the flat counts never download the flags"""
+    rng = np.random.default_rng(12)
+    rows = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(0, 400, size=300)] + ["GATTACA", "", "GATTAC"]
+    seqs = bnp.as_encoded_array(rows, bnp.DNAEncoding)
+    pattern = "GAT"
+    hits = bnp.match_string(seqs, pattern)
+    expect = [[r[i:i + 3] == pattern for i in range(max(0, len(r) - 2))] for r in rows]
+    any_rows, all_rows, per_row = hits.any(axis=-1), hits.all(axis=-1), hits.sum(axis=-1)
+    assert np.asarray(any_rows).tolist() == [any(e) for e in expect]
+    assert np.asarray(all_rows).tolist() == [all(e) for e in expect]               # (an empty row: True, as np.all)
+    assert np.asarray(per_row).tolist() == [sum(e) for e in expect]
+    assert np.asarray(np.any(hits, axis=-1)).tolist() == [any(e) for e in expect]
+    assert int(hits.sum(axis=None)) == int(np.count_nonzero(hits)) == sum(sum(e) for e in expect)
+    assert bool(hits.any(axis=None)) and not bool(hits.all(axis=None))
+    if "hip" in request.node.name:
+        assert _on_device_never_downloaded(hits._data), "the flags crossed PCIe"
+        assert _on_device_never_downloaded(any_rows.harray())
+    assert hits.tolist() == expect                                                  # (looking at them downloads them: same values)
+    # the reads that contain the pattern, selected by the device mask
+    picked = seqs[np.asarray(any_rows)]
+    assert picked.tolist() == [r for r, e in zip(rows, expect) if any(e)]
+    # motif scores: per-row maximum on the device == the oracle's
+    PWM = bnp.sequence.position_weight_matrix.PWM
+    m = np.log(rng.dirichlet(np.ones(4), size=7).T / 0.25)
+    long_rows = [r for r in rows if len(r) >= 7]
+    scores = bnp.get_motif_scores(bnp.as_encoded_array(long_rows, bnp.DNAEncoding), PWM(m, "ACGT"))
+    best = scores.max(axis=-1)
+    codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer("".join(long_rows).encode(), dtype=np.uint8))
+    flat, lens = oracle.pwm_scores(codes, [len(r) for r in long_rows], m)
+    ends = np.cumsum(lens)
+    assert np.array_equal(np.asarray(best), np.array([flat[e - n:e].max() for e, n in zip(ends, lens)]))
+    if "hip" in request.node.name:
+        assert _on_device_never_downloaded(scores._data), "the scores crossed PCIe"
+    with pytest.raises(ValueError):
+        bnp.get_motif_scores(bnp.as_encoded_array(rows, bnp.DNAEncoding), PWM(m, "ACGT")).max(axis=-1)    # rows without a window
+
+
+def test_letter_counts_without_a_host_copy(bnp, big_fq_gz):
+    """count_encoded over LETTERS (count_encoded.py:166-182) and README.rst:38-42's np.sum(chunk.sequence == "G") == 53686"""
+    reads = bnp.open(big_fq_gz).read()
+    assert int(np.sum(reads.sequence == "G")) == 53686
+    dna = bnp.change_encoding(reads.sequence, bnp.DNAEncoding)
+    text = oracle.open_text(big_fq_gz).read()
+    raw, res = text
+    starts, lens = res.field_starts[:, 1], res.field_lens[:, 1]
+    codes = oracle.encode_dna(oracle.gather_rows(raw, starts, lens))
+    flat = bnp.count_encoded(dna, axis=None)                                         # packed 2-bit words: popcounts
+    assert flat.alphabet == ["A", "C", "G", "T"] and np.array_equal(flat.counts, np.bincount(codes, minlength=4))
+    assert flat["G"] == 53686
+    per_row = bnp.count_encoded(dna)                                                 # axis=-1: one histogram per read
+    ends = np.cumsum(lens)
+    expect = np.array([np.bincount(codes[e - n:e], minlength=4) for e, n in zip(ends, lens)])
+    assert per_row.counts.shape == (len(lens), 4) and np.array_equal(per_row.counts, expect)
+    # other alphabets: 5 letters (bytes, register counters), amino acids (21: LDS bins), np.bincount with minlength
+    rng = np.random.default_rng(4)
+    for enc, letters in ((bnp.ACGTnEncoding, "ACGTn"), (bnp.AminoAcidEncoding, "ACDEFGHIKLMNPQRSTVWY*")):
+        rows = ["".join(rng.choice(list(letters), size=int(n))) for n in rng.integers(0, 90, size=200)]
+        arr = bnp.as_encoded_array(rows, enc)
+        got = bnp.count_encoded(arr, axis=None)
+        assert [int(x) for x in got.counts] == ["".join(rows).count(c) for c in letters]      # (codes follow the alphabet's order)
+        rows_got = bnp.count_encoded(arr)
+        assert rows_got.counts.tolist() == [[r.count(c) for c in letters] for r in rows]
+        flat_arr = arr.ravel()
+        assert np.bincount(flat_arr, minlength=len(letters) + 3).tolist() == \
+            np.bincount(np.asarray(flat_arr.raw()), minlength=len(letters) + 3).tolist()

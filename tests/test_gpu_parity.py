@@ -824,3 +824,43 @@ def test_fused_line_scan_against_the_oracle_on_random_line_structures(ops, lpe, 
         # has_cr as the field table uses it: the sequence line's lengths
         starts, lens = ops.field_table(_h(buf), got.newlines, got.n_records, lpe, 1, 0, got.has_cr)
         assert np.array_equal(lens.host(), want.field_lens[:, 1]) and np.array_equal(starts.host(), want.field_starts[:, 1]), trial
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 255, 4097, 1_000_003, 40_000_000])
+def test_letter_histograms(ops, n):
+    """bnpk_count_bytes (register counters for <= 8 bins, LDS bins up to 256; buffers that start at any byte),
+    bnpk_count_packed2 (popcounts over 2-bit words, whatever lies behind the last base) vs np.bincount"""
+    rng = np.random.default_rng(n)
+    for n_bins in (1, 4, 5, 8, 21, 256):
+        v = rng.integers(0, min(256, n_bins + 2), size=n + 5).astype(np.uint8)   # (two values beyond the bins: not counted)
+        for start in (0, 1, 5):
+            part = v[start:start + n]
+            import torch
+            dev = HArray(dev=_h(v).dev()[start:start + n])
+            got = ops.count_bytes(dev, n_bins).host()
+            assert np.array_equal(got, np.bincount(part[part < n_bins], minlength=n_bins)), (n_bins, start)
+        again = ops.count_bytes(dev, n_bins, hist=HArray(dev=_h(got).dev().clone())).host()     # accumulates
+        assert np.array_equal(again, 2 * got)
+    codes = rng.integers(0, 4, size=n).astype(np.uint8)
+    packed = ops.pack_codes(_h(codes)).dev().clone()
+    if n % 32:
+        packed[n // 32] |= (-1 << (2 * (n % 32)))                                # junk behind the last base
+    packed[n // 32 + 1:] = -1
+    got = ops.count_packed(HArray(dev=packed), n).host()
+    assert np.array_equal(got, np.bincount(codes, minlength=4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n_rows,max_len", [(1, 1, 1), (2, 100, 7), (3, 5000, 160), (4, 5, 100_000), (5, 300_000, 40), (6, 17, 64)])
+def test_letter_histograms_per_row(ops, seed, n_rows, max_len):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len + 1, size=n_rows).astype(np.int64)
+    lens[rng.integers(0, n_rows, size=max(1, n_rows // 8))] = 0
+    total = int(lens.sum())
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    for n_bins in (4, 5, 8):
+        v = rng.integers(0, n_bins, size=total).astype(np.uint8)
+        got = ops.count_bytes_rows(_h(v if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, total, n_bins).host().reshape(n_rows, n_bins)
+        expect = np.array([np.bincount(v[offsets[r]:offsets[r + 1]], minlength=n_bins) for r in range(n_rows)], dtype=np.int64)
+        assert np.array_equal(got, expect)
