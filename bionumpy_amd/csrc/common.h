@@ -8,6 +8,11 @@
 
 #include "../../include/bnpk.h"
 
+// First statement of a kernel whose code would otherwise be given exactly 24 VGPRs (all three 8-register granules in use): the
+// allocation becomes 32, nothing is emitted.  Round 5 found rc_packed_kernel's fully unrolled form — correct ISA by every check,
+// byte-identical with and without this line — computing garbage in every workgroup that is not the first on its CU when it runs
+// with a 24-register allocation, and never with 32 (NOTES.md "rc_packed: the cause"; csrc/isa_lint.py reports such kernels).
+#define BNPK_VGPR_FLOOR_32() asm volatile("" ::: "v31")
 #define BNPK_WAVE 64
 #define BNPK_BLOCK 256
 

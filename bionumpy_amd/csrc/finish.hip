@@ -952,6 +952,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
 __global__ void finish_check_kernel(const int64_t* __restrict__ T, const unsigned* __restrict__ meta,
                                     const int64_t* __restrict__ bucket_off, const int64_t* __restrict__ out_off,
                                     int64_t n_buckets, unsigned* __restrict__ marks) {
+  BNPK_VGPR_FLOOR_32();                                   // (24 VGPRs otherwise: see common.h)
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; b < n_buckets; b += stride) {

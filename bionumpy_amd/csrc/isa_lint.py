@@ -317,6 +317,32 @@ def check_scc(name, items):
     return found
 
 
+def kernels_with_24_vgprs(obj_path):
+    """names of the kernels of an object whose code uses exactly 24 VGPRs (``.vgpr_count`` of the code object's metadata):
+    the allocation with which rc_packed_kernel's unrolled form went wrong on gfx950 (common.h: BNPK_VGPR_FLOOR_32)"""
+    llvm = os.path.dirname(OBJDUMP)
+    tmp = "/tmp/bnpk_lint24_%d" % os.getpid()
+    try:
+        r = subprocess.run([os.path.join(llvm, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + tmp + ".fb", obj_path], capture_output=True)
+        if r.returncode != 0:
+            return []
+        subprocess.run([BUNDLER, "--unbundle", "--type=o", "--input=" + tmp + ".fb", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                        "--output=" + tmp + ".co"], check=True, capture_output=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", tmp + ".co"], capture_output=True, text=True).stdout
+    finally:
+        for ext in (".fb", ".co"):
+            if os.path.exists(tmp + ext):
+                os.remove(tmp + ext)
+    out = []
+    for blk in notes.split("  - .agpr_count:")[1:]:
+        v = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+        a = int(blk.split()[0])
+        name = re.search(r"\.symbol:\s+(\S+)\.kd", blk)
+        if v and name and int(v.group(1)) == 24 and a == 0:
+            out.append(name.group(1))
+    return out
+
+
 def lint_objects(paths, only=None, verbose=True):
     """(findings, kernels, instructions) over the device code of the given object files"""
     findings, n_kernels, n_ins = [], 0, 0
@@ -334,6 +360,16 @@ def lint_objects(paths, only=None, verbose=True):
                                 % (os.path.basename(path), f[0], f[1], ", ".join("%s%d" % r for r in f[2])))
             for f in check_scc(name, items):
                 findings.append("%s: %s: `%s` %s" % (os.path.basename(path), f[0], f[1], f[2]))
+        if not path.endswith(".s"):
+            for name in kernels_with_24_vgprs(path):
+                if only and only not in name:
+                    continue
+                if "rocprim" in name:                        # (the library sort of the heavy-hitter fall-back: not ours to pad; said once)
+                    if verbose:
+                        print("isa_lint: note: %s uses exactly 24 VGPRs (third-party kernel)" % name[:90])
+                    continue
+                findings.append("%s: %s uses exactly 24 VGPRs: put BNPK_VGPR_FLOOR_32() first in its body (common.h)"
+                                % (os.path.basename(path), name))
     if verbose:
         for f in findings:
             print(f)

@@ -19,6 +19,12 @@ namespace {
 #ifndef BNPK_RCP_LDS_PAD
 #define BNPK_RCP_LDS_PAD 0                           // extra LDS bytes per workgroup (limits the workgroups per CU)
 #endif
+#ifndef BNPK_RCP_NO_LDS
+#define BNPK_RCP_NO_LDS 0                            // 1: the row offsets are always read from global memory
+#endif
+#ifndef BNPK_RCP_FENCE
+#define BNPK_RCP_FENCE 0                             // 1: a scheduling + memory fence behind every word of a lane
+#endif
 #define BNPK_PRAGMA_(x) _Pragma(#x)
 #define BNPK_PRAGMA_UNROLL(n) BNPK_PRAGMA_(unroll n)
 
@@ -52,6 +58,9 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
                                                                int64_t n_tiles, uint64_t* __restrict__ out) {
   constexpr int RCP_LDS_ROWS = 1022;
   __shared__ int64_t srow[RCP_LDS_ROWS + 2];
+#if !defined(BNPK_RCP_NO_FLOOR)
+  BNPK_VGPR_FLOOR_32();                                      // the unrolled form of the loop below would get 24 VGPRs: see there
+#endif
 #if BNPK_RCP_LDS_PAD
   __shared__ int pad_words[BNPK_RCP_LDS_PAD / 4];
   if (total < 0) pad_words[threadIdx.x] = 1;                 // (never true: keeps the array)
@@ -69,15 +78,18 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
   // the ends of the rows it crosses there, for its four words.  Searched in global memory and one word per lane, as this
   // kernel did, a lane sat through a chain of eight dependent loads before its first packed word: 3.4 ms per 50 M reads
   // for 3.8 GB of traffic.
-  const bool staged = hi - lo + 2 <= RCP_LDS_ROWS + 2;        // (uniform) offsets lo .. hi + 1
+  const bool staged = !BNPK_RCP_NO_LDS && hi - lo + 2 <= RCP_LDS_ROWS + 2;        // (uniform) offsets lo .. hi + 1
   if (staged) {
     for (int64_t i = threadIdx.x; i <= hi - lo + 1; i += BNPK_BLOCK) srow[i] = off[lo + i];
     __syncthreads();
   }
   auto offset_of = [&](int64_t row) { return (staged && row <= hi + 1) ? srow[row - lo] : off[row]; };
-  // (not unrolled: hipcc 7.2 -O3 gets the unrolled form of this loop wrong — rows of workgroups from the 257th on came out
-  // garbled, per lane or per wavefront, with the row offsets in LDS or in global memory alike; the rolled loop is as fast.
-  // tests/test_gpu_parity.py::test_reverse_complement_kernels has a case of 12 M bases for it.)
+  // Rolled, and the allocation pinned at 32 VGPRs above.  Round 4 saw the unrolled form of this loop write garbled rows "from
+  // the 257th workgroup on"; round 5 ran it down (NOTES.md "rc_packed: the cause"): the unrolled ISA is right (every load waited
+  // for, live ranges read by hand, s_nop padding / forced waits / no LDS / fences change nothing) — what differs is that only the
+  // fully unrolled kernel needs exactly 24 VGPRs, and with a 24-register allocation every workgroup that is not the first on its
+  // CU computes garbage, nondeterministically (a CU mask of 128 / 64 / 32 / 8 CUs moves the first bad tile to 129 / 72 / 37 /
+  // 10).  The SAME code with the allocation bumped to 32 registers is right in every run.  The rolled loop is as fast.
 BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
   for (int it = 0; it < RCP_WPL; ++it) {
     const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
@@ -113,6 +125,10 @@ BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
       p = stop;
     }
     out[w] = word;
+#if BNPK_RCP_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+#endif
   }
 }
 
