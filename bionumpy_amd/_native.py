@@ -136,6 +136,10 @@ SIGNATURES = {
     "bnpk_radix_max_bits": (_i64, []),
     "bnpk_finish_capacity": (_i64, []),
     "bnpk_radix_partition": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
+    "bnpk_claimed_stride": (_i64, []),
+    "bnpk_claimed_cap_lo": (_i64, []),
+    "bnpk_radix_partition_claimed": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p, _i64, _p, _p]),
+    "bnpk_claimed_offsets": (_int, [_p, _p, _i64, _p, _p]),
     "bnpk_radix_small_capacity": (_i64, []),
     "bnpk_radix_partition_small": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
     "bnpk_bucket_census": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),

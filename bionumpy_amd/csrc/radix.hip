@@ -67,11 +67,14 @@ struct rp_cfg {
   static constexpr size_t OFF_SLAB = OFF_WSUM + 32 * 4;
   static constexpr size_t OFF_CACHE = OFF_SLAB + 8 * 8;
   static constexpr size_t LDS = OFF_CACHE + RP_CACHE_BYTES;
+  static constexpr size_t OFF_OVF = LDS;                       // claiming form: {keys that fit the bucket, bag position} per bucket
+  static constexpr size_t LDS_CLAIM = OFF_OVF + (size_t)MAXB * 8;
 };
 constexpr int RP_HIST_BINS = 1 << RP_MAXBITS;
 constexpr size_t RP_HIST_LDS = (size_t)RP_HIST_BINS * 4 + 8 * 8 + RP_CACHE_BYTES;
 
 struct slab_t {
+  int64_t seg;           // the parent segment
   int64_t lo, hi;        // key range of the slab (inside one parent segment)
   int64_t hbase;         // first histogram entry of the segment
   int64_t nsl, local;    // slabs in the segment, index of this one
@@ -100,6 +103,7 @@ __device__ __forceinline__ bool find_slab(const int64_t* __restrict__ seg_off, c
   }
   __syncthreads();
   if (sh[0] < 0) return false;
+  sl.seg = sh[0];
   sl.local = (int64_t)blockIdx.x - sh[1];
   sl.nsl = sh[2];
   sl.hbase = sh[1] * B;
@@ -123,6 +127,15 @@ struct mem_source {
     for (int q = 0; q < ITEMS; ++q) {
       const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
       if (i < hi) raw.v[q] = STREAM ? __builtin_nontemporal_load(&keys[i]) : keys[i];   // STREAM: last use of the keys
+    }
+  }
+  // the same loads, all ITEMS of them by every lane (indices clamped to the slab's last key: finish() ignores what lies behind
+  // hi): the claiming scatter wants to know HOW MANY vector memory instructions were issued behind its claims
+  __device__ __forceinline__ void issue_all(int64_t t0, int64_t hi, raw_t& raw) const {
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int64_t i = min(t0 + threadIdx.x + (int64_t)q * RP_THREADS, hi - 1);
+      raw.v[q] = __builtin_nontemporal_load(&keys[i]);
     }
   }
   __device__ __forceinline__ static void landed(const raw_t&) {}
@@ -390,13 +403,30 @@ __global__ __launch_bounds__(RP_THREADS) void rp_hist_mem_kernel(const uint64_t*
 //          offset, otherwise all slices start on LDS bank 0 and equal ranks collide 16-way
 //   flush  the FLUSH region leaves the CU as aligned 16-byte-per-lane stores (whole lines only); the CARRY region is
 //          read back into the owning lanes' registers
-template <typename Source, int LINE, int MAXB>
+// CLAIM (a level that reads its keys from memory, whole lines, 1024 buckets): no histogram pass ran before this kernel and
+// nothing says where a (slab, bucket) run belongs.  Every child bucket owns RPC_STRIDE slots of `out` — lines at the front,
+// [0, RPC_CAP_LO), the < 16 leftover keys of every slab behind them, [RPC_CAP_LO, RPC_STRIDE) — and a workgroup CLAIMS the
+// place of the lines it flushes for a bucket in a round with one returning atomicAdd on the bucket's fill counter (fill[2c];
+// the leftovers of its last round on fill[2c + 1]).  The claims are multiples of a line, so every line stays 128-byte aligned;
+// a bucket is two dense runs and no holes: [0, min(fill[2c], CAP_LO)) and [CAP_LO, CAP_LO + min(fill[2c+1], TAIL)).  What does
+// not fit a bucket's slots (a bucket that would be over the finishing kernels' capacity anyway; more slabs per segment than the
+// tail has room for) goes to an unordered BAG of keys that the caller counts on its own and adds to the result.
+constexpr int RPC_CAP_LO = 7552, RPC_TAIL = 128, RPC_STRIDE = RPC_CAP_LO + RPC_TAIL;      // = the fast finishing kernels' 7680
+struct rp_claim_t {
+  unsigned* fill;                  // [2 * buckets] {keys claimed at the front, keys claimed in the tail}
+  uint64_t* bag;                   // keys without a place in their bucket
+  unsigned long long* bag_fill;    // claimed slots of the bag (may run past bag_cap: the caller looks)
+  int64_t bag_cap;
+};
+
+template <typename Source, int LINE, int MAXB, bool CLAIM = false>
 __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, const int64_t* __restrict__ seg_off,
                                                                 const int64_t* __restrict__ seg_slabs, int64_t n_seg,
                                                                 int64_t slab_keys, int shift, int bits,
                                                                 const int64_t* __restrict__ offs,
-                                                                uint64_t* __restrict__ out) {
+                                                                uint64_t* __restrict__ out, rp_claim_t claim) {
   using C = rp_cfg<LINE, MAXB>;
+  static_assert(!CLAIM || (std::is_same<Source, mem_source>::value && LINE == 16 && MAXB == 1024), "the claiming form is level 2's");
   // Two schedules of a round (see the loop): the fused first level, which is bound by its rounds, takes the next tile's
   // keys before it stores and has the loads of the tile after next in flight for a whole round; a level that reads its
   // keys from memory is bound by HBM either way and keeps the shorter-lived registers of the plain order.
@@ -408,11 +438,13 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
   unsigned* line = reinterpret_cast<unsigned*>(smem + C::OFF_LINE);   // write cursor of the bucket / LINE
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + C::OFF_WSUM);
   int64_t* sh = reinterpret_cast<int64_t*>(smem + C::OFF_SLAB);
+  uint64_t* ovf = reinterpret_cast<uint64_t*>(smem + C::OFF_OVF);     // (claiming form) {lo keys that fit:16 | tail keys that fit:8 | bag position:40}
   const int B = 1 << bits;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   slab_t sl;
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   if (sl.lo >= sl.hi) return;
+  constexpr uint64_t NO_BAG = (1ull << 40) - 1;              // bag position of keys that found no room in the bag either
   auto tile_size = [](unsigned carried) {
     return min((unsigned)(Source::ITEMS * RP_THREADS), ((unsigned)C::STAGE - carried) & ~(unsigned)(RP_THREADS - 1));   // >= RP_THREADS
   };
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     cursor[b] = 0;
     rem[b] = 0;
     if (d < B) {
-      const int64_t c0 = offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
+      const int64_t c0 = CLAIM ? 0 : offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
       cursor[b] = c0 & ~(int64_t)(LINE - 1);
       rem[b] = (unsigned)(c0 & (LINE - 1));
       newcnt[d] = rem[b];
@@ -491,6 +523,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     const bool last = t0 + T >= sl.hi;
     // layout of the round
     unsigned nfl[C::NBT], nrem[C::NBT], packed = 0;
+    unsigned c_whole[C::NBT] = {}, c_tail[C::NBT] = {}, c_lo[C::NBT] = {}, c_hi[C::NBT] = {};   // (claiming form) what was claimed, and where
 #pragma unroll
     for (int b = 0; b < C::NBT; ++b) {
       const int d = tid + b * RP_THREADS;
@@ -500,6 +533,22 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       nrem[b] = tot - nfl[b];
       if (d < B) newcnt[d] = nrem[b];                           // where the next round's ranks start
       packed += nfl[b] | (nrem[b] << 16);
+      if (CLAIM && d < B) {
+        const int64_t c = sl.seg * B + d;
+        c_whole[b] = nfl[b] & ~(unsigned)(LINE - 1);           // lines go to the front of the bucket's slots ...
+        c_tail[b] = nfl[b] - c_whole[b];                       // ... the slab's last < 16 keys to its tail
+        if (RP_ABL & 32) {                                     // (experiment: the atomics fire and forget, the places are made up)
+          if (c_whole[b]) atomicAdd(&claim.fill[2 * c], c_whole[b]);
+          c_lo[b] = (unsigned)((cursor[b] + sl.local * 1600) % 6000) & ~15u;
+          cursor[b] += c_whole[b];
+        } else if (RP_ABL & 64) {                              // (experiment: no atomics at all)
+          c_lo[b] = (unsigned)((cursor[b] + sl.local * 1600) % 6000) & ~15u;
+          cursor[b] += c_whole[b];
+        } else {
+          if (c_whole[b]) c_lo[b] = atomicAdd(&claim.fill[2 * c], c_whole[b]);
+          if (c_tail[b]) c_hi[b] = atomicAdd(&claim.fill[2 * c + 1], c_tail[b]);
+        }
+      }
     }
     const unsigned inc = wave_inclusive_scan(packed);
     if (lane == 63) wsum[wave] = inc;
@@ -527,7 +576,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
       ex += nfl[b] | (nrem[b] << 16);
       if (d < B) {
         meta[d] = (uint64_t)(fpos | (nfl[b] << 16)) | ((uint64_t)(cpos[b] - nfl[b]) << 32);
-        line[d] = (unsigned)(cursor[b] >> C::LOG_LINE);
+        if (!CLAIM) line[d] = (unsigned)(cursor[b] >> C::LOG_LINE);
         // carried keys precede the new ones (rem < LINE <= nfl): in-bucket indices 0 .. rem-1.  Index j goes to slot
         // (j + rot) mod nfl of the flush slice — it wraps at most once, from index nfl - rot on — or, when the bucket
         // flushes nothing this round, to slot j of its carry slice.
@@ -542,7 +591,12 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
     emit_held(1);
     __syncthreads();
     RP_MARK(1)
-    if (!AHEAD && !last) src.template issue<true>(t0 + T, sl.hi, raw);   // plain order: the loads land while this tile is staged and flushed
+    if (!AHEAD && !CLAIM && !last) src.template issue<true>(t0 + T, sl.hi, raw);   // plain order: the loads land while this tile is staged and flushed
+    // (claiming form) the same place — BEHIND the claims of this round, which are returning atomics whose answers are needed
+    // before the flush: vector memory operations complete in order, so the wait for the claims is s_waitcnt vmcnt(loads issued
+    // since), and the compiler can only count them if every lane issues all eight (kernel trick of common practice: clamp, not branch)
+    // — in the slab's last round too (eight loads of its last key), or the two paths would differ in that number
+    if constexpr (CLAIM) src.issue_all(t0 + T, sl.hi, raw);
     // stage the new keys behind the carried ones, four at a time: the table reads first (one wait for the four of them),
     // then the arithmetic, then the stores
     constexpr int SG = MAXB > 1024 ? 2 : 4;                   // (two owned buckets per lane leave fewer registers)
@@ -563,13 +617,61 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
         if (!(RP_ABL & 2) && ((vm >> q) & 1u)) stage[slot] = k[q];
       }
     }
+    if (CLAIM) {
+      // the answers of the claims: where the bucket's lines of this round go.  line[d] = first line of the claimed place (bit 31:
+      // not everything fits — ovf[d] says how much does and where the rest lies in the bag); in the slab's last round newcnt[d]
+      // (free by now) = {whole-line keys:16 | leftover keys:4 | their place in the bucket's tail:12}
+      // (the answers are looked at HERE and not a cycle earlier: left to itself the scheduler moves this arithmetic up behind
+      // the atomics and the wait for them with it — the whole latency of a device-scope atomic, once per round: 4 of 25 ms)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < C::NBT; ++b) asm volatile("" : "+v"(c_lo[b]), "+v"(c_hi[b]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int b = 0; b < C::NBT; ++b) {
+        const int d = tid + b * RP_THREADS;
+        if (d < B) {
+          const int64_t c = sl.seg * B + d;
+          const unsigned fit = c_lo[b] >= (unsigned)RPC_CAP_LO ? 0u : min(c_whole[b], (unsigned)RPC_CAP_LO - c_lo[b]);
+          const unsigned hb = min(c_hi[b], (unsigned)RPC_TAIL);
+          const unsigned tfit = min(c_tail[b], (unsigned)RPC_TAIL - hb);
+          unsigned ln = (unsigned)((c * RPC_STRIDE + (int64_t)min(c_lo[b], (unsigned)RPC_CAP_LO)) >> C::LOG_LINE);
+          const unsigned spill = (c_whole[b] - fit) + (c_tail[b] - tfit);
+          if (spill) {                                         // (rare: a bucket over the capacity, a segment of very many slabs)
+            unsigned long long bp = atomicAdd(claim.bag_fill, (unsigned long long)spill);
+            if ((int64_t)(bp + spill) > claim.bag_cap) bp = NO_BAG;
+            ovf[d] = (uint64_t)fit | ((uint64_t)tfit << 16) | ((uint64_t)bp << 24);
+            ln |= 0x80000000u;
+          }
+          line[d] = ln;
+          if (last) newcnt[d] = c_whole[b] | (c_tail[b] << 16) | (hb << 20);
+        }
+      }
+    }
     __syncthreads();
     RP_MARK(2)
     if (last) {
       for (unsigned i = tid; i < total_f; i += RP_THREADS) {
         const uint64_t key = stage[i];
         const unsigned d = (unsigned)(key >> shift) & (B - 1);
-        if (!(key >> 63)) out[((int64_t)line[d] << C::LOG_LINE) + (i - ((unsigned)meta[d] & 0xffffu))] = key;
+        if (key >> 63) continue;
+        const unsigned j = i - ((unsigned)meta[d] & 0xffffu);  // index among the bucket's keys of this (last) round
+        if (!CLAIM) {
+          out[((int64_t)line[d] << C::LOG_LINE) + j] = key;
+          continue;
+        }
+        const unsigned info = newcnt[d], whole = info & 0xffffu, hb = info >> 20, ln = line[d];
+        unsigned fit = whole, tfit = (info >> 16) & 15u;
+        uint64_t bp = 0;
+        if (ln >> 31) { const uint64_t ov = ovf[d]; fit = (unsigned)ov & 0xffffu; tfit = (unsigned)(ov >> 16) & 0xffu; bp = ov >> 24; }
+        uint64_t* dst;
+        if (j < whole) dst = j < fit ? out + (((int64_t)(ln & 0x7fffffffu) << C::LOG_LINE) + j) : (bp == NO_BAG ? nullptr : claim.bag + bp + (j - fit));
+        else {
+          const unsigned t = j - whole;
+          dst = t < tfit ? out + ((sl.seg * B + d) * (int64_t)RPC_STRIDE + RPC_CAP_LO + hb + t)
+                         : (bp == NO_BAG ? nullptr : claim.bag + bp + (whole - fit) + (t - tfit));
+        }
+        if (dst) *dst = key;
       }
       break;
     }
@@ -615,7 +717,15 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
         if (i < total_f) {
           unsigned j = i - f[u] - 2u * (d[u] & (unsigned)(LINE / 2 - 1));              // undo the rotation of the slice:
           j = min(j, j + nf[u]);                                                       // (slot - rot) mod nfl
-          uint64_t* dst = out + (((int64_t)ln[u] << C::LOG_LINE) + j);
+          uint64_t* dst = out + (((int64_t)(CLAIM ? ln[u] & 0x7fffffffu : ln[u]) << C::LOG_LINE) + j);
+          if (CLAIM && (ln[u] >> 31)) {                         // part of the bucket's lines of this round lie in the bag
+            const uint64_t ov = ovf[d[u]];
+            const unsigned fit = (unsigned)ov & 0xffffu;
+            if (j >= fit) {
+              if ((ov >> 24) == NO_BAG) continue;              // (no room anywhere: the caller sees bag_fill > bag_cap and counts another way)
+              dst = claim.bag + (ov >> 24) + (j - fit);
+            }
+          }
           if (RP_ABL & 16) dst = out + (size_t)blockIdx.x * 16384 + (i & 0x3ffeu);
           if (RP_ABL & 1) {
             if (dst == nullptr) dst[0] = kk[u].x;
@@ -786,12 +896,46 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
     constexpr size_t lds = rp_cfg<L_, M_>::LDS;
     auto kernel = rp_scatter_kernel<Source, L_, M_>;
     hipLaunchKernelGGL(kernel, dim3((unsigned)bound), dim3(RP_THREADS), lds, s, src, d_seg_off, (const int64_t*)seg_slabs, n_seg,
-                       slab_keys, shift, bits, (const int64_t*)H, reinterpret_cast<uint64_t*>(d_out));
+                       slab_keys, shift, bits, (const int64_t*)H, reinterpret_cast<uint64_t*>(d_out), rp_claim_t{});
   };
   using std::integral_constant;
   if (bits > 10) launch(integral_constant<int, 8>{}, integral_constant<int, 2048>{});
   else if (line == 16) launch(integral_constant<int, 16>{}, integral_constant<int, 1024>{});
   else launch(integral_constant<int, 8>{}, integral_constant<int, 1024>{});
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+// sizes of the claimed buckets -> (dense-equivalent) bucket offsets: n_b = min(front, CAP_LO) + min(tail, TAIL)
+__global__ void rp_claimed_sizes_kernel(const unsigned* __restrict__ fill, int64_t n_buckets, int64_t* __restrict__ sizes) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n_buckets; i += stride)
+    sizes[i] = (int64_t)min(fill[2 * i], (unsigned)RPC_CAP_LO) + (int64_t)min(fill[2 * i + 1], (unsigned)RPC_TAIL);
+}
+
+// the claiming level: slab table -> scatter (no histogram, no scan)
+int rp_level_claimed(bnpk_ctx* ctx, const mem_source& src, int64_t n, const int64_t* d_seg_off, int64_t n_seg, int shift, int bits,
+                     uint64_t* d_buckets, const rp_claim_t& claim, char* scratch, hipStream_t s) {
+  const int64_t slab_keys = rp_slab_keys(n);
+  const int64_t bound = n / slab_keys + n_seg + 1;
+  if (bound > BNPK_MAX_BLOCKS / (RP_THREADS / 256)) return BNPK_ERR_RANGE;
+  int64_t* own_seg = reinterpret_cast<int64_t*>(scratch);
+  int64_t* seg_slabs = reinterpret_cast<int64_t*>(scratch + align64(16));
+  auto kernel = rp_scatter_kernel<mem_source, 16, 1024, true>;
+  constexpr size_t lds = rp_cfg<16, 1024>::LDS_CLAIM;
+  if (!ctx->launch_attr_set[4]) {
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->launch_attr_set[4] = true;
+  }
+  if (!d_seg_off) {
+    hipLaunchKernelGGL(rp_single_segment_kernel, dim3(1), dim3(1), 0, s, n, own_seg);
+    d_seg_off = own_seg;
+  }
+  hipLaunchKernelGGL(rp_slab_table_kernel, dim3(1), dim3(RP_THREADS), 0, s, d_seg_off, n_seg, slab_keys, seg_slabs);
+  bnpk_timer t(ctx, "radix_scatter_claimed", s);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)bound), dim3(RP_THREADS), lds, s, src, d_seg_off, (const int64_t*)seg_slabs, n_seg, slab_keys,
+                     shift, bits, (const int64_t*)nullptr, d_buckets, claim);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
@@ -925,6 +1069,41 @@ int bnpk_kmers_partition(bnpk_ctx* ctx, const uint64_t* d_packed, const uint64_t
   kmer_source<false> src{d_packed, reinterpret_cast<const uint8_t*>(d_kmer_starts), n_bases / 32 + 2, k};
   return rp_level(ctx, src, n_bases, nullptr, 1, shift, bits, d_out, d_child_offsets, (char*)scratch,
                   "kmers_partition_hist", "kmers_partition_scatter", s);
+}
+
+int64_t bnpk_claimed_stride(void) { return RPC_STRIDE; }
+int64_t bnpk_claimed_cap_lo(void) { return RPC_CAP_LO; }
+
+int bnpk_radix_partition_claimed(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
+                                 int shift, int bits, int64_t* d_buckets, uint32_t* d_fill, int64_t* d_bag, int64_t bag_cap,
+                                 int64_t* d_bag_fill, void* stream) {
+  if (!ctx || n < 0 || n_seg < 1 || bits < 1 || bits > 10 || shift < 0 || shift + bits > 63 || !d_fill || !d_bag_fill || bag_cap < 0)
+    return BNPK_ERR_ARG;
+  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
+  if (n > 0 && (!d_keys || !d_buckets || (bag_cap > 0 && !d_bag))) return BNPK_ERR_ARG;
+  if (n_seg > 1 && !d_seg_offsets) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  BNPK_HIP(ctx, hipMemsetAsync(d_fill, 0, (size_t)(n_seg << bits) * 2 * sizeof(uint32_t), s));
+  BNPK_HIP(ctx, hipMemsetAsync(d_bag_fill, 0, sizeof(int64_t), s));
+  if (n == 0) return BNPK_OK;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, align64(16) + align64((size_t)(n_seg + 1) * 8), &scratch, s));
+  mem_source src{reinterpret_cast<const uint64_t*>(d_keys)};
+  rp_claim_t claim{d_fill, reinterpret_cast<uint64_t*>(d_bag), reinterpret_cast<unsigned long long*>(d_bag_fill), bag_cap};
+  return rp_level_claimed(ctx, src, n, d_seg_offsets, n_seg, shift, bits, reinterpret_cast<uint64_t*>(d_buckets), claim, (char*)scratch, s);
+}
+
+int bnpk_claimed_offsets(bnpk_ctx* ctx, const uint32_t* d_fill, int64_t n_buckets, int64_t* d_bucket_offsets, void* stream) {
+  if (!ctx || n_buckets < 1 || !d_fill || !d_bucket_offsets) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  void* scratch = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, align64((size_t)n_buckets * 8) + align64(bnpk_scan_scratch_bytes(n_buckets)), &scratch, s));
+  int64_t* sizes = reinterpret_cast<int64_t*>(scratch);
+  int64_t* scan_scratch = reinterpret_cast<int64_t*>((char*)scratch + align64((size_t)n_buckets * 8));
+  bnpk_timer t(ctx, "claimed_offsets", s);
+  hipLaunchKernelGGL(rp_claimed_sizes_kernel, dim3(grid_for(ceil_div(n_buckets, 256))), dim3(256), 0, s, d_fill, n_buckets, sizes);
+  BNPK_HIP(ctx, hipGetLastError());
+  return bnpk_scan_launch(ctx, sizes, n_buckets, 1, d_bucket_offsets, true, scan_scratch, s);
 }
 
 int64_t bnpk_radix_small_capacity(void) { return RS_CAP; }
