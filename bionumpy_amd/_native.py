@@ -139,13 +139,15 @@ SIGNATURES = {
     "bnpk_claimed_stride": (_i64, []),
     "bnpk_claimed_cap_lo": (_i64, []),
     "bnpk_radix_partition_claimed": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p, _i64, _p, _p]),
-    "bnpk_claimed_offsets": (_int, [_p, _p, _i64, _p, _p]),
+    "bnpk_claimed_finalize": (_int, [_p, _p, _p, _i64, _p, _p]),
     "bnpk_radix_small_capacity": (_i64, []),
     "bnpk_radix_partition_small": (_int, [_p, _p, _i64, _p, _i64, _int, _int, _p, _p, _p]),
     "bnpk_bucket_census": (_int, [_p, _p, _i64, _i64, _int, _p, _p]),
     "bnpk_finish_state_words": (_i64, [_i64]),
     "bnpk_finish_sorted": (_int, [_p, _p, _i64, _p, _i64, _int, _p, _p, _p, _p, _int, _p, _p, C.POINTER(_i64),
                                   C.POINTER(_int), _p]),
+    "bnpk_finish_sorted_strided": (_int, [_p, _p, _i64, _i64, _p, _i64, _int, _p, _p, _p, _p, _int, _p, _p, C.POINTER(_i64),
+                                          C.POINTER(_int), _p]),
     "bnpk_run_tiles": (_i64, [_i64]),
     "bnpk_run_census": (_int, [_p, _p, _p, _i64, _p, C.POINTER(_i64), _p]),
     "bnpk_run_heads": (_int, [_p, _p, _p, _i64, _p, _i64, _p, _p, _p, _p]),

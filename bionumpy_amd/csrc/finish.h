@@ -1,4 +1,7 @@
 // Internal: what the finishing kernels of the sparse k-mer histogram share (finish.hip, finish_dup.hip).
+// pstride (every launcher): 0 = the buckets lie back to back at bucket_off[b]; otherwise bucket b's keys lie at
+// part + b * pstride (radix.hip: buckets of fixed stride, claimed line by line) and bucket_off only says how many they are /
+// where the counts of the loose convention and the output go.
 #pragma once
 #include "common.h"
 
@@ -24,17 +27,18 @@ constexpr int FINISH_CAP = 8192;
 int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                            unsigned long long* header, int64_t* Dv, unsigned* redo_ids, int64_t* loose_counts,
                            const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
-                           const unsigned* todo_ids, hipStream_t s);
+                           const unsigned* todo_ids, int64_t pstride, hipStream_t s);
 // dst[T[b] + i] = src[bucket_off[b] + i] for i < T[b + 1] - T[b]: the loose per-bucket runs moved to their final place
 // (src and dst must be different buffers); header[FS_UNIQUE] = T[n_buckets].
+// (pstride != 0: bucket b's run in src starts at b * pstride instead of bucket_off[b])
 int bnpk_finish_compact_launch(bnpk_ctx* ctx, const int64_t* src, int64_t* dst, const int64_t* bucket_off, const int64_t* T,
-                               int64_t n_buckets, unsigned long long* header, hipStream_t s);
+                               int64_t n_buckets, unsigned long long* header, int64_t pstride, hipStream_t s);
 
 // One wavefront per bucket, a 704-slot table each (finish_wave.hip): see there.
 int bnpk_finish_wave_launch(bnpk_ctx* ctx, bool probe, int64_t probe_buckets, uint64_t* part, int64_t n, const int64_t* bucket_off,
                             int64_t n_buckets, int low_bits, unsigned long long* header, int64_t* Dv, unsigned* todo_ids,
                             int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
-                            const int64_t* big_counts, hipStream_t s);
+                            const int64_t* big_counts, int64_t pstride, hipStream_t s);
 
 // The fast kernel's ranking with multiplicities, run-length emission from the sorted stage and exact output positions
 // (finish_multi.hip): nearly-distinct keys with a repeat in most buckets.  status: n_buckets zeroed 32-bit words; the
@@ -47,4 +51,4 @@ int64_t bnpk_finish_multi_park_bytes(int grid);
 int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                              unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
                              const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
-                             unsigned* redo_ids, int64_t* redo_bases, hipStream_t s);
+                             unsigned* redo_ids, int64_t* redo_bases, int64_t pstride, hipStream_t s);

@@ -65,20 +65,23 @@ __device__ __forceinline__ int fn_fresh(int x) {
 
 struct fn_bucket {
   int64_t b, lo, t;   // t: the ticket the bucket was handed out under
+  int64_t src;        // where the bucket's keys lie in the partitioned array: lo, or b * pstride for buckets of fixed stride
   int nb;          // keys in the bucket; 0 = nothing to sort (empty, past the end, or over capacity)
   bool over;
 };
 
 // bucket b from its two offsets (loaded one iteration earlier, so nothing waits on them here)
-__device__ __forceinline__ fn_bucket fn_open(int64_t n_buckets, int64_t b, int64_t lo, int64_t hi, int64_t t) {
+__device__ __forceinline__ fn_bucket fn_open(int64_t n_buckets, int64_t b, int64_t lo, int64_t hi, int64_t t, int64_t pstride) {
   fn_bucket x;
   x.b = b;
   x.t = t;
   x.lo = 0;
+  x.src = 0;
   x.nb = 0;
   x.over = false;
   if (b < n_buckets) {
     x.lo = lo;
+    x.src = pstride ? b * pstride : lo;
     const int64_t m = hi - lo;
     x.over = m > FN_CAP;
     x.nb = x.over ? 0 : (int)m;
@@ -102,7 +105,10 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
                                                                    const int64_t* __restrict__ big_counts,
                                                                    const unsigned* __restrict__ redo_ids,
                                                                    const int64_t* __restrict__ redo_bases,
-                                                                   int64_t n_redo_arg, int64_t* __restrict__ loose_D) {
+                                                                   int64_t n_redo_arg, int64_t* __restrict__ loose_D,
+                                                                   int64_t pstride) {
+  // pstride != 0: bucket b's keys lie at A + b * pstride (radix.hip: buckets of fixed stride, claimed line by line);
+  // bucket_off then only says how many they are and where the bucket's output goes
   constexpr bool REDO = MODE != 0, LOOSE = MODE == 2;
   const int64_t n_redo = LOOSE ? fn_uniform((int64_t)state[FS_REDO]) : n_redo_arg;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   {
     const int64_t t0 = fn_uniform(sh[0]);
     const int64_t b0 = fn_uniform(bucket_of(t0));
-    cur = fn_open(n_buckets, b0, b0 < n_buckets ? fn_uniform(bucket_off[b0]) : 0, b0 < n_buckets ? fn_uniform(bucket_off[b0 + 1]) : 0, t0);
+    cur = fn_open(n_buckets, b0, b0 < n_buckets ? fn_uniform(bucket_off[b0]) : 0, b0 < n_buckets ? fn_uniform(bucket_off[b0 + 1]) : 0, t0, pstride);
   }
   uint64_t k[FN_ITEMS];
   unsigned r[FN_ITEMS];
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   for (int q = 0; q < FN_ITEMS; ++q) {
     const int i = tid + q * FN_THREADS;
     if (i < cur.nb) {
-      k[q] = (A + cur.lo)[(unsigned)i];
+      k[q] = (A + cur.src)[(unsigned)i];
       r[q] = atomicAdd(&bins[(unsigned)(k[q] >> sshift) & (SB - 1)], 1u);
       valid |= 1u << q;
     }
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   unsigned prev_D = 0;
   auto resolve_prev = [&]() {                          // wavefront 0: where the previous bucket's output goes
     if (LOOSE) {
-      if (lane == 0) { sh[1] = bucket_off[prev_b]; loose_D[prev_b] = prev_D; }
+      if (lane == 0) { sh[1] = bucket_off[prev_b]; sh[3] = pstride ? prev_b * pstride : bucket_off[prev_b]; loose_D[prev_b] = prev_D; }
       return;
     }
     if (REDO) {
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
   };
   auto emit_prev = [&]() {
     const int64_t base = fn_uniform(sh[1]);
-    uint64_t* ko = keys_out + base;                    // scalar bases, 32-bit lane offsets
+    uint64_t* ko = keys_out + (LOOSE ? fn_uniform(sh[3]) : base);   // scalar bases, 32-bit lane offsets (loose: back over the bucket's own keys)
     int64_t* co = counts_out + base;
     const unsigned t0 = (unsigned)fn_fresh(tid);
     if (prev_big >= 0) {                               // pre-counted bucket: copy its (key, count) pairs into place
@@ -279,14 +285,14 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
     // (before this wavefront's loads of the next keys: the memory counter is in-order, younger loads would be waited for)
     if (have_prev && wave == 0) resolve_prev();
     // the next bucket: its offsets arrived during the previous iteration; start the loads of its keys now
-    const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi), nn_t);
+    const fn_bucket nxt = fn_open(n_buckets, nn_b, fn_uniform(nn_lo), fn_uniform(nn_hi), nn_t, pstride);
     uint64_t kn[FN_ITEMS];
     {
       const int t = fn_fresh(tid);
 #pragma unroll
       for (int q = 0; q < FN_ITEMS; ++q) {
         const int i = t + q * FN_THREADS;
-        if (i < nxt.nb) kn[q] = __builtin_nontemporal_load(&(A + nxt.lo)[(unsigned)i]);   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
+        if (i < nxt.nb) kn[q] = __builtin_nontemporal_load(&(A + nxt.src)[(unsigned)i]);   // scalar base + 32-bit lane offset: no per-lane 64-bit addresses
       }
     }
     unsigned D = 0;
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(FN_THREADS) void finish_sorted_kernel(const uint64_
 #pragma unroll
         for (int q = 0; q < FN_ITEMS; ++q) {
           const int i = tid + q * FN_THREADS;
-          if (i < nxt.nb) kn[q] = (A + nxt.lo)[(unsigned)i];
+          if (i < nxt.nb) kn[q] = (A + nxt.src)[(unsigned)i];
         }
       }
     }
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
     int64_t n_buckets, int sshift, int sbits, unsigned long long* __restrict__ header, int64_t* __restrict__ Dv,
     unsigned* __restrict__ meta, uint64_t* __restrict__ keys_out, int64_t* __restrict__ counts_out,
     const int64_t* __restrict__ big_table, int n_big, const uint64_t* __restrict__ big_keys,
-    const int64_t* __restrict__ big_counts) {
+    const int64_t* __restrict__ big_counts, int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem + FF_OFF_STAGE);
   unsigned* P32 = reinterpret_cast<unsigned*>(smem + FF_OFF_P);                 // bins: counts, then exclusive offsets
@@ -631,16 +637,17 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   // in the stage (the registers are free from then on) and stay in flight through the rest of the iteration; the
   // offsets of bucket b + 2 G are fetched an iteration before that.
   uint64_t k[FF_ITEMS];
-  struct bucket_t { int64_t lo, out; int nb; int64_t size; };
+  struct bucket_t { int64_t lo, out; int nb; int64_t size; int64_t src; };   // src: where the keys lie (lo, or b * pstride)
   auto fetch_offsets = [&](int64_t bb, int64_t& o0, int64_t& o1, int64_t& oo) {      // (scalar loads; consumed an iteration later)
     o0 = 0; o1 = 0; oo = 0;
     if (bb < n_buckets) { o0 = bucket_off[bb]; o1 = bucket_off[bb + 1]; oo = out_off[bb]; }
   };
-  auto open_bucket = [&](int64_t o0, int64_t o1, int64_t oo) {
+  auto open_bucket = [&](int64_t bb, int64_t o0, int64_t o1, int64_t oo) {
     bucket_t x;
     x.lo = fn_uniform(o0);
     x.size = fn_uniform(o1) - x.lo;
     x.out = fn_uniform(oo);
+    x.src = pstride ? bb * pstride : x.lo;
     x.nb = x.size > FF_CAP ? 0 : (int)x.size;
     return x;
   };
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   // larger ones (uniform branches around whole groups of instructions, none inside).
   constexpr int FF_USUAL = 12;
   auto load_keys = [&](const bucket_t& x) {              // k[q] = key tid + 512 q of the bucket (clamped: branch-free)
-    const uint64_t* Ab = A + x.lo;                       // scalar base + 32-bit lane offsets
+    const uint64_t* Ab = A + x.src;                      // scalar base + 32-bit lane offsets
     const int t = fn_fresh(tid);
     if (x.nb > 0) {
 #pragma unroll
@@ -663,7 +670,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   for (int q = 0; q < FF_ITEMS; ++q) k[q] = 0;
   int64_t f0, f1, fo;
   fetch_offsets((int64_t)blockIdx.x, f0, f1, fo);
-  bucket_t cur = open_bucket(f0, f1, fo);
+  bucket_t cur = open_bucket((int64_t)blockIdx.x, f0, f1, fo);
   load_keys(cur);
   fetch_offsets((int64_t)blockIdx.x + G, f0, f1, fo);
   // The first two buckets of a workgroup are blockIdx and blockIdx + G; after that the buckets are handed out by a
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
   __syncthreads();
   b_n2 = fn_uniform(sh[2]);
   for (; b < n_buckets;) {
-    const bucket_t nxt = open_bucket(f0, f1, fo);        // bucket b_nxt (its offsets were fetched an iteration ago)
+    const bucket_t nxt = open_bucket(b_nxt, f0, f1, fo); // bucket b_nxt (its offsets were fetched an iteration ago)
     fetch_offsets(b_n2, f0, f1, fo);
     unsigned long long tk = 0;                           // the ticket after b_n2: in flight until the keys are placed
     if (tid == 0) tk = atomicAdd(&header[FS_FTICKET], 1ull);
@@ -1088,6 +1095,19 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                        const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream) {
+  return bnpk_finish_sorted_strided(ctx, d_part, n, 0, d_bucket_offsets, n_buckets, low_bits, d_keys_out, d_counts_out, d_state,
+                                    d_big_table, n_big, d_big_keys, d_big_counts, h_n_unique, h_overflow, stream);
+}
+
+// part_stride != 0: bucket b's keys lie at d_part + b * part_stride (bnpk_radix_partition_claimed + bnpk_claimed_finalize);
+// d_bucket_offsets says how many they are and where they would lie in a dense array (the output positions derive from that)
+int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_t part_stride, const int64_t* d_bucket_offsets,
+                               int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                               const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
+                               int64_t* h_n_unique, int* h_overflow, void* stream) {
+  const int64_t pstride = part_stride;
+  const int64_t n_slots = pstride ? n_buckets * pstride : n;   // elements of d_part
+  if (pstride < 0) return BNPK_ERR_ARG;
   if (!ctx || n < 0 || n_buckets < 1 || low_bits < 0 || low_bits > 63 || !h_n_unique || !h_overflow || !d_state ||
       !d_bucket_offsets || n_big < 0 || (n_big > 0 && (!d_big_table || !d_big_keys || !d_big_counts)))
     return BNPK_ERR_ARG;
@@ -1140,12 +1160,12 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       BNPK_HIP(ctx, hipMemsetAsync(state + FS_TICKET, 0, 8, s));
       hipLaunchKernelGGL(finish_sorted_kernel<1>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
                          n_buckets, sshift, sbits, state, keys_out, d_counts_out, d_big_table, n_big, big_keys,
-                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)redo_bases, n_redo, (int64_t*)nullptr);
+                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)redo_bases, n_redo, (int64_t*)nullptr, pstride);
     } else {
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)(FS_BUCKETS + n_buckets + 1) * 8, s));
       hipLaunchKernelGGL(finish_sorted_kernel<0>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, part, d_bucket_offsets,
                          n_buckets, sshift, sbits, state, keys_out, d_counts_out, d_big_table, n_big, big_keys,
-                         d_big_counts, (const unsigned*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr);
+                         d_big_counts, (const unsigned*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, pstride);
     }
     BNPK_HIP(ctx, hipGetLastError());
     return BNPK_OK;
@@ -1160,22 +1180,22 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
   auto duplicate_aware = [&](bool wave_first) -> int {
     BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
     if (wave_first) {
-      BNPK_CHECK(bnpk_finish_wave_launch(ctx, false, 0, part, n, d_bucket_offsets, n_buckets, low_bits, state, Dv, todo_ids,
-                                         d_keys_out, d_big_table, n_big, big_keys, d_big_counts, s));
+      BNPK_CHECK(bnpk_finish_wave_launch(ctx, false, 0, part, n_slots, d_bucket_offsets, n_buckets, low_bits, state, Dv, todo_ids,
+                                         d_keys_out, d_big_table, n_big, big_keys, d_big_counts, pstride, s));
     }
     BNPK_CHECK(bnpk_finish_dup_launch(ctx, part, d_bucket_offsets, n_buckets, low_bits, state, Dv, redo_ids, d_keys_out,
-                                      d_big_table, n_big, big_keys, d_big_counts, wave_first ? todo_ids : nullptr, s));
+                                      d_big_table, n_big, big_keys, d_big_counts, wave_first ? todo_ids : nullptr, pstride, s));
     {
       const int sbits = std::min(low_bits, FN_MAXBITS), sshift = low_bits - sbits;
       const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units);
       hipLaunchKernelGGL(finish_sorted_kernel<2>, dim3(grid), dim3(FN_THREADS), FN_LDS, s, (const uint64_t*)part,
                          d_bucket_offsets, n_buckets, sshift, sbits, state, part, d_keys_out, d_big_table, n_big, big_keys,
-                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)nullptr, (int64_t)0, Dv);
+                         d_big_counts, (const unsigned*)redo_ids, (const int64_t*)nullptr, (int64_t)0, Dv, pstride);
       BNPK_HIP(ctx, hipGetLastError());
     }
     BNPK_CHECK(bnpk_scan_launch(ctx, Dv, n_buckets, 1, Dv, true, (int64_t*)scan_scratch, s));
-    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_keys_out, d_counts_out, d_bucket_offsets, Dv, n_buckets, state, s));
-    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_part, d_keys_out, d_bucket_offsets, Dv, n_buckets, state, s));
+    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_keys_out, d_counts_out, d_bucket_offsets, Dv, n_buckets, state, 0, s));
+    BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_part, d_keys_out, d_bucket_offsets, Dv, n_buckets, state, pstride, s));
     return BNPK_OK;
   };
   // finish_mode 0: a probe decides — a sample of the buckets goes through the wavefront kernel's table; if (nearly) all of
@@ -1189,7 +1209,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
     BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
     BNPK_HIP(ctx, hipMemsetAsync(meta, 0, (size_t)n_buckets * 4, s));
     BNPK_CHECK(bnpk_finish_multi_launch(ctx, part, d_bucket_offsets, n_buckets, low_bits, state, meta, keys_out, d_counts_out,
-                                        d_big_table, n_big, big_keys, d_big_counts, redo_ids, redo_bases, s));
+                                        d_big_table, n_big, big_keys, d_big_counts, redo_ids, redo_bases, pstride, s));
     BNPK_CHECK(read_header());
     if (host[FS_FLAGS] & 2) return BNPK_OK;               // (a wait gave up: the caller takes the general kernel)
     if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
@@ -1214,8 +1234,8 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
                          d_bucket_offsets, n_buckets, state);
       const int64_t probe_buckets = 1024;
       if (mode == 0 && can_wave)
-        BNPK_CHECK(bnpk_finish_wave_launch(ctx, true, probe_buckets, part, n, d_bucket_offsets, n_buckets, low_bits, state, Dv,
-                                           todo_ids, d_keys_out, d_big_table, n_big, big_keys, d_big_counts, s));
+        BNPK_CHECK(bnpk_finish_wave_launch(ctx, true, probe_buckets, part, n_slots, d_bucket_offsets, n_buckets, low_bits, state, Dv,
+                                           todo_ids, d_keys_out, d_big_table, n_big, big_keys, d_big_counts, pstride, s));
       int64_t probe[4] = {0, 0, 0, 0};
       BNPK_HIP(ctx, hipMemcpyAsync(probe, d_state + FS_PROBE_BAD, sizeof(probe), hipMemcpyDeviceToHost, s));
       BNPK_CHECK(read_header());
@@ -1244,11 +1264,11 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
       if (sshift <= 32)
         hipLaunchKernelGGL(finish_fast_kernel<true>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, (const uint64_t*)part, d_bucket_offsets,
                            out_off, n_buckets, sshift, sbits, state, Dv, meta, keys_out, d_counts_out, d_big_table,
-                           n_big, big_keys, d_big_counts);
+                           n_big, big_keys, d_big_counts, pstride);
       else
         hipLaunchKernelGGL(finish_fast_kernel<false>, dim3(grid), dim3(FF_THREADS), FF_LDS, s, (const uint64_t*)part, d_bucket_offsets,
                            out_off, n_buckets, sshift, sbits, state, Dv, meta, keys_out, d_counts_out, d_big_table,
-                           n_big, big_keys, d_big_counts);
+                           n_big, big_keys, d_big_counts, pstride);
       BNPK_HIP(ctx, hipGetLastError());
       BNPK_CHECK(bnpk_scan_launch(ctx, Dv, n_buckets, 1, Dv, true, (int64_t*)scan_scratch, s));
       const unsigned cgrid = grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 2048));

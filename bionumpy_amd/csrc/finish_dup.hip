@@ -87,7 +87,8 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
     uint64_t* A, const int64_t* __restrict__ bucket_off, int64_t n_buckets, int sshift, int sbits,
     unsigned long long* __restrict__ header, int64_t* __restrict__ Dv, unsigned* __restrict__ redo_ids,
     int64_t* __restrict__ loose_counts, const int64_t* __restrict__ big_table, int n_big,
-    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, const unsigned* __restrict__ todo_ids) {
+    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, const unsigned* __restrict__ todo_ids,
+    int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // the buckets to finish: all of them, or (todo_ids) the ones the wavefront kernel listed — the length of its list is
   // read here, on the device
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
   if (tid < 16) sh[tid] = 0;
   __syncthreads();
 
-  struct bucket_t { int64_t id, lo, size; int nb; };
+  struct bucket_t { int64_t id, lo, size; int nb; int64_t src; };   // src: where the bucket's keys lie in A (lo, or id * pstride)
   auto fetch_offsets = [&](int64_t j, int64_t& o0, int64_t& o1, int64_t& id) {   // (scalar loads; consumed an iteration later)
     o0 = 0; o1 = 0; id = 0;
     if (j < n_items) {
@@ -123,11 +124,12 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
     x.lo = fd_uniform(o0);
     x.size = fd_uniform(o1) - x.lo;
     x.nb = x.size > FINISH_CAP ? 0 : (int)x.size;
+    x.src = pstride ? x.id * pstride : x.lo;
     return x;
   };
   uint64_t k[FD_ITEMS];
   auto load_keys = [&](const bucket_t& x) {              // k[q] = key tid + 512 q of the bucket (clamped: branch-free)
-    const uint64_t* Ab = A + x.lo;
+    const uint64_t* Ab = A + x.src;
     const int t = fd_fresh(tid);
 #pragma unroll
     for (int q0 = 0; q0 < FD_ITEMS; q0 += FD_GROUP) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
         if (lo_i < n_big && big_table[3 * lo_i] == b) {
           D = (unsigned)fd_uniform(big_table[3 * lo_i + 1]);
           const int64_t src = fd_uniform(big_table[3 * lo_i + 2]);
-          uint64_t* ko = A + cur.lo;
+          uint64_t* ko = A + cur.src;
           int64_t* co = loose_counts + cur.lo;
           for (unsigned i = (unsigned)fd_fresh(tid); i < D; i += FD_THREADS) {
             ko[i] = big_keys[src + i];
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
       load_keys(nxt);                                    // k[] is free: the next bucket's keys, in flight until the next iteration
       const unsigned D = (unsigned)__builtin_amdgcn_readfirstlane((int)sh[0]);     // used slots = distinct keys
       const bool bad = __builtin_amdgcn_readfirstlane((int)sh[1]) != 0;
-      uint64_t* ko = A + cur.lo;                         // scalar bases, 32-bit lane offsets
+      uint64_t* ko = A + cur.src;                         // scalar bases, 32-bit lane offsets
       int64_t* co = loose_counts + cur.lo;
       const int l3 = fd_fresh(lane);
       // used slots before a slot: every wavefront scans the bitmap's popcounts in its own registers — lane l holds the
@@ -404,12 +406,12 @@ __global__ __launch_bounds__(FD_THREADS, 4) void finish_dup_kernel(
 __global__ __launch_bounds__(256) void finish_compact_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst,
                                                              const int64_t* __restrict__ bucket_off,
                                                              const int64_t* __restrict__ T, int64_t n_buckets,
-                                                             unsigned long long* __restrict__ header) {
+                                                             unsigned long long* __restrict__ header, int64_t pstride) {
   const int lane = threadIdx.x & 63;
   const int64_t n_waves = (int64_t)gridDim.x * (256 / 64);
   if (blockIdx.x == 0 && threadIdx.x == 0) header[FS_UNIQUE] = (unsigned long long)T[n_buckets];
   for (int64_t b = (int64_t)blockIdx.x * (256 / 64) + (threadIdx.x >> 6); b < n_buckets; b += n_waves) {
-    const int64_t t0 = fd_uniform(T[b]), len = fd_uniform(T[b + 1]) - t0, lo = fd_uniform(bucket_off[b]);
+    const int64_t t0 = fd_uniform(T[b]), len = fd_uniform(T[b + 1]) - t0, lo = pstride ? b * pstride : fd_uniform(bucket_off[b]);
     const int64_t* sp = src + lo;
     int64_t* dp = dst + t0;
     for (int64_t i = lane; i < len; i += 64) dp[i] = sp[i];
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void finish_compact_kernel(const int64_t* __re
 int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                            unsigned long long* header, int64_t* Dv, unsigned* redo_ids, int64_t* loose_counts,
                            const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
-                           const unsigned* todo_ids, hipStream_t s) {
+                           const unsigned* todo_ids, int64_t pstride, hipStream_t s) {
   if (!ctx->finish_dup_ready) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_dup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS));
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_dup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FD_LDS));
@@ -435,18 +437,18 @@ int bnpk_finish_dup_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_
   const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->finish_dup_grid);
   if (sshift >= 32)
     hipLaunchKernelGGL(finish_dup_kernel<true>, dim3(grid), dim3(FD_THREADS), FD_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
-                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids);
+                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids, pstride);
   else
     hipLaunchKernelGGL(finish_dup_kernel<false>, dim3(grid), dim3(FD_THREADS), FD_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
-                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids);
+                       header, Dv, redo_ids, loose_counts, big_table, n_big, big_keys, big_counts, todo_ids, pstride);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
 
 int bnpk_finish_compact_launch(bnpk_ctx* ctx, const int64_t* src, int64_t* dst, const int64_t* bucket_off, const int64_t* T,
-                               int64_t n_buckets, unsigned long long* header, hipStream_t s) {
+                               int64_t n_buckets, unsigned long long* header, int64_t pstride, hipStream_t s) {
   const unsigned grid = grid_for(std::min<int64_t>(ceil_div(n_buckets, 4), (int64_t)ctx->compute_units * 16));
-  hipLaunchKernelGGL(finish_compact_kernel, dim3(grid), dim3(256), 0, s, src, dst, bucket_off, T, n_buckets, header);
+  hipLaunchKernelGGL(finish_compact_kernel, dim3(grid), dim3(256), 0, s, src, dst, bucket_off, T, n_buckets, header, pstride);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
     unsigned long long* __restrict__ header, unsigned* __restrict__ status, uint64_t* __restrict__ keys_out,
     int64_t* __restrict__ counts_out, const int64_t* __restrict__ big_table, int n_big,
     const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, unsigned* __restrict__ redo_ids,
-    int64_t* __restrict__ redo_bases, uint64_t* park) {
+    int64_t* __restrict__ redo_bases, uint64_t* park, int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem + FM_OFF_STAGE);
   unsigned* P32 = reinterpret_cast<unsigned*>(smem + FM_OFF_P);
@@ -126,21 +126,22 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
   if (tid < FM_SLOTS) mypark[tid * FM_PARK + FM_NEAR - 1] = ~0ull;   // the sentinel in front of every parking slot
 
   uint64_t k[FM_ITEMS];
-  struct bucket_t { int64_t lo; int nb; int64_t size; };
+  struct bucket_t { int64_t lo; int nb; int64_t size; int64_t src; };   // src: where the keys lie in A (lo, or b * pstride)
   const int nbk = (int)n_buckets;                        // (< 2^30: the launcher checks)
   auto fetch_offsets = [&](int bb, int64_t& o0, int64_t& o1) {
     o0 = 0; o1 = 0;
     if (bb < nbk) { o0 = bucket_off[bb]; o1 = bucket_off[bb + 1]; }
   };
-  auto open_bucket = [&](int64_t o0, int64_t o1) {
+  auto open_bucket = [&](int bb, int64_t o0, int64_t o1) {
     bucket_t x;
     x.lo = fm_uniform(o0);
     x.size = fm_uniform(o1) - x.lo;
     x.nb = x.size > FM_CAP ? 0 : (int)x.size;
+    x.src = pstride ? (int64_t)bb * pstride : x.lo;
     return x;
   };
   auto load_keys = [&](const bucket_t& x) {
-    const uint64_t* Ab = A + x.lo;
+    const uint64_t* Ab = A + x.src;
     const int t = fm_fresh(tid);
     if (x.nb > 0) {
 #pragma unroll
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
   int b = (int)fm_uniform(sh[4]), b_nxt = (int)fm_uniform(sh[5]), b_n2 = (int)fm_uniform(sh[6]);
   int64_t f0, f1;
   fetch_offsets(b, f0, f1);
-  bucket_t cur = open_bucket(f0, f1);
+  bucket_t cur = open_bucket(b, f0, f1);
   load_keys(cur);
   fetch_offsets(b_nxt, f0, f1);
 
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
   };
   __syncthreads();
   for (; b < nbk;) {
-    const bucket_t nxt = open_bucket(f0, f1);            // bucket b_nxt (offsets fetched an iteration ago)
+    const bucket_t nxt = open_bucket(b_nxt, f0, f1);     // bucket b_nxt (offsets fetched an iteration ago)
     fetch_offsets(b_n2, f0, f1);
     unsigned long long tk = 0;
     if (tid == 0) tk = atomicAdd(&header[FS_FTICKET], 1ull);
@@ -590,7 +591,7 @@ int64_t bnpk_finish_multi_park_bytes(int grid) { return (int64_t)grid * FM_SLOTS
 int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, int low_bits,
                              unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
                              const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
-                             unsigned* redo_ids, int64_t* redo_bases, hipStream_t s) {
+                             unsigned* redo_ids, int64_t* redo_bases, int64_t pstride, hipStream_t s) {
   if (n_buckets >= (1ll << 30)) return BNPK_ERR_RANGE;
   if (!ctx->finish_multi_ready) {
     BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FM_LDS));
@@ -605,7 +606,7 @@ int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t*
   BNPK_CHECK(bnpk_scratch(ctx, (size_t)bnpk_finish_multi_park_bytes((int)grid), &park, s));
   hipLaunchKernelGGL(finish_multi_kernel, dim3(grid), dim3(FM_THREADS), FM_LDS, s, part, bucket_off, n_buckets, sshift, sbits,
                      header, status, keys_out, counts_out, big_table, n_big, big_keys, big_counts, redo_ids, redo_bases,
-                     (uint64_t*)park);
+                     (uint64_t*)park, pstride);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }

@@ -61,12 +61,13 @@ template <int N> struct fw_int { static constexpr int value = N; };
 struct fw_item {           // one request: keys [c, c + FW_ITEM) of bucket b (all fields wave-uniform)
   int64_t b, lo, size;
   int nb, c;
+  int64_t src;             // where the bucket's keys lie in A: lo, or b * pstride (finish.h)
 };
 typedef unsigned long long fw_v2 __attribute__((ext_vector_type(2), aligned(8)));
 
 // A bucket is in its wavefront's table: rank, emit and clear the entries (or leave the bucket to the next kernel).
 template <bool PROBE>
-__device__ __noinline__ void fw_finalize(uint64_t* A, int64_t b, int64_t lo, int64_t size, int nb, bool gave_up,
+__device__ __noinline__ void fw_finalize(uint64_t* A, int64_t b, int64_t lo, int64_t src_pos, int64_t size, int nb, bool gave_up,
                                          unsigned long long* __restrict__ header, int64_t* __restrict__ Dv,
                                          unsigned* __restrict__ todo_ids, int64_t* __restrict__ loose_counts,
                                          const int64_t* __restrict__ big_table, int n_big,
@@ -97,7 +98,7 @@ __device__ __noinline__ void fw_finalize(uint64_t* A, int64_t b, int64_t lo, int
         if (lo_i < n_big && big_table[3 * lo_i] == b) {
           D = (unsigned)fw_uniform(big_table[3 * lo_i + 1]);
           const int64_t src = fw_uniform(big_table[3 * lo_i + 2]);
-          uint64_t* ko = A + it.lo;
+          uint64_t* ko = A + src_pos;
           int64_t* co = loose_counts + it.lo;
           for (unsigned i = (unsigned)lane; i < D; i += 64) {
             ko[i] = big_keys[src + i];
@@ -125,7 +126,7 @@ __device__ __noinline__ void fw_finalize(uint64_t* A, int64_t b, int64_t lo, int
       return;
     }
     if (!bad) {
-      uint64_t* ko = A + it.lo;                          // scalar bases, 32-bit lane offsets
+      uint64_t* ko = A + src_pos;                          // scalar bases, 32-bit lane offsets
       int64_t* co = loose_counts + it.lo;
       // used slots before a slot: lane l holds bitmap word l and the used slots before it
       const unsigned word = lane < FW_BM_WORDS ? BM[lane] : 0u;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
     uint64_t* A, int64_t n_total, const int64_t* __restrict__ bucket_off, int64_t n_buckets, int64_t stride, int sshift, int sbits,
     unsigned long long* __restrict__ header, int64_t* __restrict__ Dv, unsigned* __restrict__ todo_ids,
     int64_t* __restrict__ loose_counts, const int64_t* __restrict__ big_table, int n_big,
-    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts) {
+    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, int64_t pstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* T = reinterpret_cast<unsigned long long*>(smem + FW_OFF_T);
   unsigned* C = reinterpret_cast<unsigned*>(smem + FW_OFF_C);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
   open(p_lo, p_hi);
   fetch(sb + G, p_lo, p_hi);
   auto next_item = [&]() -> fw_item {
-    fw_item it = {sb, s_lo, s_size, s_nb, s_c};
+    fw_item it = {sb, s_lo, s_size, s_nb, s_c, pstride ? sb * pstride : s_lo};
     s_c += FW_ITEM;
     if (s_c >= s_nb) {                                   // (uniform) the bucket is exhausted
       sb += G;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
   // bucket's last key — at an odd position — arrives as the second element.  Past the last bucket: the array's start.
   auto issue = [&](const fw_item& it, fw_v2 (&r)[2]) {
     const bool in = it.b < n_buckets;
-    const uint64_t* base = A + (in ? (it.nb >= 2 ? it.lo : std::min<int64_t>(it.lo, n_total - 2)) : 0);
+    const uint64_t* base = A + (in ? (it.nb >= 2 ? it.src : std::min<int64_t>(it.src, n_total - 2)) : 0);
     const unsigned span = (in && it.nb >= 2) ? (unsigned)(it.nb - 2) : 0u;
 #if FW_ABL & 1
     if (it.b >= 3 * (int64_t)gridDim.x) return;          // (no loads after the first buckets: the registers keep their keys)
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
     }
     FW_MARK(3)
     if (it.c + FW_ITEM < nb) return;                     // (uniform) more requests of this bucket follow
-    fw_finalize<PROBE>(A, it.b, it.lo, it.size, nb, __any(gave_up), header, Dv, todo_ids, loose_counts, big_table, n_big, big_keys,
+    fw_finalize<PROBE>(A, it.b, it.lo, it.src, it.size, nb, __any(gave_up), header, Dv, todo_ids, loose_counts, big_table, n_big, big_keys,
                        big_counts);
     gave_up = false;
     FW_MARK(4)
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64) void finish_wave_kernel(
 int bnpk_finish_wave_launch(bnpk_ctx* ctx, bool probe, int64_t probe_buckets, uint64_t* part, int64_t n, const int64_t* bucket_off,
                             int64_t n_buckets, int low_bits, unsigned long long* header, int64_t* Dv, unsigned* todo_ids,
                             int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
-                            const int64_t* big_counts, hipStream_t s) {
+                            const int64_t* big_counts, int64_t pstride, hipStream_t s) {
   if (n < 2) return BNPK_ERR_ARG;                        // (the loads are pairs of keys)
   if (!ctx->finish_wave_ready) {
     int per_cu = 1 << 30;
@@ -405,7 +406,7 @@ int bnpk_finish_wave_launch(bnpk_ctx* ctx, bool probe, int64_t probe_buckets, ui
   const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n_buckets, stride), (int64_t)ctx->finish_wave_grid);
 #define FW_LAUNCH(HI, PROBE)                                                                                                  \
   hipLaunchKernelGGL((finish_wave_kernel<HI, PROBE>), dim3(grid), dim3(64), FW_LDS, s, part, n, bucket_off, n_buckets, stride, \
-                     sshift, sbits, header, Dv, todo_ids, loose_counts, big_table, n_big, big_keys, big_counts)
+                     sshift, sbits, header, Dv, todo_ids, loose_counts, big_table, n_big, big_keys, big_counts, pstride)
   if (sshift >= 32) { if (probe) FW_LAUNCH(true, true); else FW_LAUNCH(true, false); }
   else { if (probe) FW_LAUNCH(false, true); else FW_LAUNCH(false, false); }
 #undef FW_LAUNCH

@@ -293,7 +293,8 @@ def device_listing(obj_path):
                 os.remove(tmp + ext)
 
 
-ARITH = re.compile(r"^s_(add|sub|addc|subb|lshl|lshr|ashr|mul|bfe|bcnt|min|max|abs|not|absdiff)\w*$")
+# (S_MUL_I32 / S_MUL_HI_* do not write SCC: a select behind them still reads the compare in front of them)
+ARITH = re.compile(r"^s_(add|sub|addc|subb|lshl|lshr|ashr|bfe|bcnt|min|max|abs|not|absdiff)\w*$")
 COMPARE = re.compile(r"^s_(cmp|cmpk|bitcmp|and|or|xor|andn2|orn2|nand|nor|xnor)\w*$")
 USER = re.compile(r"^s_(cselect|cbranch_scc)")
 VCMP64 = re.compile(r"^v_cmp_\w+_[iu]64")

@@ -914,6 +914,27 @@ __global__ void rp_claimed_sizes_kernel(const unsigned* __restrict__ fill, int64
     sizes[i] = (int64_t)min(fill[2 * i], (unsigned)RPC_CAP_LO) + (int64_t)min(fill[2 * i + 1], (unsigned)RPC_TAIL);
 }
 
+// a bucket's leftover keys move from the tail of its slots to right behind its lines: the bucket is ONE dense run from then
+// on and the finishing kernels read it like any other, only at slot b * RPC_STRIDE instead of at its offset.  One wavefront
+// per bucket takes the <= 128 keys into registers before it stores any of them (source and destination may overlap).
+__global__ __launch_bounds__(256) void rp_claimed_tails_kernel(uint64_t* __restrict__ buckets, const unsigned* __restrict__ fill,
+                                                               int64_t n_buckets) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = (int64_t)gridDim.x * (256 / 64);
+  for (int64_t b = (int64_t)blockIdx.x * (256 / 64) + (threadIdx.x >> 6); b < n_buckets; b += waves) {
+    const unsigned lo = min(fill[2 * b], (unsigned)RPC_CAP_LO), hi = min(fill[2 * b + 1], (unsigned)RPC_TAIL);
+    if (hi == 0 || lo == (unsigned)RPC_CAP_LO) continue;
+    uint64_t* base = buckets + b * RPC_STRIDE;
+    uint64_t v0 = 0, v1 = 0;
+    if ((unsigned)lane < hi) v0 = base[RPC_CAP_LO + lane];
+    if ((unsigned)lane + 64 < hi) v1 = base[RPC_CAP_LO + lane + 64];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((unsigned)lane < hi) base[lo + lane] = v0;
+    if ((unsigned)lane + 64 < hi) base[lo + lane + 64] = v1;
+  }
+}
+
 // the claiming level: slab table -> scatter (no histogram, no scan)
 int rp_level_claimed(bnpk_ctx* ctx, const mem_source& src, int64_t n, const int64_t* d_seg_off, int64_t n_seg, int shift, int bits,
                      uint64_t* d_buckets, const rp_claim_t& claim, char* scratch, hipStream_t s) {
@@ -1093,14 +1114,17 @@ int bnpk_radix_partition_claimed(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n
   return rp_level_claimed(ctx, src, n, d_seg_offsets, n_seg, shift, bits, reinterpret_cast<uint64_t*>(d_buckets), claim, (char*)scratch, s);
 }
 
-int bnpk_claimed_offsets(bnpk_ctx* ctx, const uint32_t* d_fill, int64_t n_buckets, int64_t* d_bucket_offsets, void* stream) {
-  if (!ctx || n_buckets < 1 || !d_fill || !d_bucket_offsets) return BNPK_ERR_ARG;
+int bnpk_claimed_finalize(bnpk_ctx* ctx, int64_t* d_buckets, const uint32_t* d_fill, int64_t n_buckets, int64_t* d_bucket_offsets,
+                          void* stream) {
+  if (!ctx || n_buckets < 1 || !d_fill || !d_bucket_offsets || !d_buckets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   void* scratch = nullptr;
   BNPK_CHECK(bnpk_scratch(ctx, align64((size_t)n_buckets * 8) + align64(bnpk_scan_scratch_bytes(n_buckets)), &scratch, s));
   int64_t* sizes = reinterpret_cast<int64_t*>(scratch);
   int64_t* scan_scratch = reinterpret_cast<int64_t*>((char*)scratch + align64((size_t)n_buckets * 8));
-  bnpk_timer t(ctx, "claimed_offsets", s);
+  bnpk_timer t(ctx, "claimed_finalize", s);
+  hipLaunchKernelGGL(rp_claimed_tails_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 4), (int64_t)ctx->compute_units * 32))),
+                     dim3(256), 0, s, reinterpret_cast<uint64_t*>(d_buckets), d_fill, n_buckets);
   hipLaunchKernelGGL(rp_claimed_sizes_kernel, dim3(grid_for(ceil_div(n_buckets, 256))), dim3(256), 0, s, d_fill, n_buckets, sizes);
   BNPK_HIP(ctx, hipGetLastError());
   return bnpk_scan_launch(ctx, sizes, n_buckets, 1, d_bucket_offsets, true, scan_scratch, s);

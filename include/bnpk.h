@@ -562,6 +562,12 @@ int bnpk_sort_pairs(bnpk_ctx* ctx, int64_t* d_keys, int64_t* d_keys_alt, int64_t
  *                         back over the bucket's own keys before they are moved into place). */
 int64_t bnpk_radix_max_bits(void);
 int64_t bnpk_finish_capacity(void);
+/* bnpk_finish_sorted over buckets of fixed stride (bnpk_radix_partition_claimed + bnpk_claimed_finalize): bucket b's keys lie
+ * at d_part + b * part_stride, d_bucket_offsets are the offsets of the equivalent dense layout; part_stride 0 = bnpk_finish_sorted */
+int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_t part_stride, const int64_t* d_bucket_offsets,
+                               int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
+                               const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
+                               int64_t* h_n_unique, int* h_overflow, void* stream);
 int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
                          int shift, int bits, int64_t* d_out, int64_t* d_child_offsets, void* stream);
 /* The same level WITHOUT its histogram pass (round 5: the second level of the 31-mer path — 48 GB that were read only to
@@ -571,14 +577,16 @@ int bnpk_radix_partition(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const 
  * [0, min(d_fill[2c], cap_lo)) and [cap_lo, cap_lo + min(d_fill[2c+1], stride - cap_lo)) of its slots; keys without a place
  * (a bucket over the finishing kernels' capacity, a segment of very many slabs) go to d_bag — *d_bag_fill of them, an
  * unordered multiset the caller counts on its own and merges in; *d_bag_fill > bag_cap: keys were dropped, use
- * bnpk_radix_partition.  bnpk_claimed_offsets turns d_fill into the n_buckets + 1 offsets of the equivalent dense layout
- * (sizes, output positions); bnpk_finish_sorted_claimed reads the buckets where they lie. */
+ * bnpk_radix_partition.  bnpk_claimed_finalize moves every bucket's leftover keys right behind its lines (one dense run per
+ * bucket from then on, at slot c * stride) and turns d_fill into the n_buckets + 1 offsets of the equivalent dense layout
+ * (sizes, output positions); bnpk_finish_sorted_strided reads the buckets where they lie. */
 int64_t bnpk_claimed_stride(void);
 int64_t bnpk_claimed_cap_lo(void);
 int bnpk_radix_partition_claimed(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n, const int64_t* d_seg_offsets, int64_t n_seg,
                                  int shift, int bits, int64_t* d_buckets, uint32_t* d_fill, int64_t* d_bag, int64_t bag_cap,
                                  int64_t* d_bag_fill, void* stream);
-int bnpk_claimed_offsets(bnpk_ctx* ctx, const uint32_t* d_fill, int64_t n_buckets, int64_t* d_bucket_offsets, void* stream);
+int bnpk_claimed_finalize(bnpk_ctx* ctx, int64_t* d_buckets, const uint32_t* d_fill, int64_t n_buckets, int64_t* d_bucket_offsets,
+                          void* stream);
 /* one more MSD level over MANY SMALL segments (each at most bnpk_radix_small_capacity() keys, bits <= 4): one
  * workgroup takes a whole segment, ranks with wave ballots and writes it back as one contiguous run.  Same
  * outputs as bnpk_radix_partition; BNPK_ERR_RANGE if a segment was larger (outputs then invalid). */

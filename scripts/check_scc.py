@@ -16,7 +16,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bionumpy_amd", "csrc")
-ARITH = re.compile(r"^\s*s_(add|sub|addc|subb|lshl|lshr|ashr|mul|bfe|bcnt|min|max|abs|not|absdiff)\w*\s")
+ARITH = re.compile(r"^\s*s_(add|sub|addc|subb|lshl|lshr|ashr|bfe|bcnt|min|max|abs|not|absdiff)\w*\s")
 COMPARE = re.compile(r"^\s*s_(cmp|cmpk|bitcmp|and|or|xor|andn2|orn2|nand|nor|xnor)\w*\s")
 USER = re.compile(r"^\s*s_(cselect|cbranch_scc)")
 VCMP64 = re.compile(r"^\s*v_cmp_\w+_[iu]64")

@@ -68,13 +68,27 @@ def _cases():
 def test_every_finishing_kernel_counts_like_np_unique(env, name, keys):
     ops, lib, dev, ptr, torch = env
     ek, ec = oracle.count_sparse(keys)
-    for mode in MODES:
-        assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
-        h = HArray(host=keys.copy())
-        gk, gc = ops.count_sparse(h, key_bits=62)
-        assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), (name, mode)
-        # bnpk_finish_sorted uses the partitioned keys as workspace — never the caller's array
-        assert np.array_equal(h.dev().cpu().numpy(), keys), (name, mode)
+    taken = set()
+    try:
+        # claim: the last partition level without its histogram pass, the finishing kernels reading buckets of fixed stride
+        # (round 5; keys without a place in their bucket — the heavy hitters — counted apart and merged in) / the plain level
+        for claim in (True, False):
+            ops.claim_last_level = claim
+            for mode in MODES:
+                assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
+                h = HArray(host=keys.copy())
+                ops.last_claimed = None
+                gk, gc = ops.count_sparse(h, key_bits=62)
+                assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), (name, mode, claim)
+                # bnpk_finish_sorted uses the partitioned keys as workspace — never the caller's array
+                assert np.array_equal(h.dev().cpu().numpy(), keys), (name, mode)
+                if ops.last_claimed is not None:
+                    assert claim
+                    taken.add("bag" if ops.last_claimed["bag"] else "claimed")
+    finally:
+        ops.claim_last_level = True
+    if keys.size >= (1 << 20):
+        assert taken, "the claiming level never ran on %s" % name
 
 
 def _direct(env, keys, top_bits):
@@ -99,6 +113,21 @@ def _direct(env, keys, top_bits):
         assert np.array_equal(out_k[:nu.value].cpu().numpy(), ek) and np.array_equal(out_c[:nu.value].cpu().numpy(), ec), mode
         handed_back[mode] = int(state[3].item())
         handed_back[(mode, "wave")] = int(state[6].item())          # buckets the wavefront kernel left to the workgroup kernel
+        # the same buckets at a fixed stride (bnpk_finish_sorted_strided: what the claiming level leaves behind)
+        sizes = np.diff(off)
+        stride = int(lib.bnpk_claimed_stride())
+        if sizes.max() <= stride:
+            spread = np.full(nb * stride, -1, dtype=np.int64)
+            for b in np.flatnonzero(sizes):
+                spread[b * stride:b * stride + sizes[b]] = part[off[b]:off[b + 1]]
+            work, out_k, out_c = torch.from_numpy(spread).cuda(), torch.empty(keys.size, dtype=torch.int64, device="cuda"), \
+                torch.empty(keys.size, dtype=torch.int64, device="cuda")
+            nu, ov = C.c_int64(0), C.c_int(0)
+            assert lib.bnpk_finish_sorted_strided(dev.ctx, ptr(work), keys.size, stride, ptr(d_off), nb, 62 - top_bits, ptr(out_k), ptr(out_c),
+                                                  ptr(state), None, 0, None, None, C.byref(nu), C.byref(ov), dev.stream()) == 0
+            assert ov.value == 0 and nu.value == ek.size, ("strided", mode)
+            assert np.array_equal(out_k[:nu.value].cpu().numpy(), ek) and np.array_equal(out_c[:nu.value].cpu().numpy(), ec), ("strided", mode)
+            assert handed_back[mode] == int(state[3].item()) and handed_back[(mode, "wave")] == int(state[6].item())
     return handed_back
 
 
@@ -157,8 +186,12 @@ def test_repeats_in_every_bucket_at_scale(env, mode):
     assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
     ops.keep_finish_state = True
     try:
-        gk, gc = ops.count_sparse(HArray(host=base), key_bits=62)
-        assert gk.size == ek.size and np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec)
-        assert int(ops.last_finish_state[0]) == 0                     # no flag: nothing overflowed, no wait gave up
+        for claim in (True, False):
+            ops.claim_last_level, ops.last_claimed = claim, None
+            gk, gc = ops.count_sparse(HArray(host=base), key_bits=62)
+            assert gk.size == ek.size and np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), claim
+            assert int(ops.last_finish_state[0]) == 0                     # no flag: nothing overflowed, no wait gave up
+            assert (ops.last_claimed is not None) == claim
     finally:
         ops.keep_finish_state = False
+        ops.claim_last_level = True
