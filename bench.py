@@ -50,6 +50,8 @@ def algorithmic_bytes(name, s, read_len, k, n_distinct=None):
         "kmers_partition_scatter": bases / 4 + bases / 8 + 8 * kmers,   # same input, every hash written once
         "radix_hist": 8 * kmers,                              # read every key
         "radix_scatter": 16 * kmers,                          # read every key, write it to its bucket
+        "radix_scatter_claimed": 16 * kmers,                  # the same level without its histogram pass (round 5): places claimed line by line
+        "claimed_finalize": 16 * 30 * (kmers / 5722) + 16 * (kmers / 5722),   # ~30 leftover keys per bucket moved + the fill counters scanned
         "finish_sorted": 8 * kmers + 16 * distinct,           # read the bucketed keys, write key + count per distinct key
         "sort_keys": 16 * kmers,                              # (fallback path) read every key once, write it once sorted
         "run_census": 8 * kmers,
@@ -625,7 +627,7 @@ def main():
     traffic, traffic_source = None, None
     try:
         from bionumpy_amd.csrc.build import _source_hash
-        for cand in (("r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
+        for cand in (("r05_genome_pmc.json", "r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
             path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -636,6 +638,7 @@ def main():
             if not same_work or pmc.get("_source_hash") != _source_hash():
                 continue
             names = {"finish_sorted": "finish_wave" if args.mode == "genome" else "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
+                     "radix_scatter_claimed": "rp_scatter<mem_source, claiming>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
                      "fastq_encode": "fq_encode_fast", "fastq_census": "fq_census_fast"}
             rec = pmc.get(names.get(dom, dom)) or pmc.get(dom)

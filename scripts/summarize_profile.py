@@ -34,7 +34,11 @@ def _short(name):
     if "rp_scatter_kernel" in name or "rp_hist_kernel" in name:
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
-        return "%s<%s>" % (kind, src)
+        claim = ", claiming" if kind == "rp_scatter" and name.replace(" ", "").rstrip(">").endswith("true") else ""
+        return "%s<%s%s>" % (kind, src, claim)
+    for key in ("rp_claimed_tails", "rp_claimed_sizes", "hist_bytes_small", "hist_bytes_rows", "hist_packed2"):
+        if key in name:
+            return key
     for key in ("finish_multi_kernel", "bucket_census", "bucket_list", "window_cuts", "rebase_lines", "copy_plain", "copy_oneshot", "copy_unrolled"):
         if key in name:
             return key.replace("_kernel", "")
