@@ -1217,8 +1217,14 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
   };
   const int mode = ctx->finish_mode;
   const bool can_wave = n >= 2;
-  bool use_general = mode == 1, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
-  bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG;
+  // Few buckets (a histogram of ten million keys, not of billions: a chunk's k-mers, a KmerIndex): the general kernel takes
+  // them in one launch, ~11 us per bucket and workgroup, and no answer from the device is needed before the end — the probe,
+  // the fast kernel's attempt and what follows it are three round trips and a dozen launches, and the kernels built for a
+  // million buckets (tickets three iterations ahead, parking rings, look-backs over thousands of status words) idle through
+  // most of them: the sacCer3 index spent 3.6 of its 8.4 ms in one finish_multi call over 2048 buckets.
+  const bool few = mode == 0 && n_buckets <= (int64_t)16 * ctx->compute_units;
+  bool use_general = mode == 1 || few, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
+  bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG && !few;
   bool use_multi = mode == 5;
   bool nearly_distinct = false;
   // (one arena: the scan partials of the fast / duplicate-aware paths, or the parking ring of the multiplicity kernel —
@@ -1228,7 +1234,8 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
                             &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
-    if (mode == 0 || try_fast || use_multi) {
+    if (!few && (mode == 0 || try_fast || use_multi)) {
+      bnpk_timer t_probe(ctx, "finish.probe", s);
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,
                          d_bucket_offsets, n_buckets, state);
@@ -1250,6 +1257,7 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       }
     }
     if (try_fast) {
+      bnpk_timer t_fast(ctx, "finish.fast", s);
       const int sbits = std::min(low_bits, FF_MAXBITS), sshift = low_bits - sbits;
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       BNPK_HIP(ctx, hipMemsetAsync(marks, 0, (size_t)n_buckets * 4, s));
@@ -1288,12 +1296,13 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       else use_dup = true;
     }
     if (use_multi) {
+      bnpk_timer t_multi(ctx, "finish.multi", s);
       BNPK_CHECK(multi());
       if (host[FS_FLAGS] & 2) use_general = true;
     }
-    if (use_wave) BNPK_CHECK(duplicate_aware(true));
-    else if (use_dup) BNPK_CHECK(duplicate_aware(false));
-    if (use_general) BNPK_CHECK(general(false, 0));
+    if (use_wave) { bnpk_timer t_wave(ctx, "finish.cascade", s); BNPK_CHECK(duplicate_aware(true)); }
+    else if (use_dup) { bnpk_timer t_dup(ctx, "finish.dup", s); BNPK_CHECK(duplicate_aware(false)); }
+    if (use_general) { bnpk_timer t_gen(ctx, "finish.general", s); BNPK_CHECK(general(false, 0)); }
   }
   BNPK_CHECK(read_header());
   *h_overflow = (int)(host[FS_FLAGS] & 3);              // 1: a bucket over the capacity without a pre-counted entry; 2: a wait gave up
