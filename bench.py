@@ -289,11 +289,114 @@ def extras(args, ops, dev, main_stats, copy_rate):
                                                  "kernels_ms": {n: round(v["total_ms"] / 2, 2) for n, v in prof.items()},
                                                  "parity": bool(ok), "parity_detail": "the rewritten text parses back; its sequences reverse-complemented are the original ones"}
             del new_text, again, orig
+
+            # ---- results that stay on the device (round 5): which reads contain a motif, the base composition of the batch
+            from bionumpy_amd import synth
+            dna = bnp.change_encoding(bnp.FastQBuffer.from_raw_buffer(text).get_field_by_number(1), bnp.DNAEncoding)
+            dna._compact()
+            motif = "GATTACA"
+
+            def reads_with_motif():
+                return bnp.match_string(dna, motif).any(axis=-1)
+            mask, dt, prof = timed(reads_with_motif, 3)
+            on_device = mask.harray()._np is None
+            n_hit = int(mask.sum())
+            sample = 20000
+            codes = synth.read_codes(sample, args.read_len, args.seed, 0, 0, 0)
+            want = np.array([motif in "".join("ACGT"[c] for c in row) for row in codes])
+            km7 = bnp.get_kmers(dna, 7)
+            km7._compact()
+            target = sum("ACGT".index(ch) << (2 * j) for j, ch in enumerate(motif))
+            windows = int((km7._flat_data().dev() == target).sum().item())
+            hits_total = int(bnp.match_string(dna, motif).sum(axis=None))
+            ok = on_device and np.array_equal(np.asarray(mask)[:sample], want) and hits_total == windows and 0 < n_hit <= hits_total
+            del km7
+            out["match_string_any"] = {"workload": "match_string(reads, %r).any(axis=-1) on the same %d reads (2-bit DNA)" % (motif, args.reads),
+                                       "ms_per_step": round(dt * 1e3, 2), "steps": 3, "reads_with_motif": n_hit, "windows_matching": hits_total,
+                                       "flags_left_the_device": not on_device, "kernels_ms": {n: round(v["total_ms"] / 3, 2) for n, v in prof.items()},
+                                       "parity": bool(ok), "parity_detail": "first %d reads against Python's `in` on the generator's twin; matching windows == 7-mer hashes equal to the motif's (another kernel)" % sample}
+            del mask
+
+            def composition():
+                return bnp.count_encoded(dna, axis=None)
+            comp, dt, prof = timed(composition, 3)
+            from bionumpy_amd.encoded_array import packed_words
+            n_part = min(int(dna.total()), 1 << 28)
+            unpacked = ops.unpack_codes(packed_words(dna._data), n_part, to_ascii=False)
+            ref = torch.bincount(unpacked.dev().to(torch.int32), minlength=4).cpu().numpy()
+            part = np.asarray(ops.count_bytes(unpacked, 4).host())                                   # (bytes: the other kernel)
+            whole = np.asarray(comp.counts)
+            ok = int(whole.sum()) == int(dna.total()) and np.array_equal(part, ref) and (n_part < dna.total() or np.array_equal(whole, ref))
+            del unpacked
+            out["letter_counts"] = {"workload": "count_encoded(reads, axis=None): the base composition of %d bases, from the 2-bit words" % int(dna.total()),
+                                    "ms_per_step": round(dt * 1e3, 2), "steps": 3, "counts": [int(x) for x in comp.counts],
+                                    "kernels_ms": {n: round(v["total_ms"] / 3, 2) for n, v in prof.items()},
+                                    "roofline": roof(prof, "count_packed2", dna.total() / 4, 3),
+                                    "parity": bool(ok), "parity_detail": "counts add up to the bases; the byte kernel on the first 2^28 unpacked codes == torch.bincount"}
+            del dna
         except AssertionError as e:
             out["config3_api_objects"] = {"parity": False, "error": str(e)}
         del text
     except AssertionError as e:
         out["config3_minimizers"] = {"parity": False, "error": str(e)}
+    torch.cuda.empty_cache()
+
+    # ---- (f2) multi-line FASTA at speed: a 1 GB synthetic genome (60-letter lines, records of ~8 Mbp) read through bnp.open
+    # (file -> pinned RAM -> HBM -> bnpk_multiline_* -> sequences), then cached as a MemMapEncodedRaggedArray and loaded back
+    try:
+        import tempfile
+        rng = np.random.default_rng(11)
+        n_rec, per_rec, width = 128, 8_000_040, 60
+        lines = per_rec // width
+        body = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(lines, width), dtype=np.int8)]
+        rec = np.concatenate([body, np.full((lines, 1), 10, dtype=np.uint8)], axis=1).reshape(-1)
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+        fa = os.path.join(tmpdir, "bnpk_bench_%d.fa" % os.getpid())
+        with open(fa, "wb") as f:
+            for i in range(n_rec):                            # (the same body under every header: the decode does not care)
+                f.write(b">chr%d synthetic\n" % i)
+                f.write(rec.data)
+        fa_bytes = os.path.getsize(fa)
+
+        def read_all():
+            n_b = n_r = 0
+            for chunk in bnp.open(fa).read_chunks(min_chunk_size=256 << 20):
+                seq = chunk.sequence
+                n_b += int(seq.total()); n_r += len(seq)
+            return n_b, n_r
+        read_all()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_b, n_r = read_all()
+        torch.cuda.synchronize()
+        t_read = time.perf_counter() - t0
+        # parity: the rows of one chunk against the bytes they were written from
+        first = next(iter(bnp.open(fa).read_chunks(min_chunk_size=32 << 20)))
+        row0 = np.asarray(first.sequence[0].raw())
+        ok = n_r == n_rec and n_b == n_rec * lines * width and row0.size == lines * width and np.array_equal(row0, body.reshape(-1))
+        base = os.path.join(tmpdir, "bnpk_bench_%d_mm" % os.getpid())
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            bnp.MemMapEncodedRaggedArray.create(lambda: (bnp.change_encoding(c.sequence, bnp.DNAEncoding) for c in bnp.open(fa).read_chunks(min_chunk_size=256 << 20)), base)
+            t_create = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        loaded = bnp.MemMapEncodedRaggedArray.load(base)
+        km = bnp.count_kmers(loaded, 5)
+        torch.cuda.synchronize()
+        t_load = time.perf_counter() - t0
+        ok = ok and int(np.sum(km.counts)) == n_rec * (lines * width - 4)
+        for suffix in ("_data.dat", "_lengths.dat", "_encoding.pkl"):
+            if os.path.exists(base + suffix):
+                os.remove(base + suffix)
+        os.remove(fa)
+        out["multiline_fasta"] = {"workload": "synthetic multi-line FASTA, %d records x %d bases in %d-letter lines (%.2f GB)" % (n_rec, lines * width, width, fa_bytes / 1e9),
+                                  "read_decode_s": round(t_read, 3), "file_gb_per_s": round(fa_bytes / t_read / 1e9, 2),
+                                  "memmap_create_s": round(t_create, 2), "memmap_load_and_count_5mers_s": round(t_load, 3),
+                                  "parity": bool(ok), "parity_detail": "records / bases of all chunks, the first row byte for byte, the 5-mers of the loaded cache"}
+    except Exception as e:                                   # noqa: BLE001
+        out["multiline_fasta"] = {"parity": False if isinstance(e, AssertionError) else None, "error": "%s: %s" % (type(e).__name__, e)}
     torch.cuda.empty_cache()
 
     # ---- config 5: sacCer3 k = 31 KmerIndex build + lookup of every 31-mer of big.fq.gz (tests/golden/)
