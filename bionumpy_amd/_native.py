@@ -122,6 +122,7 @@ SIGNATURES = {
     "bnpk_windows_flat": (_int, [_p, _p, _p, _i64, _int, _int, _i64, _p, _p]),
     "bnpk_match_windows_packed": (_int, [_p, _p, _p, _i64, _int, C.c_uint64, _i64, _p, _p]),
     "bnpk_match_windows_bytes": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p]),
+    "bnpk_match_rows_packed": (_int, [_p, _p, _i64, _p, _i64, _int, C.c_uint64, _p, _p]),
     "bnpk_pwm_scores": (_int, [_p, _p, _p, _i64, _int, _p, _i64, _p, _p]),
     "bnpk_kmers_partition": (_int, [_p, _p, _p, _i64, _int, _int, _int, _int, _p, _p, _p]),
     "bnpk_minimizers": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _int, _p, _p]),

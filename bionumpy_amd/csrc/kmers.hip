@@ -480,6 +480,81 @@ __global__ __launch_bounds__(BNPK_BLOCK) void kmer_generic_kernel(const uint8_t*
   }
 }
 
+// match_string(...).sum(axis=-1) / .any(axis=-1) on 2-bit DNA without the flags (string_matcher.py:16-55 of the reference
+// returns the flags and its callers reduce them per row): counts[r] = windows of row r equal to the pattern.  One lane per
+// row — the rows of neighbouring lanes are neighbours in the packed words, so a wavefront's loads cover one contiguous
+// stretch — 32 windows per step, bit-parallel: position j of the pattern against the bases j further on, for all 32
+// windows at once on the even bits.  Rows of more than MR_LONG bases are taken by the whole wavefront, a piece per lane.
+constexpr int MR_LONG = 4096, MR_PIECE = 1024;
+
+// windows [p, p + n_win) of m bases, p any base index: how many equal the pattern (m <= 31)
+__device__ __forceinline__ unsigned mr_count(const uint64_t* __restrict__ W, int64_t n_words, int64_t p, int64_t n_win, int m,
+                                             uint64_t pattern_hash) {
+  if (n_win <= 0) return 0u;
+  int64_t wi = p >> 5;
+  const int sh = 2 * (int)(p & 31);
+  auto word = [&](int64_t i) -> uint64_t { return i < n_words ? W[i] : 0ull; };
+  uint64_t w0 = word(wi), w1 = word(wi + 1);
+  auto funnel = [&](uint64_t lo, uint64_t hi) -> uint64_t { return sh ? (lo >> sh) | (hi << (64 - sh)) : lo; };
+  uint64_t A = funnel(w0, w1);                                   // bases p .. p + 31
+  unsigned n = 0;
+  for (int64_t done = 0; done < n_win; done += 32) {
+    const uint64_t w2 = word(wi + 2);
+    uint64_t B = funnel(w1, w2);                                 // the 32 bases after A's
+    uint32_t a0 = (uint32_t)A, a1 = (uint32_t)(A >> 32), b0 = (uint32_t)B, b1 = (uint32_t)(B >> 32);
+    uint32_t e0 = 0x55555555u, e1 = 0x55555555u;
+    uint64_t h = pattern_hash;
+    for (int j = 0; j < m; ++j) {
+      const uint32_t rep = (uint32_t)(h & 3u) * 0x55555555u;
+      const uint32_t x0 = a0 ^ rep, x1 = a1 ^ rep;
+      e0 &= ~(x0 | (x0 >> 1));
+      e1 &= ~(x1 | (x1 >> 1));
+      a0 = __builtin_amdgcn_alignbit(a1, a0, 2);                 // (a1:a0:b1:b0 as one 128-bit number) >>= 2
+      a1 = __builtin_amdgcn_alignbit(b0, a1, 2);
+      b0 = __builtin_amdgcn_alignbit(b1, b0, 2);
+      b1 >>= 2;
+      h >>= 2;
+    }
+    const int64_t left = n_win - done;
+    if (left < 32) {
+      const uint64_t keep = (1ull << (2 * left)) - 1ull;
+      e0 &= (uint32_t)keep;
+      e1 &= (uint32_t)(keep >> 32);
+    }
+    n += __popc(e0) + __popc(e1);
+    A = B;
+    w1 = w2;
+    ++wi;
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(BNPK_BLOCK) void match_rows_kernel(const uint64_t* __restrict__ W, int64_t n_words,
+                                                               const int64_t* __restrict__ off, int64_t n_rows, int m,
+                                                               uint64_t pattern_hash, int64_t* __restrict__ counts) {
+  const int lane = lane_id();
+  const int64_t n_groups = (n_rows + 63) / 64;
+  for (int64_t g = (int64_t)blockIdx.x * (BNPK_BLOCK / 64) + wave_id(); g < n_groups; g += (int64_t)gridDim.x * (BNPK_BLOCK / 64)) {
+    const int64_t r = g * 64 + lane;
+    const int64_t lo = r < n_rows ? off[r] : 0, hi = r < n_rows ? off[r + 1] : 0;
+    const int64_t n_win = hi - lo - (m - 1);
+    const bool is_long = hi - lo > MR_LONG;
+    int64_t n = is_long ? 0 : (int64_t)mr_count(W, n_words, lo, n_win, m, pattern_hash);
+    uint64_t todo = __ballot(is_long);
+    while (todo) {                                             // (uniform: every lane sees the same ballot)
+      const int src = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int64_t rlo = __shfl((long long)lo, src), rwin = __shfl((long long)n_win, src);
+      int64_t part = 0;
+      for (int64_t c = (int64_t)lane * MR_PIECE; c < rwin; c += 64 * MR_PIECE)
+        part += mr_count(W, n_words, rlo + c, min((int64_t)MR_PIECE, rwin - c), m, pattern_hash);
+      part = __shfl(wave_reduce_sum(part), 0);
+      if (lane == src) n = part;
+    }
+    if (r < n_rows) counts[r] = n;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -610,6 +685,19 @@ int bnpk_match_windows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const uin
                               uint64_t pattern_hash, int64_t n_out, uint8_t* d_out, void* stream) {
   if (!ctx || m < 1 || m > 31 || n_bases < 0 || n_out < 0) return BNPK_ERR_ARG;
   return match_windows(ctx, true, d_packed, d_start_mask, n_bases, m, pattern_hash, nullptr, n_out, d_out, stream);
+}
+
+int bnpk_match_rows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases, const int64_t* d_offsets, int64_t n_rows,
+                           int m, uint64_t pattern_hash, int64_t* d_counts, void* stream) {
+  if (!ctx || m < 1 || m > 31 || n_bases < 0 || n_rows < 0) return BNPK_ERR_ARG;
+  if (n_rows == 0) return BNPK_OK;
+  if (!d_offsets || !d_counts || (n_bases > 0 && !d_packed)) return BNPK_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  bnpk_timer t(ctx, "match_rows_packed", s);
+  hipLaunchKernelGGL(match_rows_kernel, dim3(grid_for(ceil_div(n_rows, (int64_t)BNPK_BLOCK))), dim3(BNPK_BLOCK), 0, s, d_packed,
+                     ceil_div(n_bases, (int64_t)32), d_offsets, n_rows, m, pattern_hash, d_counts);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
 }
 
 int bnpk_match_windows_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_start_mask, int64_t n_bytes, int m,

@@ -415,6 +415,18 @@ class HipOps:
                                                    ptr(out), self._s()))
         return HArray(dev=out)
 
+    def match_rows(self, packed, offsets, n_rows, total, pattern):
+        """int64 per row: its windows of len(pattern) bases that equal the pattern, from the 2-bit words — the flags of
+        match_windows summed per row without being written (bnpk_match_rows_packed); len(pattern) <= 31"""
+        out = self._empty(n_rows, np.int64)
+        h = 0
+        for j, c in enumerate(pattern):
+            h |= int(c) << (2 * j)
+        if n_rows:
+            self._chk(lib.bnpk_match_rows_packed(self.ctx, ptr(packed.dev()) if total else None, total, ptr(offsets.dev()), n_rows,
+                                                 len(pattern), h, ptr(out), self._s()))
+        return HArray(dev=out)
+
     def pwm_scores(self, packed, offsets, n_rows, total, n_out, matrix):
         """float64 motif score of every window of matrix.shape[1] bases, ragged-flat; matrix[code][position]"""
         width = matrix.shape[1]

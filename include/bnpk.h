@@ -452,6 +452,12 @@ int bnpk_match_windows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, const uin
 int bnpk_match_windows_bytes(bnpk_ctx* ctx, const uint8_t* d_bytes, const uint64_t* d_start_mask, int64_t n_bytes,
                              int m, const uint8_t* h_pattern, int64_t n_out, uint8_t* d_out, void* stream);
 
+/* The same reduced per row without the flags: d_counts[r] = windows of row r (bases d_offsets[r] .. d_offsets[r + 1] of the
+ * packed words) that equal the pattern — what `match_string(reads, p).sum(axis=-1)` / `.any(axis=-1)` of the reference's
+ * callers comes to (string_matcher.py:16-55 returns the flags, ragged reductions follow).  Rows shorter than m count 0. */
+int bnpk_match_rows_packed(bnpk_ctx* ctx, const uint64_t* d_packed, int64_t n_bases, const int64_t* d_offsets, int64_t n_rows,
+                           int m, uint64_t pattern_hash, int64_t* d_counts, void* stream);
+
 /* Position weight matrix scores (bionumpy/sequence/position_weight_matrix.py:86-104,177-196): for every
  * window of `width` <= 64 bases, in the ragged-flat order of the windows, the double-precision sum
  * ((0 + M[0][c_0]) + M[1][c_1]) + ... — the accumulation order of the reference's calculate_scores, so finite scores

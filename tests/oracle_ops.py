@@ -207,6 +207,13 @@ class OracleOps:
         assert hit.size == n_out
         return _h(hit)
 
+    def match_rows(self, packed, offsets, n_rows, total, pattern):
+        lens = np.diff(offsets.host())
+        hit, out_lens = oracle.match_string(_unpack(packed, total), lens, np.asarray(list(pattern), dtype=np.uint8))
+        ends = np.cumsum(out_lens)
+        sums = np.concatenate([[0], np.cumsum(hit.astype(np.int64))])
+        return _h((sums[ends] - sums[ends - out_lens]).astype(np.int64))
+
     def pwm_scores(self, packed, offsets, n_rows, total, n_out, matrix):
         scores, _ = oracle.pwm_scores(_unpack(packed, total), np.diff(offsets.host()), matrix)
         assert scores.size == n_out

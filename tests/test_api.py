@@ -1038,7 +1038,10 @@ def test_window_flags_and_scores_are_reduced_where_they_are(bnp, request):
     pattern = "GAT"
     hits = bnp.match_string(seqs, pattern)
     expect = [[r[i:i + 3] == pattern for i in range(max(0, len(r) - 2))] for r in rows]
-    any_rows, all_rows, per_row = hits.any(axis=-1), hits.all(axis=-1), hits.sum(axis=-1)
+    any_rows, per_row, n_hits = hits.any(axis=-1), hits.sum(axis=-1), hits.sum(axis=None)
+    assert hits._pending is not None, "per-row counts of 2-bit DNA come from the packed words: no flags are written for them"
+    assert n_hits == sum(sum(e) for e in expect)
+    all_rows = hits.all(axis=-1)
     if "hip" in request.node.name:
         assert _on_device_never_downloaded(hits._data) and _on_device_never_downloaded(any_rows.harray()), "the flags crossed PCIe"
     assert np.asarray(any_rows).tolist() == [any(e) for e in expect]

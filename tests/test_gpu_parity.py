@@ -461,6 +461,11 @@ def test_match_windows(ops, seed, n_rows, max_len, m):
     if m <= 31:
         got = ops.match_windows(ops.pack_codes(_h(codes)), _h(offsets), n_rows, total, n_out, pattern, True).host()
         assert np.array_equal(got, hit)
+        # the same reduced per row, without the flags (rows longer than 4096 bases: a wavefront per row)
+        per_row = ops.match_rows(ops.pack_codes(_h(codes)), _h(offsets), n_rows, total, pattern).host()
+        ends = np.cumsum(new_lens)
+        sums = np.concatenate([[0], np.cumsum(hit.astype(np.int64))])
+        assert np.array_equal(per_row, sums[ends] - sums[ends - new_lens])
     text = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
     got = ops.match_windows(_h(text if total else np.zeros(4, np.uint8)), _h(offsets), n_rows, total, n_out,
                             np.frombuffer(b"ACGT", dtype=np.uint8)[pattern], False).host()
