@@ -1063,6 +1063,12 @@ class HipOps:
     def concat(self, arrays):
         return HArray(dev=self.device.torch_cat([a.dev() for a in arrays]))
 
+    def concat_words(self, parts, pad=2):
+        """the first n words of every (int64 HArray, n) one behind the other, plus ``pad`` zero words — the packed reads /
+        k-mer start masks of several chunks as one array (the pieces are cut at whole words: SparseKmerCounts._count_reads)"""
+        pieces = [a.dev()[:n] for a, n in parts]
+        return HArray(dev=self.device.torch_cat(pieces + [self.device.zeros(pad, np.int64)]))
+
     def add_i64(self, a, b):
         return HArray(dev=a.dev() + b.dev())
 

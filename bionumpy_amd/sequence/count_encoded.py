@@ -122,6 +122,8 @@ class SparseKmerCounts:
 
     PENDING_LIMIT = 1 << 29            # uncounted hashes a histogram holds at most (4 GiB)
     LAZY_MAX = 1 << 26                 # inputs up to this many hashes are counted lazily (larger ones: at once)
+    READS_LIMIT = 3 << 30              # k-mers of uncounted READS a histogram holds at most: what one counting pass takes
+                                       # (8 B/k-mer partitioned twice + 16 B per distinct k-mer: ~130 GB of the 288)
 
     def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=None, n_pending=None, key_range=None):
         self.encoding = encoding
@@ -132,7 +134,9 @@ class SparseKmerCounts:
         as_h = lambda x: x if isinstance(x, HArray) else HArray(host=np.asarray(x, dtype=np.int64))
         self._k = None if keys is None else as_h(keys)
         self._c = None if counts is None else as_h(counts)
-        self._pending = list(pending or [])    # HArrays of int64 hashes (shared between histograms, never written to)
+        # HArrays of int64 hashes, or PendingReads (the reads themselves: their hashes are generated when they are counted) —
+        # shared between histograms, never written to
+        self._pending = list(pending or [])
         self._n_pend = sum(p.size for p in self._pending) if n_pending is None else n_pending
         self._key_bits = key_bits
 
@@ -143,14 +147,21 @@ class SparseKmerCounts:
         """count what is pending and merge it with what has been counted"""
         if self._pending:
             ops = get_ops()
-            if len(self._pending) == 1:
-                keys, counts = ops.count_sparse(self._pending[0], key_bits=self._key_bits)
-            else:                                          # (the joined array is this call's own: the counting may use it up)
-                keys, counts = ops.count_sparse(ops.concat(self._pending), key_bits=self._key_bits, consume=True)
+            reads = [p for p in self._pending if isinstance(p, PendingReads)]
+            hashes = [p for p in self._pending if not isinstance(p, PendingReads)]
             self._pending, self._n_pend = [], 0
-            if self._k is not None and self._k.size:
-                keys, counts = ops.merge_add(self._k, self._c, keys, counts)
-            self._k, self._c = keys, counts
+            done = [(self._k, self._c)] if self._k is not None and self._k.size else []
+            if reads:
+                done.append(_count_reads(ops, reads))
+            del reads
+            if len(hashes) == 1:
+                done.append(ops.count_sparse(hashes[0], key_bits=self._key_bits))
+            elif hashes:                                   # (the joined array is this call's own: the counting may use it up)
+                done.append(ops.count_sparse(ops.concat(hashes), key_bits=self._key_bits, consume=True))
+            while len(done) > 1:
+                (k1, c1), (k2, c2) = done.pop(), done.pop()
+                done.append(ops.merge_add(k2, c2, k1, c1) if k1.size and k2.size else ((k1, c1) if k1.size else (k2, c2)))
+            self._k, self._c = done[0]
         elif self._k is None:
             self._k = self._c = HArray(host=np.zeros(0, dtype=np.int64))
         return self
@@ -196,7 +207,8 @@ class SparseKmerCounts:
             # (the width of the keys comes from the operands that still have hashes to count)
             bits = max([x._key_bits for x in (self, other) if x._pending])
             out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, bits, self._n_pend + other._n_pend)
-            if out._n_pending() >= self.PENDING_LIMIT:
+            if out._n_pending() >= self.PENDING_LIMIT or \
+                    sum(p.size for p in out._pending if isinstance(p, PendingReads)) >= self.READS_LIMIT:
                 out._force()
             return out
         keys, counts = get_ops().merge_add(self._keys, self._counts, other._keys, other._counts)
@@ -251,6 +263,37 @@ class SparseKmerCounts:
 
     def __repr__(self):
         return "SparseKmerCounts(%s, %d distinct)" % (self.encoding, len(self))
+
+
+class PendingReads:
+    """2-bit reads whose k-mers a histogram has not counted yet: what ``count_kmers(chunk.sequence, k)`` of a file stream leaves
+    behind per chunk (0.4 bytes per base against 8 per k-mer hash).  ``size`` = its k-mers; toward PENDING_LIMIT — a memory
+    bound in hashes — it weighs its words."""
+
+    def __init__(self, packed, start_mask, n_bases, n_kmers, k):
+        self.packed, self.start_mask, self.n_bases, self.size, self.k = packed, start_mask, int(n_bases), int(n_kmers), int(k)
+
+
+def _count_reads(ops, reads):
+    """(keys, counts) of the k-mers of several chunks' reads, counted TOGETHER the way a resident batch is (pipeline.py): the
+    chunks' packed words and start masks are put one behind the other — every chunk cut at a whole mask word = 64 bases; the
+    bases between a chunk's last one and the cut start no k-mer, which is all the generator asks of them — the hashes are
+    generated into the first radix level (bnpk_kmers_partition) and never laid out read by read."""
+    k = reads[0].k
+    assert all(r.k == k for r in reads)
+    if len(reads) == 1:
+        packed, mask, n_bases = reads[0].packed, reads[0].start_mask, reads[0].n_bases
+    else:
+        blocks = [-(-r.n_bases // 64) for r in reads]
+        packed = ops.concat_words([(r.packed, 2 * b) for r, b in zip(reads, blocks)])
+        mask = ops.concat_words([(r.start_mask, b) for r, b in zip(reads, blocks)])
+        n_bases = 64 * sum(blocks)
+    n_kmers = sum(r.size for r in reads)
+    levels = ops.radix_plan(n_kmers, 2 * k)
+    bits = levels[0] if levels else 0
+    hashes, cuts = ops.kmers_partitioned(packed, mask, n_bases, n_kmers, k, bits)
+    del packed, mask
+    return ops.count_sparse(hashes, key_bits=2 * k, consume=True, partition=(cuts, bits) if bits else None)
 
 
 def _key_bits_of(encoding):

@@ -175,6 +175,11 @@ class _LazyLens:
         return np.dtype(np.int64)
 
 
+def _pending_weight(n_bases):
+    """what uncounted reads weigh toward SparseKmerCounts.PENDING_LIMIT (a bound in 8-byte hashes): their words"""
+    return n_bases // 32 + n_bases // 64 + 4
+
+
 _DENSE_MAX_K = 13            # 4^13 int64 bins = 512 MiB (pipeline.DENSE_MAX_K)
 
 
@@ -205,11 +210,14 @@ def count_kmers(sequence, k, axis=None, canonical=False):
         ops = get_ops()
         packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
         out_off, n_out = ops.row_offsets(lens, k)
-        if 0 < n_out <= SparseKmerCounts.LAZY_MAX and not canonical:
-            # a small input — a chunk of a file read the reference's way: its hashes are laid out and counted LATER, with
-            # those of the chunks it is added to (see SparseKmerCounts)
-            hashes = ops.kmers(packed, in_off, out_off, n_rows, n_out, k, total=total)
-            return SparseKmerCounts(KmerEncoding(sequence.encoding, k), pending=[hashes], key_bits=2 * k)
+        if 0 < n_out <= SparseKmerCounts.READS_LIMIT // 4 and not canonical:
+            # a chunk of a file stream (or anything else of moderate size): nothing is counted yet — the histogram keeps the
+            # READS, and counts them together with those of the chunks it is added to as soon as somebody looks at it
+            # (see SparseKmerCounts / PendingReads: one pass of the fused generator over all of them)
+            from .count_encoded import PendingReads
+            mask = ops.kmer_start_mask(in_off, n_rows, total, k)
+            return SparseKmerCounts(KmerEncoding(sequence.encoding, k), pending=[PendingReads(packed, mask, total, n_out, k)],
+                                    key_bits=2 * k, n_pending=_pending_weight(total))
         if n_out > 0:
             mask = ops.kmer_start_mask(in_off, n_rows, total, k)
             skew = 2.0 if canonical else 1.0          # min(h, rc(h)) has density 2(1 - x) over the key range

@@ -415,6 +415,9 @@ class OracleOps:
     def concat(self, arrays):
         return _h(np.concatenate([a.host() for a in arrays]))
 
+    def concat_words(self, parts, pad=2):
+        return _h(np.concatenate([a.host()[:n] for a, n in parts] + [np.zeros(pad, dtype=np.int64)]))
+
     def synth_fastq(self, n_reads, read_len, seed, mode=0, genome_len=0, first_read=0):
         from bionumpy_amd import synth
         return _h(synth.fastq_bytes(n_reads, read_len, seed, mode, genome_len, first_read))

@@ -821,6 +821,38 @@ def test_streamed_counts_equal_whole_file(bnp, big_fq_gz):
     assert sparse["CGGTAGCCAGCTGCGTTCAGTATGGAAGATT"] >= 1
 
 
+def test_chunk_histograms_keep_the_reads_until_somebody_looks(bnp, big_fq_gz):
+    """the reference's loop — sum(count_kmers(chunk.sequence, k) for chunk in reader), scripts/kmer_counting_example.py:4-17 — adds
+    up histograms that have counted nothing yet: each holds its chunk's 2-bit reads (count_encoded.PendingReads), the sum holds all
+    of them, and the first look counts them in one pass (the chunks cut at whole mask words: row counts / lengths that are no
+    multiple of 64 bases, an empty chunk, rows shorter than k) == the histogram of all reads at once == the oracle's"""
+    from bionumpy_amd.sequence.count_encoded import PendingReads
+    rng = np.random.default_rng(77)
+    k = 21
+    pieces = []
+    for n_rows in (1, 37, 0, 300, 5):
+        rows = ["".join(rng.choice(list("ACGT"), size=int(n))) for n in rng.integers(0, 180, size=n_rows)]
+        pieces.append(rows)
+    hists = [bnp.count_kmers(bnp.as_encoded_array(rows, bnp.DNAEncoding), k) for rows in pieces if rows]
+    total = sum(hists)
+    assert all(isinstance(p, PendingReads) for p in total._pending) and len(total._pending) == sum(1 for h in hists if h._pending)
+    all_rows = [r for rows in pieces for r in rows]
+    codes = np.searchsorted(np.frombuffer(b"ACGT", dtype=np.uint8), np.frombuffer("".join(all_rows).encode(), dtype=np.uint8))
+    h, _ = oracle.get_kmers(codes.astype(np.uint8), np.array([len(r) for r in all_rows]), k)
+    ek, ec = oracle.count_sparse(h)
+    assert np.array_equal(total.keys, ek) and np.array_equal(total.counts, ec) and not total._pending
+    assert total == bnp.count_kmers(bnp.as_encoded_array(all_rows, bnp.DNAEncoding), k)
+    # mixed with counted histograms and with hashes that wait (count_encoded on k-mers): everything merges
+    again = hists[0] + total + bnp.count_encoded(bnp.get_kmers(bnp.as_encoded_array(pieces[1], bnp.DNAEncoding), k), axis=None)
+    h2, _ = oracle.get_kmers(codes.astype(np.uint8)[:sum(len(r) for r in pieces[0] + pieces[1])],
+                             np.array([len(r) for r in pieces[0] + pieces[1]]), k)
+    ek2, ec2 = oracle.count_sparse(np.concatenate([h, h2]))
+    assert np.array_equal(again.keys, ek2) and np.array_equal(again.counts, ec2)
+    # a file read in small chunks by hand (no coalescing): the same histogram as the whole file
+    by_hand = sum(bnp.count_kmers(chunk.sequence, 31) for chunk in bnp.open(big_fq_gz).read_chunks(20000))
+    assert by_hand == bnp.count_kmers(bnp.open(big_fq_gz).read().sequence, 31) and len(by_hand) == 168493
+
+
 def test_quality_reductions_before_and_after_the_column_is_gathered(bnp):
     """np.sum / mean / min / max(chunk.quality, axis=1) straight from the chunk's text ([hip]: ragged.py _DeferredRows — the
     column is only gathered when somebody looks at the values) == the same on the gathered column == numpy on the bytes minus
