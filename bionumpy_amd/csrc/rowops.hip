@@ -389,9 +389,9 @@ __device__ __forceinline__ int64_t jl_row_of(const int64_t* __restrict__ off, in
 // walked the lines to see where its bytes came from: ~1200 lane cycles per sixteen bytes, 31 ms for 50 M FASTQ records,
 // whatever was done to the loads; half a wavefront per entry (the first version of this kernel) was no faster: the
 // entries of a group went through their loads one after the other.
-constexpr int JL_RECS = 128;                            // entries described per pass (a FASTQ tile holds ~52)
+constexpr int JL_RECS = 64;                             // entries described per pass (a FASTQ tile holds ~52)
 constexpr int JL_DESC = JL_RECS * JL_MAX_LINES;
-constexpr int JL_WORDS = 2048;                          // words numbered per pass (a FASTQ tile: ~1150)
+constexpr int JL_WORDS = 1536;                          // words numbered per pass (a FASTQ tile: ~1150)
 constexpr int JL_PER_LANE = JL_WORDS / BNPK_BLOCK;
 
 __global__ __launch_bounds__(BNPK_BLOCK) void join_lines_kernel(jl_lines lines, int n_lines, uint8_t header,
