@@ -95,6 +95,13 @@ for _ in range(2):
 sync(); prof = dev.prof_report(); dev.prof_enable(False)
 out["match_string_packed"] = {"reads": reads, "pattern": "GATTACA", "hits": n_hits,
                               "kernels_ms": {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}}
+def match_rows_only():
+    return ops.match_rows(bnp.encoded_array.packed_words(seqs._data), seqs.offsets(), len(seqs), seqs.total(), [2, 0, 3, 3, 0, 1, 0])
+h = match_rows_only(); assert int(h.dev().sum().item()) == n_hits; del h; sync(); dev.prof_enable(True); dev.prof_reset()
+for _ in range(2):
+    h = match_rows_only(); del h
+sync(); prof = dev.prof_report(); dev.prof_enable(False)
+out["match_string_packed"]["per_row_counts_ms"] = {name: round(v["total_ms"] / 2, 2) for name, v in prof.items()}
 _rng = np.random.default_rng(1)
 _m = np.log(_rng.dirichlet(np.ones(4), size=12).T / 0.25)
 def pwm_kernel_only():
@@ -191,6 +198,7 @@ table = {
     "kmer_starts_from_ends": (c3["kmer_starts_from_ends"], 2 * (NB // 8)),
     "minimizers_flat": (c3["minimizers_flat"], 8 * n_min + NB // 4 + NB // 8),
     "match_windows_packed": (mt["match_windows_packed"], NB // 4 + NB // 8 + (NB - 6 * NR)),
+    "match_rows_packed (per-row counts, no flags)": (out["match_string_packed"]["per_row_counts_ms"]["match_rows_packed"], NB // 4 + 16 * NR),
     "pwm_scores": (pw["pwm_scores"], NB // 4 + NB // 8 + 8 * (NB - 11 * NR)),
     "reverse_complement_packed": (out["reverse_complement_packed"]["kernel_ms"], 2 * (NB // 4) + 8 * NR),
     "reverse_complement_bytes": (rw["kernels_ms"]["reverse_complement_bytes"], 2 * NB + 8 * NR),
