@@ -34,7 +34,7 @@ def test_newline_scan_matches_flatnonzero(ops, n):
     assert total4 == expect.size and np.array_equal(pos4.host(), expect[:expect.size - expect.size % 4])
 
 
-@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 2048 * 2048 + 5])
+@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 2048 * 2048 + 5, 33_554_433])
 def test_exclusive_scan(ops, n):
     rng = np.random.default_rng(n + 7)
     v = rng.integers(0, 1000, size=n).astype(np.int64)
@@ -43,6 +43,14 @@ def test_exclusive_scan(ops, n):
     off, total = ops.row_offsets(_h(v), 31)
     expect = np.concatenate(([0], np.cumsum(np.maximum(v - 30, 0))))
     assert total == expect[-1] and np.array_equal(off.host(), expect)
+    if n > 4096:
+        # input that does not start on a 16-byte boundary (the one-pass kernel's loads want one: the three-kernel form takes it),
+        # and sums near 2^61 (the status words of the look-back keep two bits for themselves)
+        from bionumpy_amd.device import HArray
+        odd = HArray(dev=_h(np.concatenate(([0], v))).dev()[1:])
+        assert np.array_equal(ops.exclusive_scan(odd).host(), np.concatenate(([0], np.cumsum(v))))
+        big = np.full(n, (1 << 61) // n, dtype=np.int64)
+        assert np.array_equal(ops.exclusive_scan(_h(big)).host(), np.concatenate(([0], np.cumsum(big))))
 
 
 @pytest.mark.parametrize("mode,genome_len", [(0, 0), (1, 100_000)])
