@@ -138,10 +138,16 @@ class SparseKmerCounts:
         # shared between histograms, never written to
         self._pending = list(pending or [])
         self._n_pend = sum(p.size for p in self._pending) if n_pending is None else n_pending
+        self._n_read_kmers = None          # k-mers of the PendingReads among them (summed once, then carried along by __add__)
         self._key_bits = key_bits
 
     def _n_pending(self):
         return self._n_pend
+
+    def _pending_read_kmers(self):
+        if self._n_read_kmers is None:
+            self._n_read_kmers = sum(p.size for p in self._pending if isinstance(p, PendingReads))
+        return self._n_read_kmers
 
     def _force(self):
         """count what is pending and merge it with what has been counted"""
@@ -149,7 +155,7 @@ class SparseKmerCounts:
             ops = get_ops()
             reads = [p for p in self._pending if isinstance(p, PendingReads)]
             hashes = [p for p in self._pending if not isinstance(p, PendingReads)]
-            self._pending, self._n_pend = [], 0
+            self._pending, self._n_pend, self._n_read_kmers = [], 0, 0
             done = [(self._k, self._c)] if self._k is not None and self._k.size else []
             if reads:
                 done.append(_count_reads(ops, reads))
@@ -207,8 +213,8 @@ class SparseKmerCounts:
             # (the width of the keys comes from the operands that still have hashes to count)
             bits = max([x._key_bits for x in (self, other) if x._pending])
             out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, bits, self._n_pend + other._n_pend)
-            if out._n_pending() >= self.PENDING_LIMIT or \
-                    sum(p.size for p in out._pending if isinstance(p, PendingReads)) >= self.READS_LIMIT:
+            out._n_read_kmers = self._pending_read_kmers() + other._pending_read_kmers()
+            if out._n_pending() >= self.PENDING_LIMIT or out._n_read_kmers >= self.READS_LIMIT:
                 out._force()
             return out
         keys, counts = get_ops().merge_add(self._keys, self._counts, other._keys, other._counts)
