@@ -37,7 +37,22 @@ def packed_rc():
     return bnp.get_reverse_complement(dna)
 
 
+def read_filter():
+    chunk = bnp.SequenceEntryWithQuality._lazy(bnp.FastQBuffer.from_raw_buffer(text))
+    keep = np.mean(chunk.quality, axis=1) >= 0.0
+    keep[::3] = False
+    return chunk[keep].get_buffer().entry_bytes()
+
+
+def encode():
+    s = bnp.change_encoding(bnp.FastQBuffer.from_raw_buffer(text).get_field_by_number(1), bnp.DNAEncoding)
+    s._compact()
+    return s
+
+
 timed("rewrite", rewrite)
+timed("filter", read_filter)
+timed("encode", encode)
 dna = bnp.change_encoding(bnp.FastQBuffer.from_raw_buffer(text).get_field_by_number(1), bnp.DNAEncoding)
 dna._compact()
 timed("rc packed", packed_rc)
