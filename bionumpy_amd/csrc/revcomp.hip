@@ -14,7 +14,7 @@ namespace {
 
 // (experiment knobs of scripts/exp/rc_repro.py — the library is built with the defaults)
 #ifndef BNPK_RCP_UNROLL
-#define BNPK_RCP_UNROLL 1                            // 1: the loop over a lane's words stays rolled (see rc_packed_kernel)
+#define BNPK_RCP_UNROLL 4                            // 1: the loop over a lane's words stays rolled; 4 (with the VGPR floor): unrolled (see rc_packed_kernel)
 #endif
 #ifndef BNPK_RCP_LDS_PAD
 #define BNPK_RCP_LDS_PAD 0                           // extra LDS bytes per workgroup (limits the workgroups per CU)
@@ -84,12 +84,37 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
     __syncthreads();
   }
   auto offset_of = [&](int64_t row) { return (staged && row <= hi + 1) ? srow[row - lo] : off[row]; };
-  // Rolled, and the allocation pinned at 32 VGPRs above.  Round 4 saw the unrolled form of this loop write garbled rows "from
-  // the 257th workgroup on"; round 5 ran it down (NOTES.md "rc_packed: the cause"): the unrolled ISA is right (every load waited
-  // for, live ranges read by hand, s_nop padding / forced waits / no LDS / fences change nothing) — what differs is that only the
-  // fully unrolled kernel needs exactly 24 VGPRs, and with a 24-register allocation every workgroup that is not the first on its
-  // CU computes garbage, nondeterministically (a CU mask of 128 / 64 / 32 / 8 CUs moves the first bad tile to 129 / 72 / 37 /
-  // 10).  The SAME code with the allocation bumped to 32 registers is right in every run.  The rolled loop is as fast.
+  // The allocation is pinned at 32 VGPRs above.  Round 4 saw the unrolled form of the loop below write garbled rows "from the 257th
+  // workgroup on"; round 5 ran it down (NOTES.md "rc_packed: the cause"): the unrolled ISA is right (every load waited for, live
+  // ranges read by hand, s_nop padding / forced waits / no LDS / fences change nothing) — what differs is that only the fully
+  // unrolled kernel needed exactly 24 VGPRs, and with a 24-register allocation every workgroup that is not the first on its CU
+  // computes garbage, nondeterministically (a CU mask of 128 / 64 / 32 / 8 CUs moves the first bad tile to 129 / 72 / 37 / 10).
+  // The SAME code with the allocation bumped to 32 registers is right in every run; the build's ISA lint refuses a kernel that
+  // comes out at 24.  With the floor in place the loop is unrolled again (BNPK_RCP_UNROLL).
+  // reverse complement of the n <= 32 bases that END the source run [from, from + n): the low 2n bits
+  auto rc_piece = [&](int64_t from, int n) -> uint64_t {
+    const uint64_t src = packed_run(in, from, n);
+    const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
+    return n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
+  };
+  // any number of pieces (rows shorter than a word, empty rows): the walk
+  auto walk = [&](int64_t r, int64_t p0, int64_t p1) -> uint64_t {
+    uint64_t word = 0;
+    int64_t p = p0;
+    while (p < p1) {
+      int64_t s = offset_of(r), e = offset_of(r + 1);
+      while (e <= p) { ++r; s = e; e = offset_of(r + 1); }   // empty rows, and the step to the next row
+      const int64_t stop = min(e, p1);
+      // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
+      word |= rc_piece(s + e - stop, (int)(stop - p)) << (2 * (int)(p - p0));
+      p = stop;
+    }
+    return word;
+  };
+  // A word of 32 output bases lies in one row or — reads are longer than a word — in the end of one and the start of the
+  // next: both pieces are fetched without waiting for each other, for all of the lane's words at once (the walk above, a loop
+  // with loads inside, was a chain of dependent round trips per word: 0.25 of the peak whether rolled or unrolled).  Words
+  // that need a third piece take the walk.
 BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
   for (int it = 0; it < RCP_WPL; ++it) {
     const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
@@ -98,6 +123,7 @@ BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
       if (p0 < total + 64) out[w] = 0;                       // the pad words behind the last tile's data
       continue;
     }
+    const int64_t p1 = min(p0 + 32, total);
     int64_t r;
     if (staged) {
       int a = 0, b = (int)(hi - lo);
@@ -109,20 +135,23 @@ BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
     } else {
       r = row_of(off, lo, hi, p0);
     }
-    const int64_t p1 = min(p0 + 32, total);
-    uint64_t word = 0;
-    int64_t p = p0;
-    while (p < p1) {
-      int64_t s = offset_of(r), e = offset_of(r + 1);
-      while (e <= p) { ++r; s = e; e = offset_of(r + 1); }   // empty rows, and the step to the next row
-      const int64_t stop = min(e, p1);
-      const int n = (int)(stop - p);
-      // output positions [p, stop) of row [s, e) <- source positions s + e - 1 - p down to s + e - stop
-      const uint64_t src = packed_run(in, s + e - stop, n);
-      const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
-      const uint64_t bits = n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
-      word |= bits << (2 * (int)(p - p0));
-      p = stop;
+    const int64_t s0 = offset_of(r), e0 = offset_of(r + 1);
+    uint64_t word;
+    if (e0 <= p0) {                                          // (cannot happen for p0 < total: the search returns the last row that starts at or before p0)
+      word = walk(r, p0, p1);
+    } else {
+      const int64_t stop_a = min(e0, p1);
+      const int n_a = (int)(stop_a - p0);
+      const bool two = stop_a < p1;
+      const int64_t e1 = two ? offset_of(min(r + 2, n_rows)) : e0;        // the row behind: [e0, e1)
+      const int64_t stop_b = min(e1, p1);
+      const int n_b = (int)(stop_b - stop_a);
+      if (two && (n_b <= 0 || stop_b < p1)) {                // an empty row, or a third piece
+        word = walk(r, p0, p1);
+      } else {
+        word = rc_piece(s0 + e0 - stop_a, n_a);
+        if (two) word |= rc_piece(e0 + e1 - stop_b, n_b) << (2 * n_a);
+      }
     }
     out[w] = word;
 #if BNPK_RCP_FENCE
