@@ -750,7 +750,7 @@ def main():
     traffic, traffic_source = None, None
     try:
         from bionumpy_amd.csrc.build import _source_hash
-        for cand in (("r05_genome_pmc.json", "r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
+        for cand in (("r05_genome_pmc.json", "r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r05_pmc.json", "r05_k21_pmc.json", "r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
             path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -760,7 +760,9 @@ def main():
                 (args.reads, args.read_len, args.k, args.mode, bool(args.canonical)) and world == 1
             if not same_work or pmc.get("_source_hash") != _source_hash():
                 continue
-            names = {"finish_sorted": "finish_wave" if args.mode == "genome" else "finish_fast", "radix_scatter": "rp_scatter<mem_source>",
+            ms_of = lambda n: prof.get(n, {}).get("total_ms", 0.0)
+            finisher = "finish_wave" if args.mode == "genome" else "finish_multi" if ms_of("finish.multi") > ms_of("finish.fast") else "finish_fast"
+            names = {"finish_sorted": finisher, "radix_scatter": "rp_scatter<mem_source>",
                      "radix_scatter_claimed": "rp_scatter<mem_source, claiming>",
                      "kmers_partition_scatter": "rp_scatter<kmer_source>", "radix_hist": "rp_hist<mem_source>",
                      "fastq_encode": "fq_encode_fast", "fastq_census": "fq_census_fast"}
