@@ -624,6 +624,9 @@ def main():
     from bionumpy_amd.pipeline import fastq_kmer_histogram
     ops = get_ops()
     dev = Device.get()
+    if os.environ.get("BNPK_FINISH_MODE"):                   # (experiments: force a finishing path, include/bnpk.h "finish_mode")
+        from bionumpy_amd._native import lib as _lib
+        assert _lib.bnpk_set_option(dev.ctx, b"finish_mode", int(os.environ["BNPK_FINISH_MODE"])) == 0
     mode = 0 if args.mode == "uniform" else 1
 
     if args.from_file:
