@@ -56,8 +56,11 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
                                                                const int64_t* __restrict__ off, int64_t n_rows,
                                                                int64_t total, const int64_t* __restrict__ tile_rows,
                                                                int64_t n_tiles, uint64_t* __restrict__ out) {
-  constexpr int RCP_LDS_ROWS = 1022;
+  constexpr int RCP_LDS_ROWS = 510;                          // rows of a tile whose offsets are staged (reads of 64 bases and more)
+  constexpr int RCP_SRC_WORDS = 1280;                        // packed words of the tile's rows that are staged (40 960 bases: the tile and a read on either side)
   __shared__ int64_t srow[RCP_LDS_ROWS + 2];
+  __shared__ uint64_t ssrc[RCP_SRC_WORDS + 2];
+  __shared__ int srow32[RCP_LDS_ROWS + 2];                   // the same offsets relative to the first staged word: 32-bit arithmetic from here on
 #if !defined(BNPK_RCP_NO_FLOOR)
   BNPK_VGPR_FLOOR_32();                                      // the unrolled form of the loop below would get 24 VGPRs: see there
 #endif
@@ -84,6 +87,22 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
     __syncthreads();
   }
   auto offset_of = [&](int64_t row) { return (staged && row <= hi + 1) ? srow[row - lo] : off[row]; };
+  // The bases the tile's words are made of are the tile's own rows, i.e. (for reads) the tile's own stretch of the packed
+  // stream and a read on either side: they come into LDS with coalesced loads and the words are cut out of LDS (two reads per
+  // piece) — gathered from global memory, two dependent 8-byte loads per piece at the mirror position, this kernel ran at 0.26
+  // of the peak whatever was done to its loop.  Rows much longer than a tile (a chromosome) keep the global form.
+  int64_t src_word0 = 0;
+  bool src_staged = false;                                   // (uniform)
+  const int64_t n_in_words = total / 32 + 2;                 // (the packed layout of bnpk_gather_encode_dna)
+  if (staged) {
+    const int64_t first = srow[0] >> 5, last = (srow[hi - lo + 1] + 31) >> 5;       // words [first, last) hold the rows lo .. hi
+    if (last - first <= RCP_SRC_WORDS) {
+      src_staged = true;
+      src_word0 = first;
+      for (int64_t i = threadIdx.x; i < last - first + 2; i += BNPK_BLOCK) ssrc[i] = first + i < n_in_words ? in[first + i] : 0ull;
+      __syncthreads();
+    }
+  }
   // The allocation is pinned at 32 VGPRs above.  Round 4 saw the unrolled form of the loop below write garbled rows "from the 257th
   // workgroup on"; round 5 ran it down (NOTES.md "rc_packed: the cause"): the unrolled ISA is right (every load waited for, live
   // ranges read by hand, s_nop padding / forced waits / no LDS / fences change nothing) — what differs is that only the fully
@@ -93,7 +112,15 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
   // comes out at 24.  With the floor in place the loop is unrolled again (BNPK_RCP_UNROLL).
   // reverse complement of the n <= 32 bases that END the source run [from, from + n): the low 2n bits
   auto rc_piece = [&](int64_t from, int n) -> uint64_t {
-    const uint64_t src = packed_run(in, from, n);
+    uint64_t src;
+    if (src_staged) {
+      const int i = (int)((from >> 5) - src_word0), sh = 2 * (int)(from & 31);
+      src = ssrc[i] >> sh;
+      if (sh && sh + 2 * n > 64) src |= ssrc[i + 1] << (64 - sh);
+      if (n < 32) src &= (1ull << (2 * n)) - 1ull;
+    } else {
+      src = packed_run(in, from, n);
+    }
     const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));
     return n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
   };
@@ -115,6 +142,49 @@ __global__ __launch_bounds__(BNPK_BLOCK) void rc_packed_kernel(const uint64_t* _
   // next: both pieces are fetched without waiting for each other, for all of the lane's words at once (the walk above, a loop
   // with loads inside, was a chain of dependent round trips per word: 0.25 of the peak whether rolled or unrolled).  Words
   // that need a third piece take the walk.
+  if (src_staged) {
+    // everything the tile needs is in LDS and within 2^17 bases of the first staged word: positions as 32-bit offsets from it
+    // (the 64-bit form below spends half of its instructions on carries; this kernel is bound by its instructions)
+    const int64_t base = src_word0 << 5;
+    const int nr = (int)(hi - lo);
+    for (int i = threadIdx.x; i <= nr + 1; i += BNPK_BLOCK) srow32[i] = (int)(srow[i] - base);
+    __syncthreads();
+    auto piece32 = [&](int from, int n) -> uint64_t {
+      const int i = from >> 5, sh = 2 * (from & 31);
+      uint64_t src = ssrc[i] >> sh;
+      if (sh && sh + 2 * n > 64) src |= ssrc[i + 1] << (64 - sh);
+      const uint64_t rc = ~(reverse_2bit_groups(src) >> (64 - 2 * n));      // (bits of src above 2n fall out of the shift)
+      return n >= 32 ? rc : (rc & ((1ull << (2 * n)) - 1ull));
+    };
+BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
+    for (int it = 0; it < RCP_WPL; ++it) {
+      const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
+      const int64_t p0 = w * 32;
+      if (p0 >= total) {
+        if (p0 < total + 64) out[w] = 0;
+        continue;
+      }
+      const int q0 = (int)(p0 - base), q1 = (int)(min(p0 + 32, total) - base);
+      int a = 0, b = nr;
+      while (a < b) {
+        const int mid = a + ((b - a + 1) >> 1);
+        if (srow32[mid] <= q0) a = mid; else b = mid - 1;
+      }
+      const int s0 = srow32[a], e0 = srow32[a + 1], e1 = srow32[min(a + 2, nr + 1)];
+      const int stop_a = min(e0, q1), n_a = stop_a - q0;
+      const bool two = stop_a < q1;
+      const int stop_b = min(e1, q1), n_b = stop_b - stop_a;
+      uint64_t word;
+      if (n_a <= 0 || (two && (n_b <= 0 || stop_b < q1))) {  // an empty row, or a third piece: the walk
+        word = walk(lo + a, p0, min(p0 + 32, total));
+      } else {
+        word = piece32(s0 + e0 - stop_a, n_a);
+        if (two) word |= piece32(e0 + e1 - stop_b, n_b) << (2 * n_a);
+      }
+      out[w] = word;
+    }
+    return;
+  }
 BNPK_PRAGMA_UNROLL(BNPK_RCP_UNROLL)
   for (int it = 0; it < RCP_WPL; ++it) {
     const int64_t w = w0 + it * BNPK_BLOCK + threadIdx.x;
