@@ -208,6 +208,15 @@ def count_kmers(sequence, k, axis=None, canonical=False):
         if canonical and "".join(sequence.encoding.get_alphabet()).upper() != "ACGT":
             raise NotImplementedError("canonical k-mers need the ACGT alphabet (complement = 3 - code)")
         ops = get_ops()
+        source = None if isinstance(sequence, EncodedArray) else getattr(sequence, "_trim_source", None)
+        if source is not None and not canonical and hasattr(ops, "windows_counted"):
+            # rows of a reader's batch (io/buffers.py: BatchShare — the reference's loop at its 5 MB chunks): the chunk's k-mers
+            # are a part of the batch's, computed once per batch; the histogram keeps that part and nothing is launched, packed or
+            # asked of the device for the chunk (the form below: a row-slice kernel, an offsets scan with its answer, two mask
+            # kernels per chunk — 0.19 ms per 5 MB chunk against 0.07 for this one)
+            shared = source[0].windows(source[1], k, k, source[2], source[3])
+            if shared is not None and 0 < shared.size <= SparseKmerCounts.LAZY_MAX:
+                return SparseKmerCounts(KmerEncoding(sequence.encoding, k), pending=[shared], key_bits=2 * k)
         packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
         out_off, n_out = ops.row_offsets(lens, k)
         if 0 < n_out <= SparseKmerCounts.READS_LIMIT // 4 and not canonical:
