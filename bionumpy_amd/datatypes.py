@@ -71,7 +71,18 @@ class SequenceEntry:
         return self.__class__(**{f: kwargs.get(f, None) if f in kwargs else getattr(self, f) for f in self._fields})
 
     def __repr__(self):
-        return "%s with %d entries" % (self.__class__.__name__, len(self))
+        """the entry table the reference prints (npstructures' npdataclass ``__str__``, shown in bionumpy/io/files.py:116-170,
+        docs_source/source/sequences.rst:165-170): a count line, the field names and the first ten entries in columns 25
+        wide; text longer than 20 letters is cut there and marked ``...``, a row of numbers is numpy's print of it, every
+        cell cut at 23 characters"""
+        lines = ["%s with %d entries" % (self.__class__.__name__, len(self)),
+                 "".join("%25s" % f for f in self._fields)]
+        head = self[:10] if len(self) > 10 else self
+        columns = [_cells(getattr(head, f), min(len(self), 10)) for f in self._fields]
+        lines.extend("".join("%25s" % cell for cell in row) for row in zip(*columns))
+        return "\n".join(lines)
+
+    __str__ = __repr__
 
     def __array_function__(self, func, types, args, kwargs):
         """np.concatenate(chunks) (bnpdataclass/lazybnpdataclass.py:178-196, bnpdataclass.py:477-493): the entries of
@@ -82,6 +93,22 @@ class SequenceEntry:
         if not chunks or not all(isinstance(c, SequenceEntry) and c._fields == self._fields for c in chunks):
             return NotImplemented
         return self.__class__(**{f: np.concatenate([getattr(c, f) for c in chunks]) for f in self._fields})
+
+
+def _cells(field, n):
+    """the table cells of the first n values of a field"""
+    out = []
+    for i in range(n):
+        value = field[i]
+        if hasattr(value, "to_string"):
+            text = value.to_string()
+            text = text[:20] + "..." if len(text) > 20 else text
+        elif isinstance(value, str):
+            text = value[:20] + "..." if len(value) > 20 else value
+        else:
+            text = str(np.asarray(value))
+        out.append(text[:23])
+    return out
 
 
 class SequenceEntryWithQuality(SequenceEntry):

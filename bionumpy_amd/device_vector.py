@@ -56,8 +56,11 @@ class DeviceVector:
         a = self.host()
         return a if dtype is None else a.astype(dtype, copy=False)
 
-    def __repr__(self):
-        return "DeviceVector(%r)" % (self.host(),)
+    def __repr__(self):                                # prints as the numpy array the reference returns here
+        return repr(self.host())                       # (docs_source/source/sequences.rst:173-174: ``array([4, 0])``)
+
+    def __str__(self):
+        return str(self.host())
 
     def __iter__(self):
         return iter(self.host())

@@ -597,6 +597,14 @@ def as_encoded_array(s, target_encoding=None):
     return target_encoding.encode(s)
 
 
+def from_encoded_array(encoded_array):
+    """the whole content as text: a str for an EncodedArray, a list of str for the rows of an EncodedRaggedArray
+    (encoded_array.py:621-652; ``str()`` of an array shows only its head)"""
+    if isinstance(encoded_array, EncodedRaggedArray):
+        return [from_encoded_array(row) for row in encoded_array]
+    return encoded_array.to_string()
+
+
 class EncodingException(Exception):
     pass
 

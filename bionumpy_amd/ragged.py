@@ -275,8 +275,11 @@ class RaggedArray:
             return bool((DeviceVector(HArray(dev=d)) == 0).any())
         return bool(np.any(self.lengths == 0))
 
-    def any(self, axis=-1):
-        """np.any: per row (axis -1; an empty row gives False), per column (0) or over everything (None) — flags are
+    # The reduction METHODS default to ``axis=None`` — the whole array, one scalar — as npstructures' RaggedArray methods do
+    # (pinned by the reference's doctest docs_source/source/reading_files.rst:46-54: ``chunk.quality.mean()`` prints one
+    # number per chunk); per row is ``axis=-1``, per column ``axis=0``.
+    def any(self, axis=None):
+        """np.any: over everything (None), per row (axis -1; an empty row gives False) or per column (0) — flags are
         reduced where they are (what the reference's callers do with match_string's result: string_matcher.py:16-55)"""
         self._check_axis(axis)
         if np.dtype(self.dtype) == np.bool_:
@@ -290,8 +293,8 @@ class RaggedArray:
             return self._col_sums()[0] > 0 if np.dtype(self.dtype) == np.bool_ else self._nonzero()._col_sums()[0] > 0
         return self._nonzero()._row_reduce("sum") > 0
 
-    def all(self, axis=-1):
-        """np.all: per row (an empty row gives True), per column or over everything"""
+    def all(self, axis=None):
+        """np.all: over everything, per row (an empty row gives True) or per column"""
         self._check_axis(axis)
         flags = self if np.dtype(self.dtype) == np.bool_ else self._nonzero()
         if axis is None:
@@ -314,19 +317,31 @@ class RaggedArray:
         flipped = as_bool(get_ops().mask_logic(as_u8(self._data), None, "not"))
         return RaggedArray._from_parts(flipped, None, self._lens, self._offsets, self._n_rows, self._total)
 
-    def sum(self, axis=-1):
+    def _device_total(self):
+        """sum of all elements of uint8 rows as a Python int: the per-row sums (one pass where the rows lie, also for a
+        text column that was never gathered) added up on the device — exact, so ``/ size`` is numpy's float64 mean"""
+        if not self.total():
+            return 0
+        sums = self._row_reduce("sum").harray()
+        return int(sums.dev().sum().item()) if sums.on_device else int(sums.host().sum())
+
+    def sum(self, axis=None):
         self._check_axis(axis)
         if axis is None:
             if np.dtype(self.dtype) == np.bool_:             # np.sum(sequence == "G"): counted on the device (README.rst:38-42)
                 return self._n_true()
+            if np.dtype(self.dtype) == np.uint8:             # (numpy adds uint8 up in uint64)
+                return np.uint64(self._device_total())
             return self._flat_values().sum()
         if axis == 0:
             return self._col_sums()[0]
         return self._row_reduce("sum")
 
-    def mean(self, axis=-1):
+    def mean(self, axis=None):
         self._check_axis(axis)
         if axis is None:
+            if np.dtype(self.dtype) == np.uint8 and self.total():
+                return np.float64(self._device_total()) / self.total()      # (integers below 2^53: the exact sum, as numpy's)
             return self._flat_values().mean()
         if axis == 0:
             if self.dtype not in (np.uint8, np.bool_):                      # (accumulated in float64, as np.mean does)
@@ -366,11 +381,26 @@ class RaggedArray:
             raise ValueError("zero-size row in a reduction which has no identity")
         return self._row_reduce(what)
 
-    def min(self, axis=-1):
+    def min(self, axis=None):
         return self._extreme("min", axis)
 
-    def max(self, axis=-1):
+    def max(self, axis=None):
         return self._extreme("max", axis)
+
+    def std(self, axis=None):
+        """np.std (population, ddof 0): over everything, or per row — presentation-side, on the host"""
+        self._check_axis(axis)
+        values = self._flat_values().astype(np.float64)
+        if axis is None:
+            return values.std()
+        if axis == 0:
+            raise NotImplementedError("std along the columns of a ragged array")
+        lens = self.lengths
+        with np.errstate(invalid="ignore", divide="ignore"):
+            row_of = np.repeat(np.arange(self._n_rows), lens)
+            means = np.bincount(row_of, weights=values, minlength=self._n_rows) / lens
+            dev2 = (values - means[row_of]) ** 2
+            return np.sqrt(np.bincount(row_of, weights=dev2, minlength=self._n_rows) / lens)
 
     @staticmethod
     def _concatenate(arrays):
@@ -392,7 +422,7 @@ class RaggedArray:
                 return NotImplemented
             return self._concatenate(arrays)
         name = {np.sum: "sum", np.mean: "mean", np.min: "min", np.max: "max", np.amin: "min", np.amax: "max", np.any: "any",
-                np.all: "all"}.get(func)
+                np.all: "all", np.std: "std"}.get(func)
         if func is np.count_nonzero and args and args[0] is self and np.dtype(self.dtype) == np.bool_ and \
                 kwargs.get("axis", args[1] if len(args) > 1 else None) is None:
             return self._n_true()
@@ -401,6 +431,13 @@ class RaggedArray:
         axis = kwargs.get("axis", args[1] if len(args) > 1 else None)
         return getattr(self, name)(axis=axis)
 
+    def get_column_values(self, col):
+        """the values in column ``col`` of the rows that reach it (npstructures RaggedArray.get_column_values; the
+        reference's docs_source/source/sequences.rst:115 counts the first letters of its sequences with it)"""
+        lens = self.lengths
+        reach = lens > col if col >= 0 else lens >= -col
+        return (self if bool(np.all(reach)) else self[reach])[:, col]
+
     def __iter__(self):
         return (self[i] for i in range(self._n_rows))
 
@@ -408,9 +445,12 @@ class RaggedArray:
         return [np.asarray(r).tolist() for r in self]
 
     def __repr__(self):
-        rows = [repr(np.asarray(self._row(i)).tolist()) for i in range(min(self._n_rows, 20))]
-        more = ", ..." if self._n_rows > 20 else ""
-        return "ragged_array([%s%s])" % (",\n              ".join(rows), more)
+        """the rows as numpy prints them, one per line (sequence/string_matcher.py:34-36, position_weight_matrix.py:186-189
+        of the reference: ``ragged_array([ True False False]\n[False  True False False  True])``); the first 20 rows"""
+        rows = [str(np.asarray(self._row(i))) for i in range(min(self._n_rows, 20))]
+        if self._n_rows > 20:
+            rows.append("...")
+        return "ragged_array(%s)" % "\n".join(rows)
 
     def __eq__(self, other):
         if not isinstance(other, RaggedArray):
