@@ -485,9 +485,9 @@ def virtual_ranks_mode(args, ops, dev, mode):
 def from_file_mode(args, ops, dev, mode, rank, world):
     """--from-file PATH: BASELINE config 4's shape from an actual FASTQ file.  Every rank calls the reference's stream form
 
-        count_kmers(bnp.open(PATH).read_chunks().sequence, k)
+        count_kmers(bnp.open(PATH, shard="auto").read_chunks().sequence, k)
 
-    and nothing else: under torch.distributed ``bnp.open`` gives every rank its part of the file (byte ranges cut at record
+    and nothing else: under torch.distributed ``shard="auto"`` gives every rank its part of the file (byte ranges cut at record
     starts, io/sharding.py) and the reduction finishes with the merge over the ranks.  The file is written first (rank 0,
     outside the timed region: world x --reads synthetic reads) unless it exists.  Exits 4 if the ranks' read counts do not add
     up to the reads of the file, and checks the merged histogram against the k-mers of all parts in read order (checksums,
@@ -515,7 +515,7 @@ def from_file_mode(args, ops, dev, mode, rank, world):
     chunk = args.file_chunk_mb << 20
 
     def step():
-        return bnp.count_kmers(bnp.open(path).read_chunks(min_chunk_size=chunk).sequence, args.k)
+        return bnp.count_kmers(bnp.open(path, shard="auto").read_chunks(min_chunk_size=chunk).sequence, args.k)
 
     for _ in range(args.warmup):
         h = step(); h._keys; del h
@@ -533,7 +533,7 @@ def from_file_mode(args, ops, dev, mode, rank, world):
     # ---- what was read and counted, outside the timed region -------------------------------------------------------
     n_reads = n_bases = 0
     flat = [0, 0, 0, 0]
-    for c in bnp.open(path).read_chunks(min_chunk_size=chunk):
+    for c in bnp.open(path, shard="auto").read_chunks(min_chunk_size=chunk):
         n_reads += len(c)
         seqs = bnp.change_encoding(c.sequence, bnp.DNAEncoding)
         n_bases += int(seqs.total())
@@ -558,7 +558,7 @@ def from_file_mode(args, ops, dev, mode, rank, world):
     if rank == 0:
         from bionumpy_amd import parallel
         print(json.dumps({
-            "mode": "from-file (count_kmers(bnp.open(f).read_chunks().sequence, k) on every rank; file -> pinned RAM -> HBM: never the headline value)",
+            "mode": "from-file (count_kmers(bnp.open(f, shard='auto').read_chunks().sequence, k) on every rank; file -> pinned RAM -> HBM: never the headline value)",
             "file": path, "file_bytes": file_bytes, "n_gpus": world, "k": args.k, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(float(tmax.item()) * 1e3, 2),
             "gbases_per_s": round(int(both[2][1].item()) / float(tmax.item()) / 1e9, 3),

@@ -101,12 +101,20 @@ def build(force=False, verbose=True):
 
 def _lint(objs, verbose):
     """the ISA lint over the device code of every object (isa_lint.py: a load's destination touched before its s_waitcnt;
-    an S_CSELECT on the SCC of scalar arithmetic across a 64-bit V_CMP) — a finding fails the build"""
+    an S_CSELECT on the SCC of scalar arithmetic across a 64-bit V_CMP) — a finding fails the build (BNPK_LINT=warn: it is
+    printed and the library is kept; BNPK_LINT=off, or the LLVM tools of the ROCm image absent: not run, said so)"""
     import importlib.util
+    mode = os.environ.get("BNPK_LINT", "strict").lower()
     spec = importlib.util.spec_from_file_location("bnpk_isa_lint", os.path.join(HERE, "isa_lint.py"))
     lint = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lint)
+    if mode == "off" or not (os.path.exists(lint.OBJDUMP) and os.path.exists(lint.BUNDLER)):
+        print("isa_lint: not run (%s)" % ("BNPK_LINT=off" if mode == "off" else "llvm-objdump / clang-offload-bundler not found"))
+        return
     findings, n_kernels, n_ins = lint.lint_objects(objs, verbose=False)
+    if findings and mode == "warn":
+        print("isa_lint: WARNING, %d finding(s) in the built kernels:\n%s" % (len(findings), "\n".join(findings)))
+        return
     if findings:
         raise RuntimeError("isa_lint: %d finding(s) in the built kernels:\n%s" % (len(findings), "\n".join(findings)))
     if verbose:

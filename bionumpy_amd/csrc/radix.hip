@@ -1100,7 +1100,10 @@ int bnpk_radix_partition_claimed(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n
                                  int64_t* d_bag_fill, void* stream) {
   if (!ctx || n < 0 || n_seg < 1 || bits < 1 || bits > 10 || shift < 0 || shift + bits > 63 || !d_fill || !d_bag_fill || bag_cap < 0)
     return BNPK_ERR_ARG;
-  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
+  // the claims of a child bucket are counted in 32 bits (fill[2c], fill[2c+1]): 2^32 keys of ONE bucket would wrap the
+  // counter, later claims would land on slots that already hold keys and the bag would never see them — so the
+  // level refuses any input that could do that; such inputs take the two-pass level (64-bit offsets)
+  if (n >= (1ll << 32)) return BNPK_ERR_RANGE;
   if (n > 0 && (!d_keys || !d_buckets || (bag_cap > 0 && !d_bag))) return BNPK_ERR_ARG;
   if (n_seg > 1 && !d_seg_offsets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;

@@ -61,11 +61,14 @@ def bnp_open(filename, mode=None, buffer_type=None, lazy=None, shard=None):
     """Open a sequence file for chunked reading (io/files.py:85-182).
 
     shard (extension): which part of the file this process reads when several ranks read it together.
-    None / "auto" — under an initialised ``torch.distributed`` job with more than one rank, rank r's part (so that
-    ``count_kmers(bnp.open(f).read_chunks().sequence, k)`` launched with torchrun reads the file ONCE and returns the
-    histogram of the whole file: dense counts summed on every rank, sparse counts partitioned by key range over the ranks);
-    otherwise the whole file.  ``False`` — the whole file on every rank (a reference genome every rank indexes).
-    ``(rank, world)`` — that part, whatever the job is (no merge is attempted without a process group)."""
+    ``"auto"`` — under an initialised ``torch.distributed`` job with more than one rank, rank r's part (so that
+    ``count_kmers(bnp.open(f, shard="auto").read_chunks().sequence, k)`` launched with torchrun reads the file ONCE and
+    returns the histogram of the whole file: dense counts summed on every rank, sparse counts partitioned by key range
+    over the ranks).  None (default) — the whole file on every rank, as the reference reads it, unless the environment
+    says BNPK_SHARD=auto: sharding is opt-in, because only a reduction that ends in the merge over the ranks
+    (``streamable`` reductions) gives the whole file's answer from a part per rank.  ``False`` — the whole file, whatever
+    the environment says (a reference genome every rank indexes).  ``(rank, world)`` — that part, whatever the job is
+    (no merge is attempted without a process group)."""
     from .sharding import resolve_shard
     suffix, is_gzip = _split_suffix(filename)
     open_func = gzip.open if is_gzip else open

@@ -24,7 +24,14 @@ class NpDataclassReader:
         return chunk.get_data()
 
     def read(self):
-        """the whole file as one chunk object (npdataclassreader.py:36-58)"""
+        """the whole file as one chunk object (npdataclassreader.py:36-58); of a sharded reader: the rank's part"""
+        if getattr(self._reader, "_chunk_modulo", None) is not None:
+            # the shard of a gzip stream is every n-th chunk (io/sharding.py): its entries are those chunks, joined
+            import numpy as np
+            chunks = list(self.read_chunks())
+            if not chunks:
+                return self._reader._buffer_type.dataclass.empty()
+            return chunks[0] if len(chunks) == 1 else np.concatenate(chunks)
         chunk = self._reader.read()
         if chunk is None:
             return self._reader._buffer_type.dataclass.empty()
@@ -32,10 +39,10 @@ class NpDataclassReader:
 
     def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
         """all complete entries of the next >= min_chunk_size bytes (npdataclassreader.py:60-92)"""
-        n_lines_read = self._reader.lines_before_chunk()
         chunk = self._reader.read_chunk(min_chunk_size, max_chunk_size)
         if chunk is None:
             return self._reader._buffer_type.dataclass.empty()
+        n_lines_read = self._reader.lines_before_chunk(chunk.n_lines)     # (behind the read: a shard may have skipped chunks)
         try:
             return self._wrap(chunk, n_lines_read)
         except FormatException as e:

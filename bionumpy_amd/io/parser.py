@@ -176,6 +176,7 @@ class _LinesBefore:
 
 class NumpyFileReader:
     _start, _stop, _chunk_modulo, _lines_before, _lines_before_value = 0, None, None, None, None     # (a reader of a whole file)
+    _chunk_index = 0                      # chunks read through read_chunk() so far (chunk-modulo shards)
 
     def __init__(self, file_obj, buffer_type, has_header=False, byte_range=None, chunk_modulo=None, lines_before=None):
         """byte_range: (start, stop) — the reader's file is bytes [start, stop) of the plain file ``file_obj`` (a rank's part
@@ -282,6 +283,10 @@ class NumpyFileReader:
 
     def read(self):
         """the whole file as one buffer (parser.py:89-94)"""
+        if self._chunk_modulo is not None:
+            # one buffer cannot hold every n-th chunk of a stream; NpDataclassReader.read() joins the shard's chunks instead
+            raise ValueError("read() of a chunk-modulo shard (a gzip stream that cannot be entered in the middle): the part of "
+                             "rank %d of %d is a set of chunks — use read_chunks(), or bnp.open(...).read()" % self._chunk_modulo)
         raw = self._file_obj.read() if self._stop is None else self._file_obj.read(max(0, self._stop - self._file_obj.tell()))
         if len(raw) == 0:
             return None
@@ -293,7 +298,8 @@ class NumpyFileReader:
     def read_chunks(self, min_chunk_size=5000000, max_chunk_size=None):
         if self._chunk_modulo is not None:
             r, n = self._chunk_modulo
-            for i, chunk in enumerate(self._read_chunks(min_chunk_size, max_chunk_size)):
+            for chunk in self._read_chunks(min_chunk_size, max_chunk_size):
+                i, self._chunk_index = self._chunk_index, self._chunk_index + 1
                 if i % n == r:
                     yield chunk
             return
@@ -310,7 +316,7 @@ class NumpyFileReader:
             yield from self._read_chunks_ahead(batch, max_chunk_size, window=min_chunk_size)
             return
         while not self._is_finished:
-            chunk = self.read_chunk(min_chunk_size, max_chunk_size)
+            chunk = self._read_chunk(min_chunk_size, max_chunk_size)
             if chunk is None:
                 break
             yield chunk
@@ -528,6 +534,18 @@ class NumpyFileReader:
             yield buff, s
 
     def read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
+        """the next chunk of THIS reader's part of the file: of a chunk-modulo shard (a gzip stream every rank inflates,
+        io/sharding.py) the next chunk i with i % n == r — the others are read and dropped, as ``read_chunks`` drops them"""
+        if self._chunk_modulo is None:
+            return self._read_chunk(min_chunk_size, max_chunk_size)
+        r, n = self._chunk_modulo
+        while True:
+            chunk = self._read_chunk(min_chunk_size, max_chunk_size)
+            i, self._chunk_index = self._chunk_index, self._chunk_index + 1
+            if chunk is None or i % n == r:
+                return chunk
+
+    def _read_chunk(self, min_chunk_size=5000000, max_chunk_size=None):
         """the next buffer of complete entries, or None at the end of the file (parser.py:96-171)"""
         if self._staging is None:
             self._staging = _Staging()

@@ -50,16 +50,19 @@ class Shard:
 def resolve_shard(shard):
     """``bnp.open(..., shard=...)`` -> Shard or None.
 
-    None / "auto": the ranks of ``torch.distributed`` if a process group has been initialised with more than one rank (a
-    job launched with torchrun reads every file ONCE, a part per rank) — unless BNPK_SHARD=0; False / "off": the whole
-    file; (rank, world) or (rank, world, group): as given; a Shard: itself."""
+    Sharding is OPT-IN (round 6): a script written against the reference and launched with torchrun keeps getting
+    the whole file on every rank — only the reductions that end in a merge over the ranks (``streamable`` reductions of
+    histograms, bincounts, sums) give the whole file's answer from a part per rank; a manual chunk loop or ``.read()`` would
+    silently see a 1/N part.  None: the whole file, unless the environment says BNPK_SHARD=auto (or 1); "auto": the ranks of
+    ``torch.distributed`` if a process group has been initialised with more than one rank (the job reads every file ONCE, a
+    part per rank); False / "off": the whole file; (rank, world) or (rank, world, group): as given; a Shard: itself."""
     if isinstance(shard, Shard):
         return shard if shard.world > 1 else None
     if shard is False or shard == "off":
         return None
+    if shard is None and os.environ.get("BNPK_SHARD", "0").lower() not in ("1", "auto"):
+        return None
     if shard is None or shard == "auto":
-        if os.environ.get("BNPK_SHARD", "1") == "0":
-            return None
         try:
             import torch.distributed as dist
         except Exception:                                    # noqa: BLE001

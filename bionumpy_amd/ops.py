@@ -38,6 +38,10 @@ class HipOps:
     def _empty(self, n, dtype):
         return self.device.empty(n, dtype)
 
+    def device_memory_bytes(self):
+        """HBM of the device this process counts on (what the batch limits of the lazy histograms are scaled to)"""
+        return int(torch_mod().cuda.get_device_properties(self.device.tdev).total_memory)
+
     # -- host staging --------------------------------------------------------------------------------
     def _fetch(self, t, n=None):
         """the first n int64 words of a device tensor as a list of Python ints (bnpk_fetch_i64: the page-locked mailbox)"""
@@ -855,7 +859,7 @@ class HipOps:
     def _claim_fits(self, n, n_buckets, bits):
         """the claiming level is worth its slots: a digit of at most 10 bits, buckets that are not nearly empty (the slots
         are 7680 per bucket whatever it holds: at most three times the keys), and the HBM to spare"""
-        if bits > 10 or bits < 1 or n < (1 << 20):
+        if bits > 10 or bits < 1 or n < (1 << 20) or n >= (1 << 32):     # (32-bit claim counters: bnpk_radix_partition_claimed)
             return False
         stride = int(lib.bnpk_claimed_stride())
         if n_buckets * stride > 3 * n:

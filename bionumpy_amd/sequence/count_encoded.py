@@ -123,7 +123,23 @@ class SparseKmerCounts:
     PENDING_LIMIT = 1 << 29            # uncounted hashes a histogram holds at most (4 GiB)
     LAZY_MAX = 1 << 26                 # inputs up to this many hashes are counted lazily (larger ones: at once)
     READS_LIMIT = 3 << 30              # k-mers of uncounted READS a histogram holds at most: what one counting pass takes
-                                       # (8 B/k-mer partitioned twice + 16 B per distinct k-mer: ~130 GB of the 288)
+                                       # (8 B/k-mer partitioned twice + 16 B per distinct k-mer: ~130 GB of the 288 of an
+                                       # MI355X; _reads_limit() scales it to the HBM of the device that is there)
+    _reads_limit_value = None
+
+    @classmethod
+    def _reads_limit(cls):
+        """READS_LIMIT for the device the process runs on: a counting pass takes ~44 bytes per pending k-mer; of a device
+        with less HBM than 288 GB only the same share is claimed (the constant was hard-wired to one chip)"""
+        if cls._reads_limit_value is None:
+            limit = cls.READS_LIMIT
+            try:
+                total = int(get_ops().device_memory_bytes())
+                limit = max(1 << 24, min(limit, int(limit * total / (288 << 30))))
+            except Exception:                              # noqa: BLE001  (host-logic backend: no device to ask)
+                pass
+            cls._reads_limit_value = limit
+        return cls._reads_limit_value
 
     def __init__(self, encoding, keys=None, counts=None, pending=None, key_bits=None, n_pending=None, key_range=None):
         self.encoding = encoding
@@ -214,7 +230,7 @@ class SparseKmerCounts:
             bits = max([x._key_bits for x in (self, other) if x._pending])
             out = SparseKmerCounts(self.encoding, k, c, self._pending + other._pending, bits, self._n_pend + other._n_pend)
             out._n_read_kmers = self._pending_read_kmers() + other._pending_read_kmers()
-            if out._n_pending() >= self.PENDING_LIMIT or out._n_read_kmers >= self.READS_LIMIT:
+            if out._n_pending() >= self.PENDING_LIMIT or out._n_read_kmers >= self._reads_limit():
                 out._force()
             return out
         keys, counts = get_ops().merge_add(self._keys, self._counts, other._keys, other._counts)

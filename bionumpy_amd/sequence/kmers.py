@@ -219,7 +219,7 @@ def count_kmers(sequence, k, axis=None, canonical=False):
                 return SparseKmerCounts(KmerEncoding(sequence.encoding, k), pending=[shared], key_bits=2 * k)
         packed, in_off, lens, n_rows, total = _as_dna_ragged(sequence)
         out_off, n_out = ops.row_offsets(lens, k)
-        if 0 < n_out <= SparseKmerCounts.READS_LIMIT // 4 and not canonical:
+        if 0 < n_out <= SparseKmerCounts._reads_limit() // 4 and not canonical:
             # a chunk of a file stream (or anything else of moderate size): nothing is counted yet — the histogram keeps the
             # READS, and counts them together with those of the chunks it is added to as soon as somebody looks at it
             # (see SparseKmerCounts / PendingReads: one pass of the fused generator over all of them)

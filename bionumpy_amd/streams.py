@@ -76,13 +76,15 @@ class streamable:
     instead of the size the caller named (the reference's default is 5 MB, a few hundredths of what one launch of the
     counting kernels is sized for)."""
 
-    def __init__(self, reduction=None, coalesce=False):
+    def __init__(self, reduction=None, coalesce=False, merge=None):
         self._reduction = reduction
         self._coalesce = coalesce
+        self._merge = merge                # (list of every rank's reduced value) -> the job's: plain numpy results of sharded streams
 
     def __call__(self, func):
         reduction = self._reduction
         coalesce = self._coalesce and reduction is not None
+        merge = self._merge
 
         @functools.wraps(func)
         def wrapped(*args, **kwargs):
@@ -105,21 +107,23 @@ class streamable:
                         return
                     yield func(*a, **kw)
 
+            shards = [v._shard for v in list(args) + list(kwargs.values()) if getattr(v, "_shard", None) is not None]
             if reduction is None:
-                return BnpStream(results())
+                out = BnpStream(results())
+                out._shard = shards[0] if shards else None       # what is mapped over a rank's part is a rank's part
+                return out
             reduced = reduction(results())
             # the stream was one rank's part of a file that several ranks read (bnp.open(..., shard=...), io/sharding.py): what
             # the ranks reduced is put together — the sum of the chunks' histograms of ALL ranks is what the reference's loop
             # over the whole file returns (EncodedCounts.__add__ across GPUs: SURVEY §8e)
-            shards = [v._shard for v in list(args) + list(kwargs.values()) if getattr(v, "_shard", None) is not None]
             if shards:
-                reduced = _merged_over_ranks(reduced, shards[0])
+                reduced = _merged_over_ranks(reduced, shards[0], merge)
             return reduced
 
         return wrapped
 
 
-def _merged_over_ranks(reduced, shard):
+def _merged_over_ranks(reduced, shard, merge=None):
     """what every rank reduced from its part of a file, put together (collective: every rank of the shard's group gets here,
     also one whose part held no entry — its ``sum`` of nothing is the int 0, so the ranks first tell each other what they
     hold, and a rank without a result joins the merge with an empty one of the others' kind)"""
@@ -129,7 +133,15 @@ def _merged_over_ranks(reduced, shard):
     mine = reduced._merge_descriptor() if hasattr(reduced, "_merge_descriptor") else None
     proto = next((d for d in parallel.all_gather_objects(mine, shard.group) if d is not None), None)
     if proto is None:
-        return reduced                                       # nothing that merges on any rank (plain numbers, arrays: as they are)
+        # nothing that knows how to merge itself on any rank: plain numbers and numpy arrays.  The reductions of this module
+        # say how their values add up (bincounts, histograms, sums); anybody else's reduction of a sharded stream stays the
+        # rank's partial result — said aloud, because the reference's caller expects the whole file's
+        if merge is not None:
+            return merge(parallel.all_gather_objects(reduced, shard.group))
+        import warnings
+        warnings.warn("the reduction of a sharded stream (bnp.open(..., shard=...)) returned %s, which this package cannot merge "
+                      "over the ranks: every rank holds the result of ITS part of the file" % type(reduced).__name__, stacklevel=3)
+        return reduced
     if mine is None:
         reduced = proto[0]._empty_like_descriptor(proto)
     return reduced._merged_over_ranks(shard)
@@ -152,18 +164,31 @@ def _join_bincounts(parts):
 
 
 def _join_histograms(parts):
-    hist, edges = next(parts)
+    first = next(parts, None)
+    if first is None:                                    # (no chunk: a rank of a sharded job whose part held no entry)
+        return None
+    hist, edges = first
     hist = np.asarray(hist).copy()
     for h, _ in parts:                                   # (the caller gives explicit bins / range, or the edges would differ)
         hist += h
     return hist, edges
 
 
-bincount = streamable(_join_bincounts)(np.bincount)
-histogram = streamable(_join_histograms)(np.histogram)
+def _merge_histograms(parts):
+    parts = [p for p in parts if isinstance(p, tuple)]
+    return _join_histograms(iter(parts)) if parts else None
 
 
-@streamable(sum)
+def _merge_sums(parts):
+    parts = [p for p in parts if not (np.ndim(p) == 0 and p == 0)]      # (sum of no chunk is the int 0)
+    return _join_bincounts(parts) if parts else 0
+
+
+bincount = streamable(_join_bincounts, merge=lambda parts: _join_bincounts([p for p in parts if p is not None]))(np.bincount)
+histogram = streamable(_join_histograms, merge=_merge_histograms)(np.histogram)
+
+
+@streamable(sum, merge=_merge_sums)
 def _sum_and_n(array, axis=None):
     n = array.size if axis is None else len(array)
     return np.append(np.asarray(np.sum(array, axis=axis), dtype=np.float64), n)
