@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbnpk.so")
+LIB_PATH = os.environ.get("BNPK_LIB") or os.path.join(_HERE, "csrc", "libbnpk.so")   # (BNPK_LIB: experiment builds, scripts/exp/build_variant.sh)
 
 NONE = (1 << 63) - 1          # BNPK_NONE
 
@@ -48,6 +48,10 @@ SIGNATURES = {
     "bnpk_copy_peak": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_copy_rates": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double), _p]),
     "bnpk_set_option": (_int, [_p, C.c_char_p, _i64]),
+    "bnpk_count_sparse_workspace": (_i64, [_i64, _int, _int, _i64, _int, _int]),
+    "bnpk_count_sparse": (_int, [_p, _p, _i64, _int, _int, _i64, _p, _int, _p, _i64, _p, _p, C.POINTER(_i64), C.POINTER(_i64), _p]),
+    "bnpk_index_build_workspace": (_i64, [_i64, _int, _i64]),
+    "bnpk_index_build": (_int, [_p, _p, _p, _i64, _int, _i64, _p, _i64, _p, _p, _p, C.POINTER(_i64), _p]),
     "bnpk_comm_available": (_int, []),
     "bnpk_comm_unique_id": (_int, [_p]),
     "bnpk_comm_init": (_int, [_p, _p, _int, _int, C.POINTER(C.c_void_p)]),

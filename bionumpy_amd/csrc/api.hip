@@ -127,6 +127,16 @@ int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value) {
     ctx->fastq_encoder = (int)value;
     return BNPK_OK;
   }
+  if (!strcmp(name, "sparse_claim")) {
+    if (value < 0 || value > 1) return BNPK_ERR_ARG;
+    ctx->sparse_claim = (int)value;
+    return BNPK_OK;
+  }
+  if (!strcmp(name, "l1_ring")) {
+    if (value < 0 || value > 1) return BNPK_ERR_ARG;
+    ctx->l1_ring = (int)value;
+    return BNPK_OK;
+  }
   return BNPK_ERR_ARG;
 }
 

@@ -24,6 +24,12 @@
 #ifndef RP_L1_LINE
 #define RP_L1_LINE 16       // flush granule (keys) of the fused first level
 #endif
+#ifndef RR_ABL
+#define RR_ABL 0            // experiment builds only (rp_ring_kernel): 1 no global stores, 2 no flush at all (counts only), 4 no ring writes
+#endif
+#ifndef KS_ITEMS
+#define KS_ITEMS 8          // base positions per lane and round of the k-mer source (experiment builds: 4, 12)
+#endif
 #ifndef RP_HELD
 #define RP_HELD 1           // the fused first level holds two store requests per lane back (see rp_scatter_kernel)
 #endif
@@ -170,7 +176,7 @@ struct kmer_source {
   // base positions per lane and round.  (Twelve fit the staging area too — a fifth of the positions start no k-mer and
   // 64-byte granules halve what a bucket carries — and were measured: 20.1 instead of 19.5 ms, the rounds get longer
   // faster than they get fewer.)
-  static constexpr int ITEMS = 8;
+  static constexpr int ITEMS = KS_ITEMS;
   const uint64_t* __restrict__ W;          // 2 bits per base
   const uint8_t* __restrict__ V;           // 1 bit per base: a k-mer starts here
   int64_t n_words;                         // words of W
@@ -780,6 +786,195 @@ __global__ __launch_bounds__(RP_THREADS) void rp_scatter_kernel(Source src, cons
 #endif
 }
 
+// ---- pass 2 of the fused first level, second form (round 6): every bucket has ONE 128-byte line at a fixed place in LDS ----
+// rp_scatter_kernel lays every round out anew: a packed scan over the buckets, a table look-up per key, the keys that do not
+// complete a line carried through registers into the next round's layout — 70 vector and 11 LDS instructions per k-mer, four
+// barriers per round, and what the SQ counters show is both pipes half busy and neither filling the other's gaps.  Here
+// nothing is laid out.  Bucket d owns the sixteen slots ring[16 d .. 16 d + 15] for the whole slab; cnt[d] = {keys of the
+// bucket that were ranked and not yet flushed : 16 | lines flushed so far : 16}.  A key takes its rank with one returning LDS
+// atomic, rel = the low half of the answer, and
+//     rel < 16        it is written to slot rel                                         (this round)
+//     16 <= rel < 32  its slot (rel - 16) is free after this round's flush: the lane keeps it in registers and writes it
+//                     first thing in the next round — the bucket's line of THIS round is complete without it
+//     rel >= 32       rare (a bucket that takes more than two lines of keys in one round: skewed digits): the workgroup
+//                     loops {write whoever's turn it is, flush} until nobody is left — correct for any input, fast for none
+// The flush needs no list and no owner either: eight lanes look at bucket d (d = tid / 8, + 128, ...), and if it holds
+// sixteen keys they read its line (16 bytes each, conflict-free), store it to line line_tab[d] of the output and the first of
+// them takes 16 off the count.  Two barriers per round: ranks + writes | flush.  The next tile's words are awaited, turned into
+// k-mers and the tile after next is requested BETWEEN the two (before the round's stores are issued: s_waitcnt vmcnt counts
+// stores, rp_scatter_kernel's comment), so the wait covers loads and stores that are a whole round old.
+// The slots in front of a bucket's first key (the bucket starts in the middle of a line that the previous slab completes)
+// hold RP_PHANTOM and are never stored; a slab's last round writes every bucket's remaining < 16 keys one by one.
+struct rr_cfg {
+  static constexpr int MAXB = 1024;
+  static constexpr size_t OFF_CNT = (size_t)MAXB * 16 * 8;
+  static constexpr size_t OFF_LINE = OFF_CNT + (size_t)MAXB * 4;
+  static constexpr size_t OFF_MISC = OFF_LINE + (size_t)MAXB * 4;
+  static constexpr size_t LDS = OFF_MISC + 8 * 8 + 16;
+};
+
+template <typename Source>
+__global__ __launch_bounds__(RP_THREADS) void rp_ring_kernel(Source src, const int64_t* __restrict__ seg_off,
+                                                             const int64_t* __restrict__ seg_slabs, int64_t n_seg,
+                                                             int64_t slab_keys, int shift, int bits,
+                                                             const int64_t* __restrict__ offs, uint64_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* ring = reinterpret_cast<uint64_t*>(smem);
+  unsigned* cnt = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_CNT);
+  unsigned* line_tab = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_LINE);
+  int64_t* sh = reinterpret_cast<int64_t*>(smem + rr_cfg::OFF_MISC);
+  unsigned* flags = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_MISC + 64);
+  const int B = 1 << bits;
+  const int tid = threadIdx.x;
+  slab_t sl;
+  if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
+  if (sl.lo >= sl.hi) return;
+  for (int i = tid; i < B * 16; i += RP_THREADS) ring[i] = RP_PHANTOM;
+  for (int d = tid; d < B; d += RP_THREADS) {
+    const int64_t c0 = offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
+    cnt[d] = (unsigned)(c0 & 15);
+    line_tab[d] = (unsigned)(c0 >> 4);
+  }
+  if (tid == 0) { flags[0] = 0; flags[1] = 0; }
+  __syncthreads();
+
+  constexpr int IT = Source::ITEMS;
+  constexpr int64_t TILE = (int64_t)IT * RP_THREADS;
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const unsigned dmask = (unsigned)(B - 1);
+  auto digit = [&](uint64_t key) { return (unsigned)(key >> shift) & dmask; };
+  // eight lanes per bucket: a bucket that holds a whole line gives it up.  The counts of four of a lane's buckets are read
+  // together, then the lines of those that are full (reads under their own exec masks, nothing waited for in between), then
+  // the stores: three LDS round trips per four buckets instead of two per bucket.
+  auto flush_lines = [&]() {
+    const int sub = tid & 7;
+    constexpr int G = RP_THREADS / 8;                            // buckets looked at per pass of the workgroup
+    constexpr int U = 4;
+    for (int d0 = tid >> 3; d0 < B; d0 += U * G) {
+      unsigned w[U], ln[U];
+      ulonglong2 kk[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) w[j] = d0 + j * G < B ? cnt[d0 + j * G] : 0u;
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if ((w[j] & 0xffffu) >= 16u && !(RR_ABL & 2)) {
+          ln[j] = line_tab[d0 + j * G];
+          kk[j] = *reinterpret_cast<const ulonglong2*>(ring + (d0 + j * G) * 16 + 2 * sub);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        if ((w[j] & 0xffffu) >= 16u) {
+          const int d = d0 + j * G;
+          if (sub == 0) {
+            cnt[d] = w[j] - 16u;
+            if (!(RR_ABL & 2)) line_tab[d] = ln[j] + 1u;
+          }
+          if (RR_ABL & 3) continue;
+          uint64_t* dst = out + (((uint64_t)ln[j] << 4) + (unsigned)(2 * sub));
+          if (!((kk[j].x | kk[j].y) >> 63)) {
+            u64x2 pair;
+            pair.x = kk[j].x;
+            pair.y = kk[j].y;
+            __builtin_nontemporal_store(pair, reinterpret_cast<u64x2*>(dst));
+          } else {                                             // phantom slots in front of the bucket's first key
+            if (!(kk[j].x >> 63)) dst[0] = kk[j].x;
+            if (!(kk[j].y >> 63)) dst[1] = kk[j].y;
+          }
+        }
+      }
+    }
+  };
+
+  int64_t t0 = sl.lo;
+  typename Source::raw_t raw;
+  src.template issue<true>(t0, sl.hi, raw);
+  // a late key waits in kd[q] for its slot: ad[q] = {slot in the ring : 16 | lines its bucket has to give up first : 16}.
+  // Every call of flush_lines takes exactly one line off a bucket that has late keys (its count is over 16 as long as they
+  // wait), so the lane counts the flushes down itself.
+  uint64_t k[IT] = {}, kd[IT] = {};
+  unsigned ad[IT] = {};
+  unsigned dm = 0;                                             // bit q: kd[q] is a late key
+  auto one_flush_passed = [&]() {
+#pragma unroll
+    for (int q = 0; q < IT; ++q) ad[q] -= ((dm >> q) & 1u) << 16;
+  };
+  // writes the late keys whose turn has come; returns whether any of this lane's still wait
+  auto write_late = [&]() {
+    unsigned still = 0;
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+      if ((dm >> q) & 1u) {
+        if ((ad[q] >> 16) == 0u) {
+          if (!(RR_ABL & 4)) ring[ad[q]] = kd[q];
+          dm &= ~(1u << q);
+        } else {
+          still = 1u;
+        }
+      }
+    }
+    return still;
+  };
+  Source::landed(raw);
+  unsigned vm = src.finish(t0, sl.hi, IT, raw, k);
+  if (t0 + TILE < sl.hi) src.template issue<true>(t0 + TILE, sl.hi, raw);
+  while (true) {
+    // the previous round's late keys: their bucket's line left at the end of that round
+    write_late();
+    // ranks, branch-free and back to back (a position where no k-mer starts adds zero to some bucket)
+#pragma unroll
+    for (int q = 0; q < IT; ++q) ad[q] = atomicAdd(&cnt[digit(k[q])], (vm >> q) & 1u);
+    unsigned ndm = 0, slow = 0;
+#pragma unroll
+    for (int q = 0; q < IT; ++q) {
+      const unsigned rel = ad[q];
+      const unsigned slot = digit(k[q]) * 16u + (rel & 15u);
+      const bool valid = (vm >> q) & 1u;
+      if (!(RR_ABL & 4) && valid && rel < 16u) ring[slot] = k[q];
+      ad[q] = slot | ((rel >> 4) << 16);
+      kd[q] = k[q];
+      ndm |= (valid && rel >= 16u) ? (1u << q) : 0u;
+      slow |= (valid && rel >= 32u) ? 1u : 0u;
+    }
+    dm = ndm;
+    if (slow) flags[0] = 1u;
+    __syncthreads();
+    const bool last = t0 + TILE >= sl.hi;
+    if (!last) {                                               // the next tile's k-mers, the loads of the tile after next
+      t0 += TILE;
+      Source::landed(raw);
+      vm = src.finish(t0, sl.hi, IT, raw, k);
+      if (t0 + TILE < sl.hi) src.template issue<true>(t0 + TILE, sl.hi, raw);
+    }
+    flush_lines();
+    one_flush_passed();
+    __syncthreads();
+    if (flags[0] != 0u) {                                      // (uniform) somebody's key is more than a line behind
+      while (true) {
+        __syncthreads();
+        if (tid == 0) { flags[0] = 0u; flags[1] = 0u; }
+        __syncthreads();
+        if (write_late()) flags[1] = 1u;
+        __syncthreads();
+        flush_lines();
+        one_flush_passed();
+        __syncthreads();
+        if (flags[1] == 0u) break;
+      }
+    }
+    if (last) break;
+  }
+  write_late();
+  __syncthreads();
+  for (int i = tid; i < B * 16; i += RP_THREADS) {              // what is left of every bucket: fewer than sixteen keys
+    const int d = i >> 4, sl_ = i & 15;
+    if ((unsigned)sl_ < cnt[d]) {
+      const uint64_t key = ring[i];
+      if (!(key >> 63)) out[((uint64_t)line_tab[d] << 4) + (unsigned)sl_] = key;
+    }
+  }
+}
+
 // seg_slabs[p] = slabs before segment p (p <= n_seg); one workgroup, any n_seg
 __global__ __launch_bounds__(RP_THREADS) void rp_slab_table_kernel(const int64_t* __restrict__ seg_off, int64_t n_seg,
                                                                    int64_t slab_keys, int64_t* __restrict__ seg_slabs) {
@@ -889,6 +1084,19 @@ int rp_level(bnpk_ctx* ctx, const Source& src, int64_t n, const int64_t* d_seg_o
                          (const int64_t*)H, (const int64_t*)seg_slabs, n_seg, B, hn, d_child_off);
   }
   bnpk_timer t(ctx, scatter_name, s);
+  if constexpr (!std::is_same<Source, mem_source>::value) {
+    if (ctx->l1_ring && bits <= 10) {                          // the fixed-line form of the fused first level (rp_ring_kernel)
+      auto kernel = rp_ring_kernel<Source>;
+      if (!attr_set[4 + which]) {
+        BNPK_HIP(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_cfg::LDS));
+        attr_set[4 + which] = true;
+      }
+      hipLaunchKernelGGL(kernel, dim3((unsigned)bound), dim3(RP_THREADS), rr_cfg::LDS, s, src, d_seg_off, (const int64_t*)seg_slabs,
+                         n_seg, slab_keys, shift, bits, (const int64_t*)H, reinterpret_cast<uint64_t*>(d_out));
+      BNPK_HIP(ctx, hipGetLastError());
+      return BNPK_OK;
+    }
+  }
   // (the granule: 16 keys for levels that read their keys from memory, 8 for the fused first level — see rp_cfg)
   constexpr int line = std::is_same<Source, mem_source>::value ? 16 : RP_L1_LINE;
   auto launch = [&](auto line_c, auto maxb_c) {

@@ -1,0 +1,505 @@
+// The planners of the sparse histogram and of the k-mer index as single C-ABI calls (round 6; SURVEY §8b lists
+// bnpk_count_sparse and bnpk_index_build as the entry points a caller binds).
+//
+//   bnpk_count_sparse   np.unique(keys, return_counts=True) (A9 for k > 13, SURVEY §3.5: the reference has no implementation):
+//                       plans the MSD levels for the buckets the finishing kernels take, runs them (the last one without its
+//                       histogram pass where the workspace allows: radix.hip's claiming level + the bag), looks at the real
+//                       bucket sizes (one census, ONE download), adds up to two levels or pre-counts a few heavy buckets,
+//                       finishes; whatever cannot be taken that way is sorted (the heavy-hitter fall-back).  Rounds 1-5 had this
+//                       in Python (ops.count_sparse: 200 lines around a dozen entry points); a C or Cython caller had to
+//                       rewrite it.  The workspace comes from the caller (bnpk_count_sparse_workspace), the function
+//                       synchronises where an answer decides the next launch: the bag's fill (claiming level), the census
+//                       (plain level), the number of distinct keys (always) — two or three round trips per call.
+//   bnpk_index_build    KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47): the sorted distinct
+//                       (k-mer, row) pairs WITHOUT a key-value sort: distinct k-mers (one sparse count), every k-mer's rank
+//                       among them (a 2^16-entry prefix table narrows the binary search to a few cache lines), the distinct
+//                       values of rank * n_rows + row (a second sparse count), split back into (k-mer, row).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int64_t FINISH_TARGET = 6500;   // average bucket the plan aims for (the fast finishing kernels take 7680 keys; random keys: sigma = 80)
+constexpr int MAX_PRECOUNTED = 256;       // buckets over the finishing capacity that are counted one by one
+constexpr int64_t CLAIM_MIN_KEYS = 1ll << 20;
+
+struct arena_t {
+  char* base = nullptr;
+  size_t size = 0, used = 0;
+  void* take(size_t bytes) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (at + bytes > size) return nullptr;
+    used = at + bytes;
+    return base + at;
+  }
+  int64_t* words(int64_t n) { return reinterpret_cast<int64_t*>(take((size_t)std::max<int64_t>(n, 1) * 8)); }
+  size_t left() const { return size - std::min(size, (used + 255) & ~(size_t)255); }
+};
+
+// digit widths of the MSD levels still to run so that the buckets average <= FINISH_TARGET keys, the top `done` bits resolved
+int radix_plan(int64_t n, int key_bits, int done, int levels[8]) {
+  int need = 0;
+  while (need < key_bits && (n >> need) > FINISH_TARGET) ++need;
+  const int rest = std::max(0, need - done);
+  if (rest == 0) return 0;
+  int max_bits = 10;                                   // 10-bit digits flush whole 128-byte lines ...
+  if ((rest + 10) / 11 < (rest + 9) / 10) max_bits = 11;   // ... but an 11-bit digit is cheaper than one more level
+  const int n_levels = (rest + max_bits - 1) / max_bits;
+  const int base = rest / n_levels, extra = rest % n_levels;
+  for (int i = 0; i < n_levels; ++i) levels[i] = base + (i < extra ? 1 : 0);
+  return n_levels;
+}
+
+size_t state_bytes(int64_t n_buckets) { return (size_t)bnpk_finish_state_words(n_buckets) * 8; }
+
+enum { SP_TRY_PLAIN = 1 };                              // (internal) the claiming level could not be used: take the plain one
+
+struct sparse_info {
+  int path = 0;          // 1 = claiming level + strided finish, 2 = plain levels + finish, 3 = sorted (fall-back), 0 = empty input
+  int levels = 0;        // partition levels run (the claiming one included)
+  int syncs = 0;         // host round trips
+  int64_t n_bag = 0;     // keys the claiming level put into the bag
+  int n_precounted = 0;  // heavy buckets counted one by one
+};
+
+int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
+                      const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth);
+
+// (sorted distinct keys, counts) by the library sort + run kernels: what heavy-hitter inputs take.  `work` is consumed.
+// keys_out NULL: the distinct keys go to the ping-pong buffer the sort left free, *keys_where says which, *sorted_where where
+// the sorted keys lie (dead after the call: the caller may reuse it); `alt` NULL: taken from the arena.
+int count_by_sorting(bnpk_ctx* ctx, int64_t* work, int64_t n, int key_bits, arena_t& arena, int64_t* keys_out, int64_t* counts_out,
+                     int64_t* h_n_unique, sparse_info& info, hipStream_t s, int64_t* alt = nullptr, int64_t** keys_where = nullptr,
+                     int64_t** sorted_where = nullptr) {
+  if (!alt) alt = arena.words(n);
+  const int64_t tiles = bnpk_run_tiles(n);
+  int64_t* tile_off = arena.words(tiles + 1);
+  if (!alt || !tile_off) return BNPK_ERR_NOMEM;
+  int in_alt = 0;
+  BNPK_CHECK(bnpk_sort_keys(ctx, work, alt, n, 0, std::min(key_bits, 64), &in_alt, s));
+  int64_t* sorted = in_alt ? alt : work;
+  int64_t n_runs = 0;
+  BNPK_CHECK(bnpk_run_census(ctx, sorted, nullptr, n, tile_off, &n_runs, s));
+  ++info.syncs;
+  int64_t* starts = arena.words(n_runs + 1);
+  if (!starts) return BNPK_ERR_NOMEM;
+  if (!keys_out) keys_out = in_alt ? work : alt;
+  BNPK_CHECK(bnpk_run_heads(ctx, sorted, nullptr, n, tile_off, n_runs, keys_out, nullptr, starts, s));
+  BNPK_CHECK(bnpk_run_sums(ctx, starts, n_runs, nullptr, counts_out, s));
+  if (keys_where) *keys_where = keys_out;
+  if (sorted_where) *sorted_where = sorted;
+  *h_n_unique = n_runs;
+  info.path = 3;
+  return BNPK_OK;
+}
+
+// (table, keys, counts) for bnpk_finish_sorted: the listed buckets {bucket, index of its first key, its keys} (ascending by
+// bucket) counted in ONE batch — gathered into one array, sorted and run-length-counted once (buckets differ in their top bits,
+// so the batch sorts bucket by bucket), the distinct keys cut back into buckets by a binary search of every bucket's first key
+// among the running key totals.
+int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& listed, int key_bits, arena_t& arena, int64_t** table_out,
+                     int64_t** big_keys, int64_t** big_counts, sparse_info& info, hipStream_t s) {
+  const int nb = (int)(listed.size() / 3);
+  std::vector<int64_t> order(nb);
+  for (int i = 0; i < nb; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return listed[3 * a] < listed[3 * b]; });
+  std::vector<int64_t> ids(nb), lo8(nb), byte_off(nb + 1, 0), prefix(nb);
+  int64_t total = 0;
+  for (int i = 0; i < nb; ++i) {
+    const int64_t* row = &listed[3 * order[i]];
+    ids[i] = row[0];
+    lo8[i] = row[1] * 8;
+    prefix[i] = total;
+    total += row[2];
+    byte_off[i + 1] = total * 8;
+  }
+  // three arrays of the batch's size: the batch, the sort's ping-pong buffer, the counts — the distinct keys go to whichever of
+  // the first two the sort leaves free, the running totals over the sorted keys once the runs are taken
+  int64_t* batch = arena.words(total + 1);
+  int64_t* batch_alt = arena.words(total + 1);
+  int64_t* c = arena.words(total);
+  int64_t* d_lo = arena.words(nb);
+  int64_t* d_off = arena.words(nb + 1);
+  int64_t* d_prefix = arena.words(nb);
+  int64_t* d_starts = arena.words(nb);
+  int64_t* table = arena.words(3 * (int64_t)nb);
+  if (!batch || !batch_alt || !c || !d_lo || !d_off || !d_prefix || !d_starts || !table) return BNPK_ERR_NOMEM;
+  BNPK_HIP(ctx, hipMemcpyAsync(d_lo, lo8.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(d_off, byte_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(d_prefix, prefix.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));                // (the host vectors go out of scope; pageable copies are staged anyway)
+  BNPK_CHECK(bnpk_gather_rows(ctx, reinterpret_cast<const uint8_t*>(keys), d_lo, d_off, nb, total * 8, 0,
+                              reinterpret_cast<uint8_t*>(batch), s));
+  int64_t d = 0;
+  int64_t *k = nullptr, *cum = nullptr;
+  BNPK_CHECK(count_by_sorting(ctx, batch, total, key_bits, arena, nullptr, c, &d, info, s, batch_alt, &k, &cum));
+  BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, c, d, cum, s));
+  BNPK_CHECK(bnpk_search_sorted(ctx, cum, d + 1, d_prefix, nb, 0, d_starts, s));
+  std::vector<int64_t> starts(nb);
+  BNPK_CHECK(bnpk_fetch_i64(ctx, d_starts, nb, starts.data(), s));
+  ++info.syncs;
+  std::vector<int64_t> host_table(3 * (size_t)nb);
+  for (int i = 0; i < nb; ++i) {
+    const int64_t end = i + 1 < nb ? starts[i + 1] : d;
+    host_table[3 * i] = ids[i];
+    host_table[3 * i + 1] = end - starts[i];
+    host_table[3 * i + 2] = starts[i];
+  }
+  BNPK_HIP(ctx, hipMemcpyAsync(table, host_table.data(), host_table.size() * 8, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipStreamSynchronize(s));
+  *table_out = table;
+  *big_keys = k;
+  *big_counts = c;
+  info.n_precounted = nb;
+  return BNPK_OK;
+}
+
+// bytes the claiming level + strided finish need for n keys in n_b buckets (besides the outputs)
+size_t claimed_bytes(int64_t n, int64_t n_b) {
+  const int64_t stride = bnpk_claimed_stride();
+  const int64_t bag_cap = std::max<int64_t>(n / 8, 1 << 16);
+  return (size_t)n_b * stride * 8 + (size_t)n_b * 8 + (size_t)bag_cap * 8 + 8 + (size_t)(n_b + 1) * 8 + state_bytes(n_b) + 16 * 256;
+}
+
+// the last level + finishing stage through buckets of fixed stride (bnpk_radix_partition_claimed, bnpk_claimed_finalize,
+// bnpk_finish_sorted_strided); the keys that found no place in their bucket (the bag) are counted on their own and merged in.
+// SP_TRY_PLAIN if the bag overflowed / a wait between workgroups gave up / the merge has no room: `cur` is intact then.
+int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets, int64_t n_seg, int shift, int bits, int key_bits,
+                  arena_t& arena, int64_t* keys_out, int64_t* counts_out, int64_t* h_n_unique, sparse_info& info, hipStream_t s,
+                  int depth) {
+  const int64_t n_b = n_seg << bits, stride = bnpk_claimed_stride();
+  const int64_t bag_cap = std::max<int64_t>(n / 8, 1 << 16);
+  const size_t mark = arena.used;
+  int64_t* buckets = arena.words(n_b * stride);
+  uint32_t* fill = reinterpret_cast<uint32_t*>(arena.take((size_t)n_b * 8));
+  int64_t* bag = arena.words(bag_cap);
+  int64_t* bag_fill = arena.words(1);
+  int64_t* b_off = arena.words(n_b + 1);
+  int64_t* state = reinterpret_cast<int64_t*>(arena.take(state_bytes(n_b)));
+  if (!buckets || !fill || !bag || !bag_fill || !b_off || !state) {
+    arena.used = mark;
+    return SP_TRY_PLAIN;
+  }
+  BNPK_CHECK(bnpk_radix_partition_claimed(ctx, cur, n, offsets, n_seg, shift, bits, buckets, fill, bag, bag_cap, bag_fill, s));
+  BNPK_CHECK(bnpk_claimed_finalize(ctx, buckets, fill, n_b, b_off, s));
+  int64_t n_bag = 0;
+  BNPK_CHECK(bnpk_fetch_i64(ctx, bag_fill, 1, &n_bag, s));
+  ++info.syncs;
+  info.n_bag = n_bag;
+  if (n_bag > bag_cap) {                                 // keys were dropped: the level again, the plain way
+    arena.used = mark;
+    return SP_TRY_PLAIN;
+  }
+  const int64_t n_in = n - n_bag;
+  int64_t d = 0;
+  int overflow = 0;
+  if (n_in > 0) {
+    BNPK_CHECK(bnpk_finish_sorted_strided(ctx, buckets, n_in, stride, b_off, n_b, shift, keys_out, counts_out, state, nullptr, 0,
+                                          nullptr, nullptr, &d, &overflow, s));
+    ++info.syncs;
+    if (overflow) {                                      // (a wait between workgroups gave up: the caller's plain path sorts)
+      arena.used = mark;
+      return SP_TRY_PLAIN;
+    }
+  }
+  ++info.levels;
+  info.path = 1;
+  if (n_bag > 0) {
+    // the bag's keys: counted the same way (a smaller problem), then one merge along the merge path.  The buckets are free:
+    // the bag's result and the merged lists live there if they fit (keys_out may be the caller's input: not scratch).
+    arena_t sub;
+    sub.base = reinterpret_cast<char*>(buckets);
+    sub.size = (size_t)n_b * stride * 8;
+    int64_t* bk = sub.words(n_bag);
+    int64_t* bc = sub.words(n_bag);
+    int64_t* mk = sub.words(d + n_bag);
+    int64_t* mc = sub.words(d + n_bag);
+    if (!bk || !bc || !mk || !mc) {                      // (no room for the merge: `cur` is intact, the plain level counts it)
+      arena.used = mark;
+      --info.levels;
+      return SP_TRY_PLAIN;
+    }
+    int64_t d_bag = 0;
+    sparse_info inner;
+    const int rb = count_sparse_impl(ctx, bag, n_bag, key_bits, 0, n_bag, nullptr, 0, sub, bk, bc, &d_bag, inner, s, depth + 1);
+    info.syncs += inner.syncs;
+    if (rb == BNPK_ERR_NOMEM) {
+      arena.used = mark;
+      --info.levels;
+      return SP_TRY_PLAIN;
+    }
+    BNPK_CHECK(rb);
+    int64_t m = 0;
+    BNPK_CHECK(bnpk_merge_add(ctx, d ? keys_out : nullptr, d ? counts_out : nullptr, d, bk, bc, d_bag, mk, mc, &m, s));
+    ++info.syncs;
+    BNPK_HIP(ctx, hipMemcpyAsync(keys_out, mk, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+    BNPK_HIP(ctx, hipMemcpyAsync(counts_out, mc, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+    d = m;
+  }
+  *h_n_unique = d;
+  return BNPK_OK;
+}
+
+int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
+                      const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth) {
+  if (n == 0) {
+    *h_n_unique = 0;
+    return BNPK_OK;
+  }
+  if (depth > 3) return BNPK_ERR_RANGE;
+  int64_t* cur = d_keys;
+  int64_t* spare = nullptr;                              // a free n-word buffer: what the previous level read
+  if (key_bits > 62)                                     // (no room for the phantom bit: the library sort)
+    return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s);
+  const int kb = key_bits - skip_bits;
+  const int64_t* offsets = d_part_offsets;
+  int done = part_bits;
+  int64_t n_seg = 1ll << done;
+  int plan[8];
+  const int n_levels = radix_plan(n_plan > 0 ? n_plan : n, kb, done, plan);
+  const bool may_claim = ctx->sparse_claim != 0;
+  for (int level = 0; level < n_levels; ++level) {
+    const int bits = plan[level];
+    const int shift = kb - done - bits;
+    if (level == n_levels - 1 && may_claim && bits >= 1 && bits <= 10 && n >= CLAIM_MIN_KEYS && n < (1ll << 32) &&
+        (n_seg << bits) * bnpk_claimed_stride() <= 3 * n && claimed_bytes(n, n_seg << bits) <= arena.left()) {
+      const int r = count_claimed(ctx, cur, n, offsets, n_seg, shift, bits, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, depth);
+      if (r != SP_TRY_PLAIN) return r;
+    }
+    int64_t* out = spare ? spare : arena.words(n);
+    int64_t* child = arena.words((n_seg << bits) + 1);
+    if (!out || !child) return BNPK_ERR_NOMEM;
+    BNPK_CHECK(bnpk_radix_partition(ctx, cur, n, offsets, n_seg, shift, bits, out, child, s));
+    spare = cur;
+    cur = out;
+    offsets = child;
+    done += bits;
+    n_seg <<= bits;
+    ++info.levels;
+  }
+  if (!offsets) {
+    int64_t* two = arena.words(2);
+    if (!two) return BNPK_ERR_NOMEM;
+    const int64_t host_two[2] = {0, n};
+    BNPK_HIP(ctx, hipMemcpyAsync(two, host_two, 16, hipMemcpyHostToDevice, s));
+    BNPK_HIP(ctx, hipStreamSynchronize(s));
+    offsets = two;
+  }
+  // The plan assumes well-spread keys; the real bucket sizes decide.  MANY buckets over the finishing kernels' capacity
+  // (skewed / duplicate-heavy keys): up to two extra levels sized from the largest bucket.  A FEW (heavy-hitter k-mers:
+  // extra levels cannot split equal keys): those are counted one by one and handed to the finishing kernel ready-made.
+  const int64_t cap = bnpk_finish_capacity();
+  bool fits = false;
+  int64_t *table = nullptr, *big_keys = nullptr, *big_counts = nullptr;
+  int n_big = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    int64_t* census = arena.words(2 + 3 * MAX_PRECOUNTED);
+    if (!census) return BNPK_ERR_NOMEM;
+    BNPK_CHECK(bnpk_bucket_census(ctx, offsets, n_seg, cap, MAX_PRECOUNTED, census, s));
+    std::vector<int64_t> got(2 + 3 * MAX_PRECOUNTED);
+    BNPK_CHECK(bnpk_fetch_i64(ctx, census, (int64_t)got.size(), got.data(), s));
+    ++info.syncs;
+    const int64_t largest = got[0], n_over = got[1];
+    if (largest <= cap) {
+      fits = true;
+      break;
+    }
+    int bits = std::max(1, (int)std::ceil(std::log2((double)largest / (0.7 * (double)cap))));
+    bits = std::min(std::min(11, kb - done), bits);
+    if (n_over <= MAX_PRECOUNTED) {
+      std::vector<int64_t> listed(got.begin() + 2, got.begin() + 2 + 3 * n_over);
+      BNPK_CHECK(precount_buckets(ctx, cur, listed, key_bits, arena, &table, &big_keys, &big_counts, info, s));
+      n_big = (int)n_over;
+      fits = true;
+      break;
+    }
+    if (attempt == 2 || bits <= 0) break;                // too many heavy buckets: the full sort below
+    int64_t* out = spare ? spare : arena.words(n);
+    int64_t* child = arena.words((n_seg << bits) + 1);
+    if (!out || !child) break;                           // (no room for another level: the sort)
+    if (bits <= 4 && n_seg > 4096 && largest <= bnpk_radix_small_capacity())
+      BNPK_CHECK(bnpk_radix_partition_small(ctx, cur, n, offsets, n_seg, kb - done - bits, bits, out, child, s));
+    else
+      BNPK_CHECK(bnpk_radix_partition(ctx, cur, n, offsets, n_seg, kb - done - bits, bits, out, child, s));
+    spare = cur;
+    cur = out;
+    offsets = child;
+    done += bits;
+    n_seg <<= bits;
+    ++info.levels;
+  }
+  if (fits) {
+    // (bnpk_finish_sorted uses the partitioned keys as workspace; d_keys_out is never the input: checked by the entry point)
+    int64_t* state = reinterpret_cast<int64_t*>(arena.take(state_bytes(n_seg)));
+    if (!state) return BNPK_ERR_NOMEM;
+    int64_t d = 0;
+    int overflow = 0;
+    BNPK_CHECK(bnpk_finish_sorted(ctx, cur, n, offsets, n_seg, kb - done, d_keys_out, d_counts_out, state, table, n_big, big_keys,
+                                  big_counts, &d, &overflow, s));
+    ++info.syncs;
+    if (overflow & 1) return BNPK_ERR_RANGE;             // every bucket was checked against the capacity above
+    if (overflow == 0) {
+      *h_n_unique = d;
+      info.path = 2;
+      return BNPK_OK;
+    }
+    // a wait between workgroups gave up (a run-time condition): the partitioned keys are intact, the sort gives the answer
+  }
+  return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s);
+}
+
+// ---- k-mer index ---------------------------------------------------------------------------------------------------------
+constexpr int PT_BITS = 16;                               // prefix table: first distinct key at or above every 16-bit prefix
+
+// table[p] = lower_bound(keys, p << (key_bits - PT_BITS)) for p in [0, 2^PT_BITS]
+__global__ void prefix_table_kernel(const int64_t* __restrict__ keys, int64_t d, int key_bits, int64_t* __restrict__ table) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > (1ll << PT_BITS)) return;
+  if (p == (1ll << PT_BITS)) {
+    table[p] = d;
+    return;
+  }
+  const int sh = key_bits > PT_BITS ? key_bits - PT_BITS : 0;
+  const int64_t q = p << sh;
+  int64_t lo = 0, hi = d;
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] < q) lo = mid + 1; else hi = mid;
+  }
+  table[p] = lo;
+}
+
+// ids[i] = rank(kmer_i) * n_rows + row_i, the rank by a binary search inside the k-mer's prefix range (a few cache lines)
+__global__ __launch_bounds__(256) void rank_compose_kernel(const int64_t* __restrict__ kmers, const int64_t* __restrict__ rows,
+                                                           int64_t n, const int64_t* __restrict__ keys,
+                                                           const int64_t* __restrict__ table, int key_bits, int64_t n_rows,
+                                                           int64_t* __restrict__ ids) {
+  const int sh = key_bits > PT_BITS ? key_bits - PT_BITS : 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int64_t q = kmers[i];
+    const int64_t p = key_bits > PT_BITS ? (q >> sh) : q;
+    int64_t lo = table[p], hi = table[p + 1];
+    while (lo < hi) {
+      const int64_t mid = lo + ((hi - lo) >> 1);
+      if (keys[mid] < q) lo = mid + 1; else hi = mid;
+    }
+    ids[i] = lo * n_rows + rows[i];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int64_t n_plan, int part_bits, int mode) {
+  if (n <= 0) return 256;
+  int plan[8];
+  const int kb = std::max(1, std::min(key_bits, 62) - skip_bits);
+  const int n_levels = radix_plan(n_plan > 0 ? n_plan : n, kb, part_bits, plan);
+  int total_bits = part_bits;
+  for (int i = 0; i < n_levels; ++i) total_bits += plan[i];
+  const int64_t n_b = 1ll << total_bits;
+  // mode 0: the levels' ping-pong buffer (none if no level runs), every level's offsets, the finishing state, the census
+  size_t bytes = (n_levels > 0 ? (size_t)n * 8 : 0) + (size_t)n_b * 8 * 2 + state_bytes(n_b) + (size_t)(2 + 3 * MAX_PRECOUNTED) * 8 * 4 +
+                 (1 << 20);
+  if (mode >= 1 && n_levels > 0 && plan[n_levels - 1] <= 10 && n >= CLAIM_MIN_KEYS && n < (1ll << 32) &&
+      n_b * bnpk_claimed_stride() <= 3 * n)
+    bytes = std::max(bytes, claimed_bytes(n, n_b) + (size_t)n_b * 8 + (1 << 20));      // mode 1: or the claiming level's slots
+  if (mode >= 2)
+    // mode 2: any input — the ping-pong buffer whether planned or not, two more levels' offsets (2^8 times the buckets at most),
+    // three arrays of n words for the heavy buckets' batch or the library sort
+    bytes = std::max(bytes, (size_t)n * 8 * 4 + (size_t)std::min<int64_t>(n_b << 8, 2 * n + 2) * 8 * 2 + state_bytes(std::min<int64_t>(n_b << 8, n + 1)) +
+                                ((size_t)bnpk_run_tiles(n) + 2) * 8 * 2 + (1 << 20));
+  return (int64_t)bytes;
+}
+
+int bnpk_count_sparse(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
+                      const int64_t* d_part_offsets, int part_bits, void* d_work, int64_t work_bytes, int64_t* d_keys_out,
+                      int64_t* d_counts_out, int64_t* h_n_unique, int64_t* h_info5, void* stream) {
+  if (!ctx || n < 0 || key_bits < 1 || key_bits > 64 || skip_bits < 0 || skip_bits >= key_bits || part_bits < 0 || part_bits > 20 ||
+      !h_n_unique || work_bytes < 0)
+    return BNPK_ERR_ARG;
+  if (part_bits > 0 && !d_part_offsets) return BNPK_ERR_ARG;
+  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
+  if (n > 0 && (!d_keys || !d_keys_out || !d_counts_out || !d_work)) return BNPK_ERR_ARG;
+  if (n > 0 && (d_counts_out == d_keys || d_keys_out == d_keys || d_keys_out == d_counts_out)) return BNPK_ERR_ARG;
+  arena_t arena;
+  arena.base = reinterpret_cast<char*>(d_work);
+  arena.size = (size_t)work_bytes;
+  sparse_info info;
+  *h_n_unique = 0;
+  const int st = count_sparse_impl(ctx, d_keys, n, key_bits, skip_bits, n_plan, part_bits ? d_part_offsets : nullptr, part_bits, arena,
+                                   d_keys_out, d_counts_out, h_n_unique, info, (hipStream_t)stream, 0);
+  if (h_info5) {
+    h_info5[0] = info.path;
+    h_info5[1] = info.levels;
+    h_info5[2] = info.syncs;
+    h_info5[3] = info.n_bag;
+    h_info5[4] = info.n_precounted;
+  }
+  return st;
+}
+
+int64_t bnpk_index_build_workspace(int64_t n, int key_bits, int64_t n_rows) {
+  if (n <= 0) return 256;
+  // the k-mers' copy, its distinct keys + counts, the ids, the prefix table; the two counts share one workspace
+  return (int64_t)((size_t)n * 8 * 4 + (((size_t)1 << PT_BITS) + 2) * 8 + (1 << 16)) +
+         std::max(bnpk_count_sparse_workspace(n, key_bits, 0, 0, 0, 2), bnpk_count_sparse_workspace(n, 62, 0, 0, 0, 2));
+}
+
+int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_rows, int64_t n, int key_bits, int64_t n_rows,
+                     void* d_work, int64_t work_bytes, int64_t* d_keys_out, int64_t* d_rows_out, int64_t* d_counts_out,
+                     int64_t* h_n_pairs, void* stream) {
+  if (!ctx || n < 0 || key_bits < 1 || key_bits > 62 || n_rows < 1 || !h_n_pairs || work_bytes < 0) return BNPK_ERR_ARG;
+  *h_n_pairs = 0;
+  if (n == 0) return BNPK_OK;
+  if (!d_kmers || !d_rows || !d_work || !d_keys_out || !d_rows_out) return BNPK_ERR_ARG;
+  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
+  hipStream_t s = (hipStream_t)stream;
+  arena_t arena;
+  arena.base = reinterpret_cast<char*>(d_work);
+  arena.size = (size_t)work_bytes;
+  int64_t* work_keys = arena.words(n);
+  int64_t* distinct = arena.words(n);
+  int64_t* counts = arena.words(n);
+  int64_t* ids = arena.words(n);
+  int64_t* table = arena.words((1ll << PT_BITS) + 1);
+  if (!work_keys || !distinct || !counts || !ids || !table) return BNPK_ERR_NOMEM;
+  const size_t mark = arena.used;
+  // 1. the distinct k-mers (the input is the caller's: counted on a copy)
+  BNPK_HIP(ctx, hipMemcpyAsync(work_keys, d_kmers, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+  int64_t d = 0;
+  sparse_info info;
+  BNPK_CHECK(count_sparse_impl(ctx, work_keys, n, key_bits, 0, n, nullptr, 0, arena, distinct, counts, &d, info, s, 0));
+  arena.used = mark;
+  // 2. every k-mer's rank among them, composed with its row: id = rank * n_rows + row orders like (k-mer, row)
+  int id_bits = 1;
+  while (id_bits < 63 && ((d * n_rows - 1) >> id_bits) != 0) ++id_bits;
+  if (d > 0 && (d > ((1ll << 62) / n_rows))) return BNPK_ERR_RANGE;
+  {
+    bnpk_timer t(ctx, "index_rank_compose", s);
+    hipLaunchKernelGGL(prefix_table_kernel, dim3((unsigned)(((1 << PT_BITS) + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const int64_t*)distinct, d, key_bits, table);
+    hipLaunchKernelGGL(rank_compose_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->compute_units * 32))),
+                       dim3(256), 0, s, d_kmers, d_rows, n, (const int64_t*)distinct, (const int64_t*)table, key_bits, n_rows, ids);
+    BNPK_HIP(ctx, hipGetLastError());
+  }
+  // 3. the distinct ids (ids is consumed; its distinct values go to work_keys, their multiplicities to counts)
+  int64_t m = 0;
+  sparse_info info2;
+  BNPK_CHECK(count_sparse_impl(ctx, ids, n, id_bits, 0, n, nullptr, 0, arena, work_keys, counts, &m, info2, s, 0));
+  // 4. back to (k-mer, row)
+  BNPK_CHECK(bnpk_pair_split(ctx, work_keys, m, n_rows, distinct, d_keys_out, d_rows_out, s));
+  if (d_counts_out) BNPK_HIP(ctx, hipMemcpyAsync(d_counts_out, counts, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+  *h_n_pairs = m;
+  return BNPK_OK;
+}
+
+}  // extern "C"

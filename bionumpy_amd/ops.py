@@ -733,7 +733,9 @@ class HipOps:
         return out, child
 
     def count_sparse(self, values, key_bits=62, consume=False, partition=None, key_range=None, fast=True, skew=1.0, dest=None):
-        """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys).
+        """np.unique(values, return_counts=True) on the device -> (keys, counts) HArrays (sorted keys): ONE call of
+        bnpk_count_sparse (csrc/sparse.hip plans the levels, the claiming level, the census, the heavy buckets and the
+        fall-back; rounds 1-5 had that planner here).
 
         partition: (bucket_offsets, bits) if ``values`` is already grouped by its top ``bits`` bits
         (kmers_partitioned).  key_range: (lo, hi) if all values are known to lie in [lo, hi) (the key range a
@@ -754,168 +756,50 @@ class HipOps:
                 return HArray(dev=out_keys[pos:pos]), HArray(dev=out_counts[pos:pos])
             z = self._empty(0, np.int64)
             return HArray(dev=z), HArray(dev=z.clone())
-        cur, owned = t, consume                          # owned: may ``cur`` be overwritten / handed out?
-        spare = None
-        if fast and key_bits <= 62:
-            skip, n_plan = 0, int(n * skew)
-            if key_range is not None and partition is None:
-                lo, hi = int(key_range[0]), int(key_range[1])
-                skip = key_bits - (lo ^ (hi - 1)).bit_length()
-                n_plan = int(n * skew * (1 << (key_bits - skip)) / max(hi - lo, 1))
-            offsets, done = (partition[0].dev(), partition[1]) if partition is not None else (None, 0)
-            n_seg = 1 << done
-            plan = self.radix_plan(n_plan, key_bits - skip, done)
-            for level, bits in enumerate(plan):
-                if level == len(plan) - 1 and self.claim_last_level and self._claim_fits(n, n_seg << bits, bits):
-                    # the last level without its histogram pass (radix.hip: buckets of fixed stride, claimed line by line)
-                    got = self._count_claimed(cur, offsets, n_seg, key_bits - skip - done - bits, bits, key_bits, spare if owned else None,
-                                              dest, out_keys if dest is not None else None, out_counts if dest is not None else None,
-                                              pos if dest is not None else 0)
-                    if got is not None:
-                        return got
-                out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
-                spare = cur if owned else None
-                cur, owned = out, True
-                done += bits
-                n_seg <<= bits
-            if offsets is None:
-                offsets = self.device.upload(np.array([0, n], dtype=np.int64))
-            # The plan assumes well-spread keys; the real bucket sizes decide.  MANY buckets over the finishing
-            # kernel's capacity (skewed / duplicate-heavy keys): up to two extra levels sized from the largest
-            # bucket.  A FEW (heavy-hitter k-mers: extra levels cannot split equal keys): those buckets are
-            # counted here, one by one, with the sort + run kernels and handed to the finishing kernel as
-            # ready-made (key, count) runs.
-            cap = int(lib.bnpk_finish_capacity())
-            big, fits = None, False
-            for attempt in range(3):
-                # the largest bucket, how many are over the capacity, and which (one reduction, one download)
-                census = self._empty(2 + 3 * self.MAX_PRECOUNTED, np.int64)
-                self._chk(lib.bnpk_bucket_census(self.ctx, ptr(offsets), n_seg, cap, self.MAX_PRECOUNTED, ptr(census), self._s()))
-                largest, n_over = self._fetch(census, 2)
-                if largest <= cap:
-                    fits = True
-                    break
-                bits = min(11, key_bits - skip - done, max(1, int(np.ceil(np.log2(largest / (0.7 * cap))))))
-                if n_over <= self.MAX_PRECOUNTED:
-                    listed = np.array(self._fetch(census[2:], 3 * n_over), dtype=np.int64).reshape(n_over, 3)
-                    listed = listed[np.argsort(listed[:, 0])]        # (the kernel lists them as it finds them)
-                    big = self._precount_buckets(cur, listed, key_bits)
-                    fits = True
-                    break
-                if attempt == 2 or bits <= 0:
-                    break                                # too many heavy buckets: the full sort below
-                if bits <= 4 and n_seg > 4096 and largest <= int(lib.bnpk_radix_small_capacity()):
-                    out = spare if spare is not None else self._empty(n, np.int64)
-                    child = self._empty(n_seg * (1 << bits) + 1, np.int64)
-                    self._chk(lib.bnpk_radix_partition_small(self.ctx, ptr(cur), n, ptr(offsets), n_seg,
-                                                             key_bits - skip - done - bits, bits, ptr(out), ptr(child),
-                                                             self._s()))
-                    offsets = child
-                else:
-                    out, offsets = self.radix_partition(cur, offsets, n_seg, key_bits - skip - done - bits, bits, spare)
-                spare = cur if owned else None
-                cur, owned = out, True
-                done += bits
-                n_seg <<= bits
-            if fits:
-                # bnpk_finish_sorted uses the partitioned keys as workspace: never the caller's array
-                work = cur if owned else cur.clone()
-                if dest is not None:
-                    keys_out, counts = out_keys[pos:pos + n], out_counts[pos:pos + n]
-                else:
-                    keys_out = spare if spare is not None else self._empty(n, np.int64)
-                    counts = self._empty(n, np.int64)
-                state = self._empty(lib.bnpk_finish_state_words(n_seg), np.int64)
-                n_unique, overflow = C.c_int64(0), C.c_int(0)
-                table, big_keys, big_counts = big if big is not None else (None, None, None)
-                self._chk(lib.bnpk_finish_sorted(self.ctx, ptr(work), n, ptr(offsets), n_seg, key_bits - skip - done,
-                                                 ptr(keys_out), ptr(counts), ptr(state), ptr(table),
-                                                 0 if table is None else table.numel() // 3, ptr(big_keys), ptr(big_counts),
-                                                 C.byref(n_unique), C.byref(overflow), self._s()))
-                if self.keep_finish_state:               # (experiments: the header words of the finishing kernels)
-                    self.last_finish_state = state[:128].cpu().numpy()
-                if overflow.value & 1:                   # every bucket was checked against the capacity above
-                    raise RuntimeError("bnpk_finish_sorted reported an overflow on buckets that fit")
-                if overflow.value == 0:
-                    return HArray(dev=keys_out[:n_unique.value]), HArray(dev=counts[:n_unique.value])
-                # a wait between workgroups gave up (bit 1: a run-time condition, not a capacity one — more plausible with
-                # another stream's kernels on the CUs): the partitioned keys are intact, the slower sort gives the answer
-                cur, owned = work, True
-                del keys_out, counts, state
-            del spare, big
-        keys_out, counts = self._count_by_sorting(cur if owned else cur.clone(), key_bits)
-        if dest is not None:
-            d = keys_out.numel()
-            out_keys[pos:pos + d].copy_(keys_out)
-            out_counts[pos:pos + d].copy_(counts)
-            keys_out, counts = out_keys[pos:pos + d], out_counts[pos:pos + d]
-        return HArray(dev=keys_out), HArray(dev=counts)
-
-    keep_finish_state = False
-    MAX_PRECOUNTED = 256          # buckets over the finishing kernel's capacity that are counted one by one
-    claim_last_level = True       # the last partition level claims its buckets' places instead of counting them first (see _count_claimed)
-    last_claimed = None           # what the last call of _count_claimed did (experiments, tests)
-
-    def _claim_fits(self, n, n_buckets, bits):
-        """the claiming level is worth its slots: a digit of at most 10 bits, buckets that are not nearly empty (the slots
-        are 7680 per bucket whatever it holds: at most three times the keys), and the HBM to spare"""
-        if bits > 10 or bits < 1 or n < (1 << 20) or n >= (1 << 32):     # (32-bit claim counters: bnpk_radix_partition_claimed)
-            return False
-        stride = int(lib.bnpk_claimed_stride())
-        if n_buckets * stride > 3 * n:
-            return False
-        t = torch_mod()
-        free, _ = t.cuda.mem_get_info(self.device.tdev)
-        reusable = t.cuda.memory_reserved(self.device.tdev) - t.cuda.memory_allocated(self.device.tdev)
-        return (n_buckets * stride + 2 * n + n // 8) * 8 < free + reusable
-
-    def _count_claimed(self, cur, offsets, n_seg, shift, bits, key_bits, spare, dest, out_keys, out_counts, pos):
-        """the last level + finishing stage through buckets of fixed stride: bnpk_radix_partition_claimed (no histogram pass:
-        48 GB less read per 6e9 keys), bnpk_claimed_finalize, bnpk_finish_sorted_strided; the keys that found no place in
-        their bucket (the bag: buckets over the finishing capacity) are counted on their own and merged in.
-        -> (keys, counts) HArrays, or None if the bag overflowed (the caller takes the plain level)."""
-        n = cur.numel()
-        n_b = n_seg << bits
-        stride = int(lib.bnpk_claimed_stride())
-        buckets = self._empty(n_b * stride, np.int64)
-        fill = self._empty(2 * n_b, np.int32)
-        bag_cap = max(n // 8, 1 << 16)
-        bag = self._empty(bag_cap, np.int64)
-        bag_fill = self._empty(1, np.int64)
-        self._chk(lib.bnpk_radix_partition_claimed(self.ctx, ptr(cur), n, ptr(offsets), n_seg, shift, bits, ptr(buckets), ptr(fill),
-                                                   ptr(bag), bag_cap, ptr(bag_fill), self._s()))
-        b_off = self._empty(n_b + 1, np.int64)
-        self._chk(lib.bnpk_claimed_finalize(self.ctx, ptr(buckets), ptr(fill), n_b, ptr(b_off), self._s()))
-        n_bag = self._fetch(bag_fill, 1)[0]
-        self.last_claimed = {"n": n, "buckets": n_b, "bag": n_bag, "bag_cap": bag_cap}
-        if n_bag > bag_cap:                                  # keys were dropped: the level again, the plain way
-            return None
-        n_in = n - n_bag
+        work = t if consume else t.clone()                   # (the call uses its input as workspace: never the caller's array)
+        if not fast or key_bits > 62:
+            keys_out, counts = self._count_by_sorting(work, key_bits)
+            if dest is not None:
+                d = keys_out.numel()
+                out_keys[pos:pos + d].copy_(keys_out)
+                out_counts[pos:pos + d].copy_(counts)
+                keys_out, counts = out_keys[pos:pos + d], out_counts[pos:pos + d]
+            return HArray(dev=keys_out), HArray(dev=counts)
+        skip, n_plan = 0, int(n * skew)
+        if key_range is not None and partition is None:
+            lo, hi = int(key_range[0]), int(key_range[1])
+            skip = key_bits - (lo ^ (hi - 1)).bit_length()
+            n_plan = int(n * skew * (1 << (key_bits - skip)) / max(hi - lo, 1))
+        offsets, done = (partition[0].dev(), int(partition[1])) if partition is not None else (None, 0)
         if dest is not None:
             keys_out, counts = out_keys[pos:pos + n], out_counts[pos:pos + n]
         else:
-            keys_out = spare if spare is not None else self._empty(n, np.int64)
-            counts = self._empty(n, np.int64)
-        state = self._empty(lib.bnpk_finish_state_words(n_b), np.int64)
-        n_unique, overflow = C.c_int64(0), C.c_int(0)
-        if n_in > 0:
-            self._chk(lib.bnpk_finish_sorted_strided(self.ctx, ptr(buckets), n_in, stride, ptr(b_off), n_b, shift, ptr(keys_out), ptr(counts),
-                                                     ptr(state), None, 0, None, None, C.byref(n_unique), C.byref(overflow), self._s()))
-            if self.keep_finish_state:
-                self.last_finish_state = state[:128].cpu().numpy()
-            if overflow.value:                               # (a wait between workgroups gave up: the caller's plain path sorts)
-                return None
+            keys_out, counts = self._empty(n, np.int64), self._empty(n, np.int64)
+        # the workspace: enough for any input where the device has it to spare (heavy-hitter buckets, the library sort: ~4 n
+        # words), else what the claiming level takes (~1.4 n: the 31-mer batch that fills the HBM), else the plain levels'
+        tm = torch_mod()
+        free, _ = tm.cuda.mem_get_info(self.device.tdev)
+        room = free + tm.cuda.memory_reserved(self.device.tdev) - tm.cuda.memory_allocated(self.device.tdev)
+        sizes = [int(lib.bnpk_count_sparse_workspace(n, key_bits, skip, n_plan, done, mode)) for mode in (0, 1, 2)]
+        if not self.claim_last_level:
+            sizes[1] = sizes[0]
+        lib.bnpk_set_option(self.ctx, b"sparse_claim", 1 if self.claim_last_level else 0)
+        work_bytes = sizes[2] if sizes[2] < room // 2 else (sizes[1] if sizes[1] + (64 << 20) < room else sizes[0])
+        space = self._empty(work_bytes, np.uint8)
+        n_unique = C.c_int64(0)
+        info = (C.c_int64 * 5)()
+        self._chk(lib.bnpk_count_sparse(self.ctx, ptr(work), n, key_bits, skip, n_plan, ptr(offsets), done, ptr(space), work_bytes,
+                                        ptr(keys_out), ptr(counts), C.byref(n_unique), info, self._s()))
+        self.last_sparse_info = {"path": int(info[0]), "levels": int(info[1]), "round_trips": int(info[2]), "bag": int(info[3]),
+                                 "precounted": int(info[4]), "workspace": work_bytes}
+        if info[0] == 1:
+            self.last_claimed = {"n": n, "bag": int(info[3])}
         d = n_unique.value
-        keys, cnts = HArray(dev=keys_out[:d]), HArray(dev=counts[:d])
-        if n_bag:
-            bk, bc = self.count_sparse(HArray(dev=bag[:n_bag].clone()), key_bits=key_bits, consume=True)
-            keys, cnts = self.merge_add(keys, cnts, bk, bc)
-            if dest is not None:
-                m = keys.size
-                out_keys[pos:pos + m].copy_(keys.dev())
-                out_counts[pos:pos + m].copy_(cnts.dev())
-                keys, cnts = HArray(dev=out_keys[pos:pos + m]), HArray(dev=out_counts[pos:pos + m])
-        return keys, cnts
+        return HArray(dev=keys_out[:d]), HArray(dev=counts[:d])
+
+    claim_last_level = True       # may the last partition level claim its buckets' places (bnpk_count_sparse's claiming level)?
+    last_claimed = None           # {"n", "bag"} if the last call of count_sparse took the claiming level (experiments, tests)
+    last_sparse_info = None       # what bnpk_count_sparse reported about its last call
 
     def _count_by_sorting(self, work, key_bits):
         """(sorted distinct keys, counts) of a torch int64 tensor (consumed): rocPRIM radix sort + run kernels"""
@@ -929,35 +813,6 @@ class HipOps:
         counts = self._empty(n_runs, np.int64)
         self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, None, ptr(counts), self._s()))
         return keys_out, counts
-
-    def _precount_buckets(self, keys_t, listed, key_bits):
-        """(table, keys, counts) for bnpk_finish_sorted: the listed buckets — rows {bucket, index of its first key, its keys}
-        on the host, ascending (bnpk_bucket_census) — counted in ONE batch: their keys are gathered into one array
-        (bnpk_gather_rows over the buckets' byte ranges), sorted and run-length-counted once (buckets differ in their top
-        bits, so the batch sorts bucket by bucket), and the distinct keys are cut back into buckets by a binary search of
-        every bucket's first possible key.  The few offsets involved are host arithmetic; nothing of it is a tensor op."""
-        t = torch_mod()
-        nb = listed.shape[0]
-        ids, lo, sizes = listed[:, 0], listed[:, 1], listed[:, 2]
-        byte_off = np.zeros(nb + 1, dtype=np.int64)
-        byte_off[1:] = np.cumsum(sizes * 8)
-        total = int(byte_off[nb])
-        batch = self._empty(total, np.uint8)
-        # (named, so that they live until the launch: a temporary freed between two uploads hands its memory to the next one)
-        d_lo, d_off = self.device.upload(lo * 8), self.device.upload(byte_off)
-        self._chk(lib.bnpk_gather_rows(self.ctx, ptr(keys_t.view(t.uint8)), ptr(d_lo), ptr(d_off), nb, total, 0, ptr(batch), self._s()))
-        k, c = self._count_by_sorting(batch.view(t.int64), key_bits)
-        # the distinct keys of listed bucket b start where the keys (with multiplicity) of the earlier listed buckets end
-        prefix = np.cumsum(sizes) - sizes                    # keys (with multiplicity) of earlier buckets in the batch
-        cum = self._empty(k.numel() + 1, np.int64)
-        self._chk(lib.bnpk_exclusive_scan_i64(self.ctx, ptr(c), c.numel(), ptr(cum), self._s()))
-        starts_t = self._empty(nb, np.int64)
-        d_prefix = self.device.upload(prefix)
-        self._chk(lib.bnpk_search_sorted(self.ctx, ptr(cum), cum.numel(), ptr(d_prefix), nb, 0, ptr(starts_t), self._s()))
-        starts = np.array(self._fetch(starts_t), dtype=np.int64)
-        ends = np.concatenate([starts[1:], [k.numel()]])
-        table = self.device.upload(np.stack([ids, ends - starts, starts], axis=1).reshape(-1).astype(np.int64))
-        return table, k, c
 
     def merge_add(self, a_keys, a_counts, b_keys, b_counts):
         """(keys, counts) of the sum of two sparse histograms (sorted distinct keys each): bnpk_merge_add"""
@@ -1001,56 +856,33 @@ class HipOps:
         self._chk(lib.bnpk_row_ids(self.ctx, ptr(offsets.dev()), n_rows, n, ptr(rows), self._s()))
         return HArray(dev=rows)
 
-    PAIRS_BY_SORT_MAX = 1 << 26       # pairs up to which unique_pairs is one sort + one run-length pass
-
     def unique_pairs(self, keys, values, key_bits=62, n_values=None, with_counts=False):
-        """sorted distinct (key, value) pairs, values in [0, n_values) — KmerIndex.create_index.  No key-value sort: the
-        pairs are the distinct values of id = rank(key) * n_values + value, rank = position among the sorted distinct
-        keys, so the index is two runs of the sparse counting path (bnpk_pair_compose / bnpk_pair_split around them)."""
+        """sorted distinct (key, value) pairs, values in [0, n_values) — KmerIndex.create_index
+        (bionumpy/sequence/indexing/kmer_indexing.py:24-47) as ONE call of bnpk_index_build: no key-value sort, the pairs are
+        the distinct values of id = rank(key) * n_values + value, rank = position among the sorted distinct keys — two runs
+        of the sparse counting path around a rank kernel (csrc/sparse.hip; round 5 sorted (k-mer, row) with the library's
+        radix_sort_pairs for indices under 2^26 pairs)."""
         t, v = keys.dev(), values.dev()
         n = t.numel()
         if n == 0:
             empty = (HArray(dev=t.clone()), HArray(dev=v.clone()))
             return empty + (HArray(dev=t.clone()),) if with_counts else empty
-        if n <= self.PAIRS_BY_SORT_MAX and key_bits <= 62:
-            # a small index (a genome's k-mers, not a read set's): ONE stable sort of the (k-mer, row) pairs by k-mer — the
-            # values arrive in row order, so equal k-mers come out with ascending rows — and one run-length pass over the
-            # pairs; one answer from the device (the number of runs).  The two-histogram construction below starts to pay
-            # from ~10^8 pairs on: at 1.2e7 it spent 8 ms in a dozen launch-bound kernels and six round trips.
-            t_alt, v_alt = self._empty(n, np.int64), self._empty(n, np.int64)
-            tk, tv = t.clone(), v.clone()
-            in_alt = C.c_int(0)
-            self._chk(lib.bnpk_sort_pairs(self.ctx, ptr(tk), ptr(t_alt), ptr(tv), ptr(v_alt), n, key_bits, C.byref(in_alt), self._s()))
-            if in_alt.value:
-                tk, t_alt, tv, v_alt = t_alt, tk, v_alt, tv
-            n_runs, tile_off = self._runs(tk, tv)
-            keys_out, vals_out = t_alt[:n_runs], v_alt[:n_runs]
-            starts = self._empty(n_runs + 1, np.int64)
-            self._chk(lib.bnpk_run_heads(self.ctx, ptr(tk), ptr(tv), n, ptr(tile_off), n_runs, ptr(keys_out), ptr(vals_out), ptr(starts),
-                                         self._s()))
-            if not with_counts:
-                return HArray(dev=keys_out), HArray(dev=vals_out)
-            counts = self._empty(n_runs, np.int64)
-            self._chk(lib.bnpk_run_sums(self.ctx, ptr(starts), n_runs, None, ptr(counts), self._s()))
-            return HArray(dev=keys_out), HArray(dev=vals_out), HArray(dev=counts)
         if n_values is None:
             n_values = int(v.max().item()) + 1
-        distinct, _ = self.count_sparse(HArray(dev=t), key_bits=key_bits)
-        rank = self.search_sorted(distinct, HArray(dev=t))
-        ids = self._empty(n, np.int64)
-        self._chk(lib.bnpk_pair_compose(self.ctx, ptr(rank.dev()), ptr(v), n, n_values, ptr(ids), self._s()))
-        del rank
-        id_bits = max(1, (distinct.size * n_values - 1).bit_length())
-        if id_bits > 62:
-            raise NotImplementedError("index too large: %d distinct k-mers x %d rows" % (distinct.size, n_values))
-        uids, pair_counts = self.count_sparse(HArray(dev=ids), key_bits=id_bits, consume=True)
-        m = uids.size
-        keys_out, vals_out = self._empty(m, np.int64), self._empty(m, np.int64)
-        self._chk(lib.bnpk_pair_split(self.ctx, ptr(uids.dev()), m, n_values, ptr(distinct.dev()), ptr(keys_out),
-                                      ptr(vals_out), self._s()))
-        if with_counts:                                        # how often every pair occurred
-            return HArray(dev=keys_out), HArray(dev=vals_out), pair_counts
-        return HArray(dev=keys_out), HArray(dev=vals_out)
+        work_bytes = int(lib.bnpk_index_build_workspace(n, key_bits, n_values))
+        space = self._empty(work_bytes, np.uint8)
+        keys_out, vals_out = self._empty(n, np.int64), self._empty(n, np.int64)
+        counts = self._empty(n, np.int64) if with_counts else None
+        m = C.c_int64(0)
+        status = lib.bnpk_index_build(self.ctx, ptr(t), ptr(v), n, key_bits, n_values, ptr(space), work_bytes, ptr(keys_out), ptr(vals_out),
+                                      ptr(counts), C.byref(m), self._s())
+        if status == -6:                                     # BNPK_ERR_RANGE: distinct keys x values over 62 bits
+            raise NotImplementedError("index too large: %d pairs x %d rows" % (n, n_values))
+        self._chk(status)
+        d = m.value
+        if with_counts:
+            return HArray(dev=keys_out[:d]), HArray(dev=vals_out[:d]), HArray(dev=counts[:d])
+        return HArray(dev=keys_out[:d]), HArray(dev=vals_out[:d])
 
     def search_sorted(self, sorted_keys, queries, upper=False):
         m = queries.size

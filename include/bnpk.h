@@ -121,6 +121,11 @@ int bnpk_copy_rates(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes
  *                + general kernel for buckets with a bin of more than 64 keys.  Same results in every mode.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
+ * "sparse_claim": may bnpk_count_sparse take the claiming level (1, default) or only plain levels (0)?  Same results.
+ * "l1_ring":     the scatter of bnpk_kmers_partition (the first radix level, fused with k-mer generation) — 0 = the
+ *                write-combining scatter that lays every round out anew (default; what the other levels use), 1 = one fixed
+ *                128-byte line per bucket in LDS, ranks by atomics, nothing laid out or carried (round 6: bit-identical
+ *                buckets, 21.7 ms against 17.1 per 6e9 k-mers — kept for the measurements in NOTES.md).  Same buckets.
  * Unknown names and values out of range return BNPK_ERR_ARG. */
 int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value);
 
@@ -611,6 +616,42 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
                        int64_t n_buckets, int low_bits, int64_t* d_keys_out, int64_t* d_counts_out, int64_t* d_state,
                        const int64_t* d_big_table, int n_big, const int64_t* d_big_keys, const int64_t* d_big_counts,
                        int64_t* h_n_unique, int* h_overflow, void* stream);
+/* ---- the sparse histogram as ONE call (round 6) ----------------------------------------------------------
+ * np.unique(keys, return_counts=True) for keys < 2^key_bits: d_keys_out / d_counts_out (n entries each, neither the input)
+ * receive the sorted distinct keys and their counts, *h_n_unique how many.  Replaces the k > 13 branch the reference does not
+ * have (bionumpy/sequence/count_encoded.py:150-188 counts k <= 8 densely; SURVEY §3.5 defines the rest as np.unique) and the
+ * planner that lived in Python through round 5: levels planned for buckets of ~6500 keys, the last one as the claiming level
+ * where the workspace has room for its slots, one census of the real bucket sizes, up to two more levels or up to 256 heavy
+ * buckets counted on their own, the finishing kernels; the library sort only for what none of that takes.
+ *   d_keys          CONSUMED (workspace afterwards)
+ *   skip_bits       leading bits of the key_bits that all keys share (the key range a rank owns after the exchange), else 0
+ *   n_plan          keys to plan the levels for if the keys are not spread evenly (canonical k-mers: 2 n), 0 = n
+ *   d_part_offsets  2^part_bits + 1 offsets if d_keys is already grouped by its top part_bits bits (bnpk_kmers_partition), else
+ *                   NULL / 0
+ *   d_work          work_bytes bytes of device memory.  bnpk_count_sparse_workspace(n, key_bits, skip_bits, n_plan, part_bits, mode) says how many:
+ *                   mode 2 = enough for ANY input (about 4 n words: heavy-hitter buckets are counted in a batch of their own, the
+ *                   library sort takes what nothing else does); mode 1 = the claiming level's slots (n_buckets * 7680 keys,
+ *                   ~1.4 n words: what well-spread keys take, the fastest path); mode 0 = plain levels only (~n words).  The
+ *                   call uses what it is given: the claiming level iff its slots fit, BNPK_ERR_NOMEM if the input needs a
+ *                   path the workspace has no room for (d_keys is lost then)
+ *   h_info5         optional: {path (1 claiming level, 2 plain levels, 3 library sort), levels run, host round trips, keys in
+ *                   the bag, heavy buckets counted one by one}
+ * Synchronous (the number of distinct keys is an answer). */
+int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int64_t n_plan, int part_bits, int mode);
+int bnpk_count_sparse(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
+                      const int64_t* d_part_offsets, int part_bits, void* d_work, int64_t work_bytes, int64_t* d_keys_out,
+                      int64_t* d_counts_out, int64_t* h_n_unique, int64_t* h_info5, void* stream);
+/* KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47) as ONE call: the sorted distinct (k-mer, row)
+ * pairs of n (k-mer, row) pairs, k-mers < 2^key_bits (key_bits <= 62), rows in [0, n_rows).  No key-value sort: the distinct
+ * k-mers (bnpk_count_sparse), every k-mer's rank among them (a binary search narrowed by a 2^16-entry prefix table), the
+ * distinct values of rank * n_rows + row (bnpk_count_sparse again: they order like the pairs), split back.  The inputs are
+ * left alone.  d_keys_out / d_rows_out: n entries each; d_counts_out (optional, n entries): how often every pair occurred;
+ * *h_n_pairs: the number of distinct pairs.  BNPK_ERR_RANGE if distinct k-mers * n_rows does not fit 62 bits. */
+int64_t bnpk_index_build_workspace(int64_t n, int key_bits, int64_t n_rows);
+int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_rows, int64_t n, int key_bits, int64_t n_rows,
+                     void* d_work, int64_t work_bytes, int64_t* d_keys_out, int64_t* d_rows_out, int64_t* d_counts_out,
+                     int64_t* h_n_pairs, void* stream);
+
 /* A10 for sparse histograms: the sum of two (sorted distinct keys, counts) lists — EncodedCounts.__add__
  * (bionumpy/sequence/count_encoded.py:38-48) as `streamable(sum)` folds it over the chunks of a file — by a merge along
  * the merge path: keys of either list are copied, counts of keys both lists hold are added.  d_out_* need na + nb

@@ -9,7 +9,6 @@ from bionumpy_amd.pipeline import fastq_kmer_histogram
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 reads = int(sys.argv[2]) if len(sys.argv) > 2 else 50_000_000
 ops = get_ops(); dev = Device.get()
-ops.keep_finish_state = bool(os.environ.get('FM_SPARE'))
 text = ops.synth_fastq(reads, 150, 20260925, 0, 0, 0)
 for mode in [int(m) for m in (sys.argv[3].split(',') if len(sys.argv) > 3 else '0,1,2,3,4,5'.split(','))]:
     assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
@@ -19,7 +18,6 @@ for mode in [int(m) for m in (sys.argv[3].split(',') if len(sys.argv) > 3 else '
     torch.cuda.synchronize()
     rep = dev.prof_report(); dev.prof_enable(False)
     print("finish_mode %d: finish_sorted %.1f ms, distinct %d of %d" % (mode, rep["finish_sorted"]["total_ms"], keys.size, st.n_kmers), flush=True)
-    if os.environ.get("FM_SPARE"):
-        print("   spare words:", ops.last_finish_state[72:80].tolist(), "fractions", [round(float(x) / max(float(ops.last_finish_state[72:80].sum()), 1.0), 3) for x in ops.last_finish_state[72:80]])
+    print("   ", ops.last_sparse_info)
     del keys, counts
 lib.bnpk_set_option(dev.ctx, b"finish_mode", 0)

@@ -184,14 +184,99 @@ def test_repeats_in_every_bucket_at_scale(env, mode):
     ek, ec = np.unique(base, return_counts=True)
     assert 0 < n - ek.size < n // 500
     assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == 0
-    ops.keep_finish_state = True
     try:
         for claim in (True, False):
             ops.claim_last_level, ops.last_claimed = claim, None
             gk, gc = ops.count_sparse(HArray(host=base), key_bits=62)
             assert gk.size == ek.size and np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), claim
-            assert int(ops.last_finish_state[0]) == 0                     # no flag: nothing overflowed, no wait gave up
+            # the path bnpk_count_sparse reports: the claiming level (1) or plain levels (2) — never the library sort (3), which
+            # is what an overflow or a wait that gave up would have ended in
+            assert ops.last_sparse_info["path"] == (1 if claim else 2), ops.last_sparse_info
             assert (ops.last_claimed is not None) == claim
     finally:
-        ops.keep_finish_state = False
         ops.claim_last_level = True
+
+
+# ---- the planners as single C calls (round 6: bnpk_count_sparse, bnpk_index_build — SURVEY §8b) -----------------------------
+def _count_sparse_raw(env, keys, mode, key_bits=62):
+    """bnpk_count_sparse through ctypes with nothing but device pointers: the binding INTEGRATION.md shows"""
+    ops, lib, dev, ptr, torch = env
+    n = keys.size
+    d_keys = torch.from_numpy(keys.copy()).to(dev.tdev)
+    out_k = torch.empty(max(n, 1), dtype=torch.int64, device=dev.tdev)
+    out_c = torch.empty(max(n, 1), dtype=torch.int64, device=dev.tdev)
+    nbytes = int(lib.bnpk_count_sparse_workspace(n, key_bits, 0, 0, 0, mode))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev.tdev)
+    n_unique, info = C.c_int64(-1), (C.c_int64 * 5)()
+    status = lib.bnpk_count_sparse(dev.ctx, ptr(d_keys), n, key_bits, 0, 0, None, 0, ptr(work), nbytes, ptr(out_k), ptr(out_c),
+                                   C.byref(n_unique), info, dev.stream())
+    return status, out_k[:max(n_unique.value, 0)].cpu().numpy(), out_c[:max(n_unique.value, 0)].cpu().numpy(), list(info)
+
+
+@pytest.mark.parametrize("name,keys", list(_cases()), ids=[c[0] for c in _cases()])
+def test_count_sparse_is_one_call(env, name, keys):
+    """np.unique(return_counts=True) from ONE entry point and raw pointers, on every shape of keys; with the workspace of mode 2
+    any input is taken; the paths it reports: claiming level / plain levels / library sort; at most a handful of round trips"""
+    ops, lib, dev, ptr, torch = env
+    ek, ec = oracle.count_sparse(keys)
+    assert lib.bnpk_set_option(dev.ctx, b"finish_mode", 0) == 0
+    for claim in (1, 0):
+        assert lib.bnpk_set_option(dev.ctx, b"sparse_claim", claim) == 0
+        status, gk, gc, info = _count_sparse_raw(env, keys, 2)
+        assert status == 0, (name, status)
+        assert np.array_equal(gk, ek) and np.array_equal(gc, ec), (name, claim, info)
+        assert info[0] in (1, 2, 3) and (claim or info[0] != 1), info
+        if name in ("distinct", "uniform") and keys.size >= (1 << 20):
+            assert info[0] == (1 if claim else 2) and info[2] <= 3, info        # two or three host round trips
+    assert lib.bnpk_set_option(dev.ctx, b"sparse_claim", 1) == 0
+
+
+def test_count_sparse_argument_checks_and_small_workspaces(env):
+    ops, lib, dev, ptr, torch = env
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 1 << 62, size=3_000_000, dtype=np.int64)
+    ek, ec = np.unique(keys, return_counts=True)
+    for mode in (0, 1):                                       # well-spread keys need no more than the plain / claiming workspace
+        status, gk, gc, info = _count_sparse_raw(env, keys, mode)
+        assert status == 0 and np.array_equal(gk, ek) and np.array_equal(gc, ec), (mode, info)
+        assert info[0] == (2 if mode == 0 else 1), info
+    # one key three million times cannot be split by levels: the heavy bucket is counted on its own — with a workspace that
+    # has no room for that the call says so instead of answering wrongly
+    same = np.full(3_000_000, 12345, dtype=np.int64)
+    status, gk, gc, info = _count_sparse_raw(env, same, 0)
+    assert status == -4                                       # BNPK_ERR_NOMEM
+    status, gk, gc, info = _count_sparse_raw(env, same, 2)
+    assert status == 0 and gk.tolist() == [12345] and gc.tolist() == [3_000_000]
+    # empty input, output aliasing the input
+    n_unique = C.c_int64(-1)
+    assert lib.bnpk_count_sparse(dev.ctx, None, 0, 62, 0, 0, None, 0, None, 0, None, None, C.byref(n_unique), None, dev.stream()) == 0
+    assert n_unique.value == 0
+    t = torch.zeros(16, dtype=torch.int64, device=dev.tdev)
+    w = torch.empty(1 << 20, dtype=torch.uint8, device=dev.tdev)
+    assert lib.bnpk_count_sparse(dev.ctx, ptr(t), 16, 62, 0, 0, None, 0, ptr(w), 1 << 20, ptr(t), ptr(t), C.byref(n_unique), None,
+                                 dev.stream()) == -1
+
+
+def test_index_build_is_one_call(env):
+    """KmerIndex.create_index (kmer_indexing.py:24-47) from raw pointers: sorted distinct (k-mer, row) pairs and how often each
+    occurred, against np.unique over the pairs — random 62-bit k-mers, a repeat-rich 'genome' and a heavy hitter"""
+    ops, lib, dev, ptr, torch = env
+    rng = np.random.default_rng(17)
+    for name, n, n_rows, make in (("random", 2_500_000, 17, lambda: rng.integers(0, 1 << 62, size=2_500_000, dtype=np.int64)),
+                                  ("repeats", 1_200_000, 300, lambda: _genome_like(rng, 1_200_000, 40)),
+                                  ("hitter", 400_000, 5, lambda: np.where(rng.random(400_000) < 0.5, 777, rng.integers(0, 1 << 40, size=400_000))),
+                                  ("tiny", 7, 3, lambda: np.array([5, 5, 9, 1, 5, 9, 1], dtype=np.int64))):
+        kmers = make().astype(np.int64)
+        rows = np.sort(rng.integers(0, n_rows, size=n)).astype(np.int64)
+        pairs, mult = np.unique(np.stack([kmers, rows]), axis=1, return_counts=True)
+        d_k, d_r = torch.from_numpy(kmers).to(dev.tdev), torch.from_numpy(rows).to(dev.tdev)
+        nbytes = int(lib.bnpk_index_build_workspace(n, 62, n_rows))
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev.tdev)
+        ok, orow, oc = (torch.empty(n, dtype=torch.int64, device=dev.tdev) for _ in range(3))
+        m = C.c_int64(-1)
+        assert lib.bnpk_index_build(dev.ctx, ptr(d_k), ptr(d_r), n, 62, n_rows, ptr(work), nbytes, ptr(ok), ptr(orow), ptr(oc),
+                                    C.byref(m), dev.stream()) == 0, name
+        assert m.value == pairs.shape[1], (name, m.value, pairs.shape)
+        assert np.array_equal(ok[:m.value].cpu().numpy(), pairs[0]) and np.array_equal(orow[:m.value].cpu().numpy(), pairs[1]), name
+        assert np.array_equal(oc[:m.value].cpu().numpy(), mult), name
+        assert np.array_equal(d_k.cpu().numpy(), kmers) and np.array_equal(d_r.cpu().numpy(), rows)      # the inputs are left alone
