@@ -21,7 +21,18 @@
 
 #include "common.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
+
+// BNPK_SPARSE_DEBUG=1: which request the workspace could not serve, on stderr
+int nomem_at(int line, size_t used, size_t size) {
+  static const bool on = getenv("BNPK_SPARSE_DEBUG") != nullptr;
+  if (on) fprintf(stderr, "bnpk sparse.hip:%d: workspace exhausted (%zu of %zu bytes used)\n", line, used, size);
+  return BNPK_ERR_NOMEM;
+}
+#define SP_NOMEM(arena) nomem_at(__LINE__, (arena).used, (arena).size)
 
 constexpr int64_t FINISH_TARGET = 6500;   // average bucket the plan aims for (the fast finishing kernels take 7680 keys; random keys: sigma = 80)
 constexpr int MAX_PRECOUNTED = 256;       // buckets over the finishing capacity that are counted one by one
@@ -79,7 +90,7 @@ int count_by_sorting(bnpk_ctx* ctx, int64_t* work, int64_t n, int key_bits, aren
   if (!alt) alt = arena.words(n);
   const int64_t tiles = bnpk_run_tiles(n);
   int64_t* tile_off = arena.words(tiles + 1);
-  if (!alt || !tile_off) return BNPK_ERR_NOMEM;
+  if (!alt || !tile_off) return SP_NOMEM(arena);
   int in_alt = 0;
   BNPK_CHECK(bnpk_sort_keys(ctx, work, alt, n, 0, std::min(key_bits, 64), &in_alt, s));
   int64_t* sorted = in_alt ? alt : work;
@@ -87,7 +98,7 @@ int count_by_sorting(bnpk_ctx* ctx, int64_t* work, int64_t n, int key_bits, aren
   BNPK_CHECK(bnpk_run_census(ctx, sorted, nullptr, n, tile_off, &n_runs, s));
   ++info.syncs;
   int64_t* starts = arena.words(n_runs + 1);
-  if (!starts) return BNPK_ERR_NOMEM;
+  if (!starts) return SP_NOMEM(arena);
   if (!keys_out) keys_out = in_alt ? work : alt;
   BNPK_CHECK(bnpk_run_heads(ctx, sorted, nullptr, n, tile_off, n_runs, keys_out, nullptr, starts, s));
   BNPK_CHECK(bnpk_run_sums(ctx, starts, n_runs, nullptr, counts_out, s));
@@ -128,7 +139,7 @@ int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& l
   int64_t* d_prefix = arena.words(nb);
   int64_t* d_starts = arena.words(nb);
   int64_t* table = arena.words(3 * (int64_t)nb);
-  if (!batch || !batch_alt || !c || !d_lo || !d_off || !d_prefix || !d_starts || !table) return BNPK_ERR_NOMEM;
+  if (!batch || !batch_alt || !c || !d_lo || !d_off || !d_prefix || !d_starts || !table) return SP_NOMEM(arena);
   BNPK_HIP(ctx, hipMemcpyAsync(d_lo, lo8.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_off, byte_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_prefix, prefix.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
@@ -217,8 +228,12 @@ int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets
     sub.size = (size_t)n_b * stride * 8;
     int64_t* bk = sub.words(n_bag);
     int64_t* bc = sub.words(n_bag);
-    int64_t* mk = sub.words(d + n_bag);
-    int64_t* mc = sub.words(d + n_bag);
+    int64_t* mk = arena.words(d + n_bag);                // (the merged lists: behind the level's slots if there is room, else in them)
+    int64_t* mc = mk ? arena.words(d + n_bag) : nullptr;
+    if (!mc) {
+      mk = sub.words(d + n_bag);
+      mc = sub.words(d + n_bag);
+    }
     if (!bk || !bc || !mk || !mc) {                      // (no room for the merge: `cur` is intact, the plain level counts it)
       arena.used = mark;
       --info.levels;
@@ -274,7 +289,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     }
     int64_t* out = spare ? spare : arena.words(n);
     int64_t* child = arena.words((n_seg << bits) + 1);
-    if (!out || !child) return BNPK_ERR_NOMEM;
+    if (!out || !child) return SP_NOMEM(arena);
     BNPK_CHECK(bnpk_radix_partition(ctx, cur, n, offsets, n_seg, shift, bits, out, child, s));
     spare = cur;
     cur = out;
@@ -285,7 +300,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   }
   if (!offsets) {
     int64_t* two = arena.words(2);
-    if (!two) return BNPK_ERR_NOMEM;
+    if (!two) return SP_NOMEM(arena);
     const int64_t host_two[2] = {0, n};
     BNPK_HIP(ctx, hipMemcpyAsync(two, host_two, 16, hipMemcpyHostToDevice, s));
     BNPK_HIP(ctx, hipStreamSynchronize(s));
@@ -300,7 +315,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   int n_big = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
     int64_t* census = arena.words(2 + 3 * MAX_PRECOUNTED);
-    if (!census) return BNPK_ERR_NOMEM;
+    if (!census) return SP_NOMEM(arena);
     BNPK_CHECK(bnpk_bucket_census(ctx, offsets, n_seg, cap, MAX_PRECOUNTED, census, s));
     std::vector<int64_t> got(2 + 3 * MAX_PRECOUNTED);
     BNPK_CHECK(bnpk_fetch_i64(ctx, census, (int64_t)got.size(), got.data(), s));
@@ -337,7 +352,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   if (fits) {
     // (bnpk_finish_sorted uses the partitioned keys as workspace; d_keys_out is never the input: checked by the entry point)
     int64_t* state = reinterpret_cast<int64_t*>(arena.take(state_bytes(n_seg)));
-    if (!state) return BNPK_ERR_NOMEM;
+    if (!state) return SP_NOMEM(arena);
     int64_t d = 0;
     int overflow = 0;
     BNPK_CHECK(bnpk_finish_sorted(ctx, cur, n, offsets, n_seg, kb - done, d_keys_out, d_counts_out, state, table, n_big, big_keys,
@@ -411,11 +426,14 @@ int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int6
                  (1 << 20);
   if (mode >= 1 && n_levels > 0 && plan[n_levels - 1] <= 10 && n >= CLAIM_MIN_KEYS && n < (1ll << 32) &&
       n_b * bnpk_claimed_stride() <= 3 * n)
-    bytes = std::max(bytes, claimed_bytes(n, n_b) + (size_t)n_b * 8 + (1 << 20));      // mode 1: or the claiming level's slots
+    // mode 1: or the claiming level's slots — and, for inputs small enough that a slab's leftovers overflow the buckets' tails
+    // into the bag as a matter of course (one level over a few million keys), room to merge the bag's counts in
+    bytes = std::max(bytes, claimed_bytes(n, n_b) + (size_t)n_b * 8 + (1 << 20) + (n <= (1ll << 26) ? (size_t)(n + n / 8 + (1 << 16)) * 16 : 0));
   if (mode >= 2)
     // mode 2: any input — the ping-pong buffer whether planned or not, two more levels' offsets (2^8 times the buckets at most),
-    // three arrays of n words for the heavy buckets' batch or the library sort
-    bytes = std::max(bytes, (size_t)n * 8 * 4 + (size_t)std::min<int64_t>(n_b << 8, 2 * n + 2) * 8 * 2 + state_bytes(std::min<int64_t>(n_b << 8, n + 1)) +
+    // four arrays of n words for the heavy buckets' batch (the batch, the sort's other buffer, the counts, the runs' starts) or
+    // the library sort
+    bytes = std::max(bytes, (size_t)n * 8 * 5 + (size_t)std::min<int64_t>(n_b << 8, 2 * n + 2) * 8 * 2 + state_bytes(std::min<int64_t>(n_b << 8, n + 1)) +
                                 ((size_t)bnpk_run_tiles(n) + 2) * 8 * 2 + (1 << 20));
   return (int64_t)bytes;
 }
@@ -471,7 +489,7 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
   int64_t* counts = arena.words(n);
   int64_t* ids = arena.words(n);
   int64_t* table = arena.words((1ll << PT_BITS) + 1);
-  if (!work_keys || !distinct || !counts || !ids || !table) return BNPK_ERR_NOMEM;
+  if (!work_keys || !distinct || !counts || !ids || !table) return SP_NOMEM(arena);
   const size_t mark = arena.used;
   // 1. the distinct k-mers (the input is the caller's: counted on a copy)
   BNPK_HIP(ctx, hipMemcpyAsync(work_keys, d_kmers, (size_t)n * 8, hipMemcpyDeviceToDevice, s));

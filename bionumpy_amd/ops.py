@@ -775,7 +775,7 @@ class HipOps:
             keys_out, counts = out_keys[pos:pos + n], out_counts[pos:pos + n]
         else:
             keys_out, counts = self._empty(n, np.int64), self._empty(n, np.int64)
-        # the workspace: enough for any input where the device has it to spare (heavy-hitter buckets, the library sort: ~4 n
+        # the workspace: enough for any input where the device has it to spare (heavy-hitter buckets, the library sort: ~5 n
         # words), else what the claiming level takes (~1.4 n: the 31-mer batch that fills the HBM), else the plain levels'
         tm = torch_mod()
         free, _ = tm.cuda.mem_get_info(self.device.tdev)
@@ -792,8 +792,8 @@ class HipOps:
                                         ptr(keys_out), ptr(counts), C.byref(n_unique), info, self._s()))
         self.last_sparse_info = {"path": int(info[0]), "levels": int(info[1]), "round_trips": int(info[2]), "bag": int(info[3]),
                                  "precounted": int(info[4]), "workspace": work_bytes}
-        if info[0] == 1:
-            self.last_claimed = {"n": n, "bag": int(info[3])}
+        if info[0] == 1 or info[3] > 0:                      # the claiming level ran (and, if the path is not 1, was given up: its bag overflowed)
+            self.last_claimed = {"n": n, "bag": int(info[3]), "kept": info[0] == 1}
         d = n_unique.value
         return HArray(dev=keys_out[:d]), HArray(dev=counts[:d])
 

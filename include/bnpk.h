@@ -629,7 +629,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
  *   d_part_offsets  2^part_bits + 1 offsets if d_keys is already grouped by its top part_bits bits (bnpk_kmers_partition), else
  *                   NULL / 0
  *   d_work          work_bytes bytes of device memory.  bnpk_count_sparse_workspace(n, key_bits, skip_bits, n_plan, part_bits, mode) says how many:
- *                   mode 2 = enough for ANY input (about 4 n words: heavy-hitter buckets are counted in a batch of their own, the
+ *                   mode 2 = enough for ANY input (about 5 n words: heavy-hitter buckets are counted in a batch of their own, the
  *                   library sort takes what nothing else does); mode 1 = the claiming level's slots (n_buckets * 7680 keys,
  *                   ~1.4 n words: what well-spread keys take, the fastest path); mode 0 = plain levels only (~n words).  The
  *                   call uses what it is given: the claiming level iff its slots fit, BNPK_ERR_NOMEM if the input needs a

@@ -22,14 +22,18 @@ def main():
     ops_mod.set_ops(OracleOps())
 
     n_reads, read_len, seed, genome = 300, 80, 7, 5000
-    text = synth.fastq_bytes(n_reads, read_len, seed, 1, genome, first_read=rank * n_reads)
     out = {}
-    for k in (4, 15, 31):
-        hist, stats = fastq_kmer_histogram(HArray(host=text), k)
-        if isinstance(hist, tuple):
-            out[k] = (hist[0].host().copy(), hist[1].host().copy())
-        else:
-            out[k] = hist.host().copy()
+    # what `bench.py --gpus N` runs on every rank (pipeline.fastq_kmer_histogram with the process group up: the probe, the plan
+    # it prices, the exchange, the per-range counting or the tree of merges) on both synthetic inputs of SURVEY §8d:
+    # S-uniform (mode 0: all k-mers distinct — plan "keys" territory) and S-genome (mode 1: every k-mer many times — "counts")
+    for mode in (0, 1):
+        text = synth.fastq_bytes(n_reads, read_len, seed, mode, genome, first_read=rank * n_reads)
+        for k in (4, 15, 31):
+            hist, stats = fastq_kmer_histogram(HArray(host=text), k)
+            if isinstance(hist, tuple):
+                out[(mode, k)] = (hist[0].host().copy(), hist[1].host().copy(), parallel.last["plan"])
+            else:
+                out[(mode, k)] = hist.host().copy()
     # both plans of the sparse merge, forced: raw hashes to their key range / local histograms cut at the range boundaries
     ops = ops_mod.get_ops()
     res = oracle.scan_one_line_buffer(text, oracle.FASTQ)
@@ -72,7 +76,9 @@ def main():
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:
-        all_text = synth.fastq_bytes(n_reads * world, read_len, seed, 1, genome, first_read=0)
+      plans_taken = set()
+      for mode in (0, 1):
+        all_text = synth.fastq_bytes(n_reads * world, read_len, seed, mode, genome, first_read=0)
         res = oracle.scan_one_line_buffer(all_text, oracle.FASTQ)
         codes = oracle.encode_dna(oracle.gather_rows(all_text, res.field_starts[:, 1], res.field_lens[:, 1]))
         for k in (4, 15, 31):
@@ -80,20 +86,24 @@ def main():
             if k <= 13:
                 expect = oracle.count_dense(h, k)
                 for r in range(world):
-                    assert np.array_equal(gathered[r][k], expect), "dense all-reduce mismatch"
+                    assert np.array_equal(gathered[r][(mode, k)], expect), "dense all-reduce mismatch"
             else:
                 ek, ec = oracle.count_sparse(h)
-                keys = np.concatenate([gathered[r][k][0] for r in range(world)])
-                counts = np.concatenate([gathered[r][k][1] for r in range(world)])
+                keys = np.concatenate([gathered[r][(mode, k)][0] for r in range(world)])
+                counts = np.concatenate([gathered[r][(mode, k)][1] for r in range(world)])
                 assert np.array_equal(keys, ek) and np.array_equal(counts, ec), "sparse key-range merge mismatch"
-                bounds = [g[k][0] for g in gathered]
+                bounds = [g[(mode, k)][0] for g in gathered]
                 for a, b in zip(bounds[:-1], bounds[1:]):
                     assert a.size == 0 or b.size == 0 or a[-1] < b[0], "rank ranges overlap"
-                if k == 31:
+                assert len({g[(mode, k)][2] for g in gathered}) == 1, "the ranks chose different plans"
+                plans_taken.add((mode, gathered[0][(mode, k)][2]))
+                if k == 31 and mode == 1:
                     for plan in ("keys", "counts", "keys/1", "keys/3"):
                         assert np.array_equal(np.concatenate([gathered[r][plan][0] for r in range(world)]), ek), plan
                         assert np.array_equal(np.concatenate([gathered[r][plan][1] for r in range(world)]), ec), plan
-        print("DIST_OK")
+      # the probe prices the plans from the data: all-distinct k-mers go as raw keys, a genome's repeated k-mers as counts
+      assert (0, "keys") in plans_taken and (1, "counts") in plans_taken, plans_taken
+      print("DIST_OK")
     dist.destroy_process_group()
 
 

@@ -226,8 +226,8 @@ def test_count_sparse_is_one_call(env, name, keys):
         assert status == 0, (name, status)
         assert np.array_equal(gk, ek) and np.array_equal(gc, ec), (name, claim, info)
         assert info[0] in (1, 2, 3) and (claim or info[0] != 1), info
-        if name in ("distinct", "uniform") and keys.size >= (1 << 20):
-            assert info[0] == (1 if claim else 2) and info[2] <= 3, info        # two or three host round trips
+        if name == "distinct":                                # (2 M keys in one level: the slabs' leftovers fill a small bag)
+            assert info[0] == (1 if claim else 2) and info[2] <= (6 if claim else 2), info
     assert lib.bnpk_set_option(dev.ctx, b"sparse_claim", 1) == 0
 
 
@@ -240,6 +240,7 @@ def test_count_sparse_argument_checks_and_small_workspaces(env):
         status, gk, gc, info = _count_sparse_raw(env, keys, mode)
         assert status == 0 and np.array_equal(gk, ek) and np.array_equal(gc, ec), (mode, info)
         assert info[0] == (2 if mode == 0 else 1), info
+        assert mode == 1 or info[2] == 2, info                # plain levels: the census and the number of distinct keys
     # one key three million times cannot be split by levels: the heavy bucket is counted on its own — with a workspace that
     # has no room for that the call says so instead of answering wrongly
     same = np.full(3_000_000, 12345, dtype=np.int64)
