@@ -747,13 +747,13 @@ def main():
         kernels[name] = {"ms_per_step": round(p["total_ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
                          "gbs": None if not b or avg_ms <= 0 else round(b / (avg_ms * 1e-3) / 1e9, 1)}
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the run, so they come from the committed
-    # rocprofv3 --pmc passes of this same command (scripts/profile_r03.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
+    # rocprofv3 --pmc passes of this same command (scripts/profile_r04.sh: FETCH_SIZE / WRITE_SIZE in separate passes,
     # FETCH x2 as MI355X_MICROARCH.md prescribes) — and only if that profile was taken from THIS build (hash of the kernel
     # sources) on this workload; otherwise null
     traffic, traffic_source = None, None
     try:
         from bionumpy_amd.csrc.build import _source_hash
-        for cand in (("r05_genome_pmc.json", "r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r05_pmc.json", "r05_k21_pmc.json", "r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
+        for cand in (("r06_genome_pmc.json", "r05_genome_pmc.json", "r04_genome_pmc.json", "r03_genome_pmc.json") if args.mode == "genome" else ("r06_pmc.json", "r06_k21_pmc.json", "r05_pmc.json", "r05_k21_pmc.json", "r04_pmc.json", "r03_pmc.json")) + ("r02_pmc.json", "r01_pmc.json"):
             path = os.path.join(ROOT, "profiles", cand)
             if not os.path.exists(path):
                 continue
@@ -823,6 +823,9 @@ def main():
         "per_rank": per_rank,
         "parity_fullsize": bool(parity and parity["ok"]),
         "parity": parity,
+        # what bnpk_count_sparse (ONE C-ABI call since round 6: csrc/sparse.hip) reported about the last step's histogram —
+        # path 1 = claiming level + strided finish, 2 = plain levels, 3 = library sort; host round trips inside the call
+        "planner": getattr(ops, "last_sparse_info", None),
     }
     # ---- the same workload fed from page-locked host memory (never `value`): H2D on its own stream, overlapped ----------
     out["host_fed"] = None

@@ -1223,8 +1223,14 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
   // million buckets (tickets three iterations ahead, parking rings, look-backs over thousands of status words) idle through
   // most of them: the sacCer3 index spent 3.6 of its 8.4 ms in one finish_multi call over 2048 buckets.
   const bool few = mode == 0 && n_buckets <= (int64_t)16 * ctx->compute_units;
-  bool use_general = mode == 1 || few, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
-  bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG && !few;
+  // More buckets than that but still a small histogram (up to 2^25 keys: the k-mers of sacCer3 after an extra level over the
+  // yeast genome's skewed 11-bit digits — 16 K buckets of ~740 keys): every kernel pays its per-bucket set-up on buckets a
+  // tenth of the size it was built for (round 6, scripts/exp/exp_index3.py: general 5.7 ms, fast + redo 5.9, workgroup table
+  // 3.8, multiplicities 3.9, the cascade 3.4); the cascade's one wavefront per bucket is the least bad, and the probe that
+  // would choose is a round trip saved.
+  const bool small = mode == 0 && !few && n <= (1ll << 25) && can_wave;
+  bool use_general = mode == 1 || few, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = (mode == 4 && can_wave) || small;
+  bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG && !few && !small;
   bool use_multi = mode == 5;
   bool nearly_distinct = false;
   // (one arena: the scan partials of the fast / duplicate-aware paths, or the parking ring of the multiplicity kernel —
@@ -1234,7 +1240,7 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
                             &scan_scratch, (hipStream_t)stream));
   {
     bnpk_timer t(ctx, "finish_sorted", s);
-    if (!few && (mode == 0 || try_fast || use_multi)) {
+    if (!few && !small && (mode == 0 || try_fast || use_multi)) {
       bnpk_timer t_probe(ctx, "finish.probe", s);
       BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
       hipLaunchKernelGGL(finish_fit_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 1024))), dim3(256), 0, s,

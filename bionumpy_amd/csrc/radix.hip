@@ -1308,10 +1308,13 @@ int bnpk_radix_partition_claimed(bnpk_ctx* ctx, const int64_t* d_keys, int64_t n
                                  int64_t* d_bag_fill, void* stream) {
   if (!ctx || n < 0 || n_seg < 1 || bits < 1 || bits > 10 || shift < 0 || shift + bits > 63 || !d_fill || !d_bag_fill || bag_cap < 0)
     return BNPK_ERR_ARG;
-  // the claims of a child bucket are counted in 32 bits (fill[2c], fill[2c+1]): 2^32 keys of ONE bucket would wrap the
-  // counter, later claims would land on slots that already hold keys and the bag would never see them — so the
-  // level refuses any input that could do that; such inputs take the two-pass level (64-bit offsets)
-  if (n >= (1ll << 32)) return BNPK_ERR_RANGE;
+  // The claims of a child bucket are counted in 32 bits (fill[2c], fill[2c+1]).  A counter can only wrap after 2^32 keys of
+  // ONE bucket were claimed — and all but the first 7680 of those went to the bag, whose fill is counted in 64 bits: with
+  // bag_cap <= n / 8 < 2^32 (n < 2^35) *d_bag_fill is over bag_cap long before, which every caller must treat as "keys were
+  // dropped, take bnpk_radix_partition" (ops / sparse.hip do).  So a wrapped counter never yields an accepted result, and the
+  // 6e9-key batch of the headline keeps this level (round 6 briefly refused n >= 2^32 here: 77 -> 83 ms).
+  if (n >= (1ll << 35)) return BNPK_ERR_RANGE;
+  if (bag_cap >= (1ll << 32)) return BNPK_ERR_ARG;
   if (n > 0 && (!d_keys || !d_buckets || (bag_cap > 0 && !d_bag))) return BNPK_ERR_ARG;
   if (n_seg > 1 && !d_seg_offsets) return BNPK_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;

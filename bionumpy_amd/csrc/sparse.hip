@@ -12,7 +12,7 @@
 //                       (plain level), the number of distinct keys (always) — two or three round trips per call.
 //   bnpk_index_build    KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47): the sorted distinct
 //                       (k-mer, row) pairs WITHOUT a key-value sort: distinct k-mers (one sparse count), every k-mer's rank
-//                       among them (a 2^16-entry prefix table narrows the binary search to a few cache lines), the distinct
+//                       among them (a prefix table of up to 2^22 entries narrows the binary search to a cache line or two), the distinct
 //                       values of rank * n_rows + row (a second sparse count), split back into (k-mer, row).
 #include <algorithm>
 #include <cmath>
@@ -282,7 +282,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   for (int level = 0; level < n_levels; ++level) {
     const int bits = plan[level];
     const int shift = kb - done - bits;
-    if (level == n_levels - 1 && may_claim && bits >= 1 && bits <= 10 && n >= CLAIM_MIN_KEYS && n < (1ll << 32) &&
+    if (level == n_levels - 1 && may_claim && bits >= 1 && bits <= 10 && n >= CLAIM_MIN_KEYS &&
         (n_seg << bits) * bnpk_claimed_stride() <= 3 * n && claimed_bytes(n, n_seg << bits) <= arena.left()) {
       const int r = count_claimed(ctx, cur, n, offsets, n_seg, shift, bits, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, depth);
       if (r != SP_TRY_PLAIN) return r;
@@ -370,17 +370,24 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
 }
 
 // ---- k-mer index ---------------------------------------------------------------------------------------------------------
-constexpr int PT_BITS = 16;                               // prefix table: first distinct key at or above every 16-bit prefix
+constexpr int PT_MAX_BITS = 22;                           // prefix table: first distinct key at or above every prefix of up to 22 bits
 
-// table[p] = lower_bound(keys, p << (key_bits - PT_BITS)) for p in [0, 2^PT_BITS]
-__global__ void prefix_table_kernel(const int64_t* __restrict__ keys, int64_t d, int key_bits, int64_t* __restrict__ table) {
+// as many prefix bits as leave ~8 distinct keys per prefix: the search behind the table stays inside one or two cache lines
+int prefix_bits(int64_t d, int key_bits) {
+  int b = 8;
+  while (b < PT_MAX_BITS && (d >> b) > 8) ++b;
+  return std::min(b, key_bits);
+}
+
+// table[p] = lower_bound(keys, p << (key_bits - pt_bits)) for p in [0, 2^pt_bits]
+__global__ void prefix_table_kernel(const int64_t* __restrict__ keys, int64_t d, int key_bits, int pt_bits, int64_t* __restrict__ table) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p > (1ll << PT_BITS)) return;
-  if (p == (1ll << PT_BITS)) {
+  if (p > (1ll << pt_bits)) return;
+  if (p == (1ll << pt_bits)) {
     table[p] = d;
     return;
   }
-  const int sh = key_bits > PT_BITS ? key_bits - PT_BITS : 0;
+  const int sh = key_bits - pt_bits;
   const int64_t q = p << sh;
   int64_t lo = 0, hi = d;
   while (lo < hi) {
@@ -393,13 +400,13 @@ __global__ void prefix_table_kernel(const int64_t* __restrict__ keys, int64_t d,
 // ids[i] = rank(kmer_i) * n_rows + row_i, the rank by a binary search inside the k-mer's prefix range (a few cache lines)
 __global__ __launch_bounds__(256) void rank_compose_kernel(const int64_t* __restrict__ kmers, const int64_t* __restrict__ rows,
                                                            int64_t n, const int64_t* __restrict__ keys,
-                                                           const int64_t* __restrict__ table, int key_bits, int64_t n_rows,
-                                                           int64_t* __restrict__ ids) {
-  const int sh = key_bits > PT_BITS ? key_bits - PT_BITS : 0;
+                                                           const int64_t* __restrict__ table, int key_bits, int pt_bits,
+                                                           int64_t n_rows, int64_t* __restrict__ ids) {
+  const int sh = key_bits - pt_bits;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int64_t q = kmers[i];
-    const int64_t p = key_bits > PT_BITS ? (q >> sh) : q;
+    const int64_t p = q >> sh;
     int64_t lo = table[p], hi = table[p + 1];
     while (lo < hi) {
       const int64_t mid = lo + ((hi - lo) >> 1);
@@ -422,13 +429,17 @@ int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int6
   for (int i = 0; i < n_levels; ++i) total_bits += plan[i];
   const int64_t n_b = 1ll << total_bits;
   // mode 0: the levels' ping-pong buffer (none if no level runs), every level's offsets, the finishing state, the census
+  // ... and room to count a few buckets that came out a little over the finishing capacity in a batch of their own (repeated
+  // k-mers make the bucket sizes of a genome's reads vary: at 60x coverage a handful of 2^20 buckets end up over 8192 keys)
+  const size_t heavy_room = std::min<size_t>((size_t)256 << 20, (size_t)n * 8 * 5);
   size_t bytes = (n_levels > 0 ? (size_t)n * 8 : 0) + (size_t)n_b * 8 * 2 + state_bytes(n_b) + (size_t)(2 + 3 * MAX_PRECOUNTED) * 8 * 4 +
-                 (1 << 20);
-  if (mode >= 1 && n_levels > 0 && plan[n_levels - 1] <= 10 && n >= CLAIM_MIN_KEYS && n < (1ll << 32) &&
+                 (1 << 20) + heavy_room;
+  if (mode >= 1 && n_levels > 0 && plan[n_levels - 1] <= 10 && n >= CLAIM_MIN_KEYS &&
       n_b * bnpk_claimed_stride() <= 3 * n)
     // mode 1: or the claiming level's slots — and, for inputs small enough that a slab's leftovers overflow the buckets' tails
     // into the bag as a matter of course (one level over a few million keys), room to merge the bag's counts in
-    bytes = std::max(bytes, claimed_bytes(n, n_b) + (size_t)n_b * 8 + (1 << 20) + (n <= (1ll << 26) ? (size_t)(n + n / 8 + (1 << 16)) * 16 : 0));
+    bytes = std::max(bytes, claimed_bytes(n, n_b) + (size_t)n_b * 8 + (1 << 20) + heavy_room +
+                                (n <= (1ll << 26) ? (size_t)(n + n / 8 + (1 << 16)) * 16 : 0));
   if (mode >= 2)
     // mode 2: any input — the ping-pong buffer whether planned or not, two more levels' offsets (2^8 times the buckets at most),
     // four arrays of n words for the heavy buckets' batch (the batch, the sort's other buffer, the counts, the runs' starts) or
@@ -468,7 +479,7 @@ int bnpk_count_sparse(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
 int64_t bnpk_index_build_workspace(int64_t n, int key_bits, int64_t n_rows) {
   if (n <= 0) return 256;
   // the k-mers' copy, its distinct keys + counts, the ids, the prefix table; the two counts share one workspace
-  return (int64_t)((size_t)n * 8 * 4 + (((size_t)1 << PT_BITS) + 2) * 8 + (1 << 16)) +
+  return (int64_t)((size_t)n * 8 * 4 + (((size_t)1 << PT_MAX_BITS) + 2) * 8 + (1 << 16)) +
          std::max(bnpk_count_sparse_workspace(n, key_bits, 0, 0, 0, 2), bnpk_count_sparse_workspace(n, 62, 0, 0, 0, 2));
 }
 
@@ -488,7 +499,7 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
   int64_t* distinct = arena.words(n);
   int64_t* counts = arena.words(n);
   int64_t* ids = arena.words(n);
-  int64_t* table = arena.words((1ll << PT_BITS) + 1);
+  int64_t* table = arena.words((1ll << PT_MAX_BITS) + 1);
   if (!work_keys || !distinct || !counts || !ids || !table) return SP_NOMEM(arena);
   const size_t mark = arena.used;
   // 1. the distinct k-mers (the input is the caller's: counted on a copy)
@@ -503,10 +514,11 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
   if (d > 0 && (d > ((1ll << 62) / n_rows))) return BNPK_ERR_RANGE;
   {
     bnpk_timer t(ctx, "index_rank_compose", s);
-    hipLaunchKernelGGL(prefix_table_kernel, dim3((unsigned)(((1 << PT_BITS) + 1 + 255) / 256)), dim3(256), 0, s,
-                       (const int64_t*)distinct, d, key_bits, table);
+    const int pt_bits = prefix_bits(d, key_bits);
+    hipLaunchKernelGGL(prefix_table_kernel, dim3((unsigned)(((1 << pt_bits) + 1 + 255) / 256)), dim3(256), 0, s,
+                       (const int64_t*)distinct, d, key_bits, pt_bits, table);
     hipLaunchKernelGGL(rank_compose_kernel, dim3(grid_for(std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx->compute_units * 32))),
-                       dim3(256), 0, s, d_kmers, d_rows, n, (const int64_t*)distinct, (const int64_t*)table, key_bits, n_rows, ids);
+                       dim3(256), 0, s, d_kmers, d_rows, n, (const int64_t*)distinct, (const int64_t*)table, key_bits, pt_bits, n_rows, ids);
     BNPK_HIP(ctx, hipGetLastError());
   }
   // 3. the distinct ids (ids is consumed; its distinct values go to work_keys, their multiplicities to counts)

@@ -643,7 +643,7 @@ int bnpk_count_sparse(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
                       int64_t* d_counts_out, int64_t* h_n_unique, int64_t* h_info5, void* stream);
 /* KmerIndex.create_index (bionumpy/sequence/indexing/kmer_indexing.py:24-47) as ONE call: the sorted distinct (k-mer, row)
  * pairs of n (k-mer, row) pairs, k-mers < 2^key_bits (key_bits <= 62), rows in [0, n_rows).  No key-value sort: the distinct
- * k-mers (bnpk_count_sparse), every k-mer's rank among them (a binary search narrowed by a 2^16-entry prefix table), the
+ * k-mers (bnpk_count_sparse), every k-mer's rank among them (a binary search narrowed by a prefix table to ~8 keys), the
  * distinct values of rank * n_rows + row (bnpk_count_sparse again: they order like the pairs), split back.  The inputs are
  * left alone.  d_keys_out / d_rows_out: n entries each; d_counts_out (optional, n entries): how often every pair occurred;
  * *h_n_pairs: the number of distinct pairs.  BNPK_ERR_RANGE if distinct k-mers * n_rows does not fit 62 bits. */

@@ -18,7 +18,7 @@ for pm in ("pmc1", "pmc2"):
             name = row["Kernel_Name"]
             if "kernel<true>" in name and ("fq_encode" in name or "fq_census" in name):
                 continue                                   # (the list-mode launches over the tiles handed back: empty)
-            for key in ("finish_multi", "finish_wave", "finish_dup", "finish_compact", "finish_fast", "finish_sorted", "rp_scatter", "rp_hist", "fq_encode_fast", "fq_census_fast", "fq_encode", "fq_census"):
+            for key in ("rp_ring", "finish_multi", "finish_wave", "finish_dup", "finish_compact", "finish_fast", "finish_sorted", "rp_scatter", "rp_hist", "fq_encode_fast", "fq_census_fast", "fq_encode", "fq_census"):
                 if key in name:
                     short = key + ("<kmer>" if ("kmer_source" in name or "rp_hist_kmer" in name) else "<mem>" if ("mem_source" in name or "rp_hist_mem" in name) else "")
                     agg[short][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -31,6 +31,8 @@ def _short(name):
             return key
     if "fq_encode_kernel<true>" in name or "fq_census_kernel<true>" in name:
         return name.split("_kernel")[0] + "<handed back>"
+    if "rp_ring_kernel" in name:
+        return "rp_ring<kmer_source>"
     if "rp_scatter_kernel" in name or "rp_hist_kernel" in name:
         kind = "rp_scatter" if "rp_scatter_kernel" in name else "rp_hist"
         src = "kmer_source" if "kmer_source" in name else "mem_source"
@@ -39,7 +41,7 @@ def _short(name):
     for key in ("rp_claimed_tails", "rp_claimed_sizes", "hist_bytes_small", "hist_bytes_rows", "hist_packed2"):
         if key in name:
             return key
-    for key in ("finish_multi_kernel", "bucket_census", "bucket_list", "window_cuts", "rebase_lines", "copy_plain", "copy_oneshot", "copy_unrolled"):
+    for key in ("prefix_table", "rank_compose", "finish_multi_kernel", "bucket_census", "bucket_list", "window_cuts", "rebase_lines", "copy_plain", "copy_oneshot", "copy_unrolled"):
         if key in name:
             return key.replace("_kernel", "")
     if "byte_positions_kernel<true>" in name or "byte_positions_kernelILb1" in name:
