@@ -35,7 +35,7 @@ int nomem_at(int line, size_t used, size_t size) {
 #define SP_NOMEM(arena) nomem_at(__LINE__, (arena).used, (arena).size)
 
 constexpr int64_t FINISH_TARGET = 6500;   // average bucket the plan aims for (the fast finishing kernels take 7680 keys; random keys: sigma = 80)
-constexpr int MAX_PRECOUNTED = 256;       // buckets over the finishing capacity that are counted one by one
+constexpr int MAX_PRECOUNTED = 1024;      // buckets over the finishing capacity that are counted in a batch of their own (round 5: 256, by the library sort)
 constexpr int64_t CLAIM_MIN_KEYS = 1ll << 20;
 
 struct arena_t {
@@ -77,9 +77,11 @@ struct sparse_info {
   int n_precounted = 0;  // heavy buckets counted one by one
 };
 
+// d_part_offsets / part_bits / n_seg_in: the keys come grouped in n_seg_in segments (0: 2^part_bits of them) inside each of
+// which the top part_bits bits (below the skipped ones) are the same
 int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
                       const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
-                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth);
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in = 0);
 
 // (sorted distinct keys, counts) by the library sort + run kernels: what heavy-hitter inputs take.  `work` is consumed.
 // keys_out NULL: the distinct keys go to the ping-pong buffer the sort left free, *keys_where says which, *sorted_where where
@@ -113,8 +115,13 @@ int count_by_sorting(bnpk_ctx* ctx, int64_t* work, int64_t n, int key_bits, aren
 // bucket) counted in ONE batch — gathered into one array, sorted and run-length-counted once (buckets differ in their top bits,
 // so the batch sorts bucket by bucket), the distinct keys cut back into buckets by a binary search of every bucket's first key
 // among the running key totals.
-int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& listed, int key_bits, arena_t& arena, int64_t** table_out,
-                     int64_t** big_keys, int64_t** big_counts, sparse_info& info, hipStream_t s) {
+// depth 0 (round 6): the batch is counted by the planner itself — its segments are the listed buckets, `done` bits of every
+// key are known inside each, one more level sized from the largest splits what mere skew made too large (the k-mers of a genome
+// whose top digits are unevenly filled: sacCer3) — and the library sort is left to what no level can split (one key a million
+// times), inside that call.
+int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& listed, int key_bits, int skip_bits, int done,
+                     arena_t& arena, int64_t** table_out, int64_t** big_keys, int64_t** big_counts, sparse_info& info, hipStream_t s,
+                     int depth) {
   const int nb = (int)(listed.size() / 3);
   std::vector<int64_t> order(nb);
   for (int i = 0; i < nb; ++i) order[i] = i;
@@ -129,26 +136,44 @@ int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& l
     total += row[2];
     byte_off[i + 1] = total * 8;
   }
-  // three arrays of the batch's size: the batch, the sort's ping-pong buffer, the counts — the distinct keys go to whichever of
-  // the first two the sort leaves free, the running totals over the sorted keys once the runs are taken
+  // the batch, its distinct keys and their counts; the running totals go over the batch once it is counted
+  int64_t largest = 0;
+  std::vector<int64_t> word_off(nb + 1);
+  for (int i = 0; i <= nb; ++i) word_off[i] = byte_off[i] / 8;
+  for (int i = 0; i < nb; ++i) largest = std::max(largest, word_off[i + 1] - word_off[i]);
+  const bool recurse = depth == 0;
   int64_t* batch = arena.words(total + 1);
-  int64_t* batch_alt = arena.words(total + 1);
+  int64_t* batch_alt = recurse ? nullptr : arena.words(total + 1);
+  int64_t* k = recurse ? arena.words(total) : nullptr;
   int64_t* c = arena.words(total);
   int64_t* d_lo = arena.words(nb);
   int64_t* d_off = arena.words(nb + 1);
+  int64_t* d_woff = arena.words(nb + 1);
   int64_t* d_prefix = arena.words(nb);
   int64_t* d_starts = arena.words(nb);
   int64_t* table = arena.words(3 * (int64_t)nb);
-  if (!batch || !batch_alt || !c || !d_lo || !d_off || !d_prefix || !d_starts || !table) return SP_NOMEM(arena);
+  if (!batch || (!recurse && !batch_alt) || (recurse && !k) || !c || !d_lo || !d_off || !d_woff || !d_prefix || !d_starts || !table)
+    return SP_NOMEM(arena);
   BNPK_HIP(ctx, hipMemcpyAsync(d_lo, lo8.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_off, byte_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
+  BNPK_HIP(ctx, hipMemcpyAsync(d_woff, word_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_prefix, prefix.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipStreamSynchronize(s));                // (the host vectors go out of scope; pageable copies are staged anyway)
   BNPK_CHECK(bnpk_gather_rows(ctx, reinterpret_cast<const uint8_t*>(keys), d_lo, d_off, nb, total * 8, 0,
                               reinterpret_cast<uint8_t*>(batch), s));
   int64_t d = 0;
-  int64_t *k = nullptr, *cum = nullptr;
-  BNPK_CHECK(count_by_sorting(ctx, batch, total, key_bits, arena, nullptr, c, &d, info, s, batch_alt, &k, &cum));
+  int64_t* cum = nullptr;
+  if (recurse) {
+    // (planned as if every one of the 2^done possible segments were as large as the largest listed one)
+    const int64_t n_plan = done < 40 ? std::min<int64_t>(largest << done, 1ll << 61) : 1ll << 61;
+    sparse_info inner;
+    BNPK_CHECK(count_sparse_impl(ctx, batch, total, key_bits, skip_bits, n_plan, d_woff, done, arena, k, c, &d, inner, s, depth + 1, nb));
+    info.syncs += inner.syncs;
+    info.levels += inner.levels;
+    cum = batch;                                         // (consumed by the call: free now)
+  } else {
+    BNPK_CHECK(count_by_sorting(ctx, batch, total, key_bits, arena, nullptr, c, &d, info, s, batch_alt, &k, &cum));
+  }
   BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, c, d, cum, s));
   BNPK_CHECK(bnpk_search_sorted(ctx, cum, d + 1, d_prefix, nb, 0, d_starts, s));
   std::vector<int64_t> starts(nb);
@@ -262,7 +287,7 @@ int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets
 
 int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
                       const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
-                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth) {
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in) {
   if (n == 0) {
     *h_n_unique = 0;
     return BNPK_OK;
@@ -270,12 +295,12 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   if (depth > 3) return BNPK_ERR_RANGE;
   int64_t* cur = d_keys;
   int64_t* spare = nullptr;                              // a free n-word buffer: what the previous level read
-  if (key_bits > 62)                                     // (no room for the phantom bit: the library sort)
+  if (key_bits > 63)                                     // (no room for the phantom bit: the library sort)
     return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s);
   const int kb = key_bits - skip_bits;
   const int64_t* offsets = d_part_offsets;
   int done = part_bits;
-  int64_t n_seg = 1ll << done;
+  int64_t n_seg = n_seg_in > 0 ? n_seg_in : 1ll << done;
   int plan[8];
   const int n_levels = radix_plan(n_plan > 0 ? n_plan : n, kb, done, plan);
   const bool may_claim = ctx->sparse_claim != 0;
@@ -327,9 +352,9 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     }
     int bits = std::max(1, (int)std::ceil(std::log2((double)largest / (0.7 * (double)cap))));
     bits = std::min(std::min(11, kb - done), bits);
-    if (n_over <= MAX_PRECOUNTED) {
+    if (n_over <= MAX_PRECOUNTED && depth == 0) {         // (a batch that is itself being pre-counted: levels, then the sort)
       std::vector<int64_t> listed(got.begin() + 2, got.begin() + 2 + 3 * n_over);
-      BNPK_CHECK(precount_buckets(ctx, cur, listed, key_bits, arena, &table, &big_keys, &big_counts, info, s));
+      BNPK_CHECK(precount_buckets(ctx, cur, listed, key_bits, skip_bits, done, arena, &table, &big_keys, &big_counts, info, s, depth));
       n_big = (int)n_over;
       fits = true;
       break;
@@ -366,7 +391,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     }
     // a wait between workgroups gave up (a run-time condition): the partitioned keys are intact, the sort gives the answer
   }
-  return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s);
+  return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, spare);
 }
 
 // ---- k-mer index ---------------------------------------------------------------------------------------------------------
@@ -442,9 +467,9 @@ int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int6
                                 (n <= (1ll << 26) ? (size_t)(n + n / 8 + (1 << 16)) * 16 : 0));
   if (mode >= 2)
     // mode 2: any input — the ping-pong buffer whether planned or not, two more levels' offsets (2^8 times the buckets at most),
-    // four arrays of n words for the heavy buckets' batch (the batch, the sort's other buffer, the counts, the runs' starts) or
-    // the library sort
-    bytes = std::max(bytes, (size_t)n * 8 * 5 + (size_t)std::min<int64_t>(n_b << 8, 2 * n + 2) * 8 * 2 + state_bytes(std::min<int64_t>(n_b << 8, n + 1)) +
+    // five arrays of n words for the heavy buckets' batch (the batch, its distinct keys and counts, the inner call's ping-pong
+    // buffer, the runs' starts of the library sort)
+    bytes = std::max(bytes, (size_t)n * 8 * 6 + (size_t)std::min<int64_t>(n_b << 8, 2 * n + 2) * 8 * 2 + state_bytes(std::min<int64_t>(n_b << 8, n + 1)) +
                                 ((size_t)bnpk_run_tiles(n) + 2) * 8 * 2 + (1 << 20));
   return (int64_t)bytes;
 }

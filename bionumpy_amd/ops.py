@@ -775,7 +775,7 @@ class HipOps:
             keys_out, counts = out_keys[pos:pos + n], out_counts[pos:pos + n]
         else:
             keys_out, counts = self._empty(n, np.int64), self._empty(n, np.int64)
-        # the workspace: enough for any input where the device has it to spare (heavy-hitter buckets, the library sort: ~5 n
+        # the workspace: enough for any input where the device has it to spare (heavy-hitter buckets, the library sort: ~6 n
         # words), else what the claiming level takes (~1.4 n: the 31-mer batch that fills the HBM), else the plain levels'
         tm = torch_mod()
         free, _ = tm.cuda.mem_get_info(self.device.tdev)

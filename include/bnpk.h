@@ -621,7 +621,7 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
  * receive the sorted distinct keys and their counts, *h_n_unique how many.  Replaces the k > 13 branch the reference does not
  * have (bionumpy/sequence/count_encoded.py:150-188 counts k <= 8 densely; SURVEY §3.5 defines the rest as np.unique) and the
  * planner that lived in Python through round 5: levels planned for buckets of ~6500 keys, the last one as the claiming level
- * where the workspace has room for its slots, one census of the real bucket sizes, up to two more levels or up to 256 heavy
+ * where the workspace has room for its slots, one census of the real bucket sizes, up to two more levels or up to 1024 heavy
  * buckets counted on their own, the finishing kernels; the library sort only for what none of that takes.
  *   d_keys          CONSUMED (workspace afterwards)
  *   skip_bits       leading bits of the key_bits that all keys share (the key range a rank owns after the exchange), else 0
@@ -629,13 +629,13 @@ int bnpk_finish_sorted(bnpk_ctx* ctx, int64_t* d_part, int64_t n, const int64_t*
  *   d_part_offsets  2^part_bits + 1 offsets if d_keys is already grouped by its top part_bits bits (bnpk_kmers_partition), else
  *                   NULL / 0
  *   d_work          work_bytes bytes of device memory.  bnpk_count_sparse_workspace(n, key_bits, skip_bits, n_plan, part_bits, mode) says how many:
- *                   mode 2 = enough for ANY input (about 5 n words: heavy-hitter buckets are counted in a batch of their own, the
+ *                   mode 2 = enough for ANY input (about 6 n words: heavy-hitter buckets are counted in a batch of their own, the
  *                   library sort takes what nothing else does); mode 1 = the claiming level's slots (n_buckets * 7680 keys,
  *                   ~1.4 n words: what well-spread keys take, the fastest path); mode 0 = plain levels only (~n words).  The
  *                   call uses what it is given: the claiming level iff its slots fit, BNPK_ERR_NOMEM if the input needs a
  *                   path the workspace has no room for (d_keys is lost then)
  *   h_info5         optional: {path (1 claiming level, 2 plain levels, 3 library sort), levels run, host round trips, keys in
- *                   the bag, heavy buckets counted one by one}
+ *                   the bag, heavy buckets counted in a batch of their own}
  * Synchronous (the number of distinct keys is an answer). */
 int64_t bnpk_count_sparse_workspace(int64_t n, int key_bits, int skip_bits, int64_t n_plan, int part_bits, int mode);
 int bnpk_count_sparse(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,

@@ -703,10 +703,11 @@ def test_radix_partition_small_segments(ops, seed, n, first_bits, bits):
     assert np.array_equal(co, np.searchsorted(top, np.arange(n_seg * (1 << bits) + 1)))
 
 
-@pytest.mark.parametrize("n_hot,copies", [(3, 50_000), (300, 9000)])
+@pytest.mark.parametrize("n_hot,copies", [(3, 50_000), (300, 9000), (1200, 9000)])
 def test_heavy_hitter_buckets(ops, n_hot, copies):
-    """a few buckets over the finishing kernel's capacity are counted beforehand and spliced in by the kernel;
-    more than ops.MAX_PRECOUNTED of them take the sort + run fallback — np.unique's answer either way"""
+    """buckets over the finishing kernel's capacity are counted beforehand (a batch of their own: one more level by the planner
+    itself, the library sort for keys no level can split) and spliced in by the kernel; more than 1024 of them (sparse.hip:
+    MAX_PRECOUNTED) take extra levels over everything and, failing that, the sort + run fallback — np.unique's answer either way"""
     rng = np.random.default_rng(n_hot)
     base = rng.integers(0, 1 << 62, size=400_000).astype(np.int64)
     hot = np.repeat(rng.integers(0, 1 << 62, size=n_hot).astype(np.int64), copies)
