@@ -116,7 +116,7 @@ def cpu_baseline(host_text, k, budget_s=20.0):
                       % (res.n_records, int(lens[0]) if len(lens) else 0, dt)}
 
 
-def _index_roofline(kernels_ms, n_pairs, n_distinct, build_ms):
+def _index_roofline(kernels_ms, n_pairs, n_distinct, build_ms, note=None):
     """config 5 against the HBM peak.  bnpk_index_build (round 6: no library sort on its path) is two sparse counts around a rank
     kernel — a dozen small launches, so the figure that means something is the WHOLE build: algorithmic bytes = every (k-mer, row)
     pair read once (16 B) and every distinct pair written once (16 B), over the build's wall time; the dominant kernel is named
@@ -130,9 +130,9 @@ def _index_roofline(kernels_ms, n_pairs, n_distinct, build_ms):
     return {"bound": "hbm", "kernel": dom, "avg_launch_ms": kernels_ms[dom], "algorithmic_bytes_per_build": bytes_,
             "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-            "note": "whole build (%d launches of small kernels): the yeast genome's 31-mers fill their top digits unevenly (413 of 2048 "
-                    "buckets over the finishing capacity) and share long prefixes inside a bucket; see synthetic_1e9_pairs for the "
-                    "same call at a size where the kernels set the time" % len(kernels_ms)}
+            "note": note or ("whole build (%d timed launches): the yeast genome's 31-mers fill their top digits unevenly (413 of 2048 "
+                             "buckets over the finishing capacity) and share long prefixes inside a bucket; see synthetic_1e9_pairs "
+                             "for the same call at a size where the kernels set the time" % len(kernels_ms))}
 
 
 def host_fed_leg(args, text, expected_sums):
@@ -450,8 +450,8 @@ def extras(args, ops, dev, main_stats, copy_rate):
             n_big, rows_big = 1_000_000_000, 100
             g = torch.Generator(device="cuda"); g.manual_seed(11)
             big_k = torch.randint(0, 1 << 62, (n_big,), dtype=torch.int64, device="cuda", generator=g)
-            third = big_k[::3].numel()
-            big_k[::3] = big_k[1::3][:third] if big_k[1::3].numel() >= third else big_k[::3]     # a third of the k-mers occur twice
+            m3 = n_big // 3
+            big_k[0:3 * m3:3] = big_k[1:3 * m3:3].clone()       # a third of the k-mers occur twice (next to each other: mostly in one row)
             big_r = (torch.arange(n_big, dtype=torch.int64, device="cuda") * rows_big) // n_big
             r = ops.unique_pairs(HArray(dev=big_k), HArray(dev=big_r), key_bits=62, n_values=rows_big); del r
             torch.cuda.synchronize()
@@ -474,7 +474,10 @@ def extras(args, ops, dev, main_stats, copy_rate):
             out["config5_kmer_index"]["synthetic_1e9_pairs"] = {
                 "workload": "%d random 31-mers (a third of them twice) in %d rows: bnpk_index_build" % (n_big, rows_big),
                 "build_ms": round(big_ms, 1), "distinct_pairs": int(kd.numel()), "kernels_ms": kernels_big,
-                "roofline": _index_roofline(kernels_big, n_big, int(kd.numel()), big_ms),
+                "roofline": _index_roofline(kernels_big, n_big, int(kd.numel()), big_ms,
+                                            "whole build; the rank of every k-mer among the distinct ones is a binary search at a random "
+                                            "place of an 8 GB array (a prefix table narrows it to ~240 keys): ~4 cache lines per k-mer, "
+                                            "which is what bounds this size — a partition that carries the row along would not need it"),
                 "parity": bool(inc and found and sub[0].size == want),
                 "parity_detail": "(k-mer, row) strictly increasing; 2 M sampled input k-mers found; the first 50 M pairs: as many distinct as torch.unique"}
             del big_k, big_r, pk, pr, kd, rd, sub, part_k, part_r
