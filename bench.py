@@ -117,8 +117,8 @@ def cpu_baseline(host_text, k, budget_s=20.0):
 
 
 def _index_roofline(kernels_ms, n_pairs, n_distinct, build_ms, note=None):
-    """config 5 against the HBM peak.  bnpk_index_build (round 6: no library sort on its path) is two sparse counts around a rank
-    kernel — a dozen small launches, so the figure that means something is the WHOLE build: algorithmic bytes = every (k-mer, row)
+    """config 5 against the HBM peak.  bnpk_index_build (round 6: no library sort on its path) is one partition of (k-mer, row) words
+    and a sparse count of them — a dozen small launches at sacCer3's size, so the figure that means something is the WHOLE build: algorithmic bytes = every (k-mer, row)
     pair read once (16 B) and every distinct pair written once (16 B), over the build's wall time; the dominant kernel is named
     with its own time (the group timer "finish_sorted" spans the finishing kernels and is not one of them)"""
     if not kernels_ms:
@@ -130,9 +130,10 @@ def _index_roofline(kernels_ms, n_pairs, n_distinct, build_ms, note=None):
     return {"bound": "hbm", "kernel": dom, "avg_launch_ms": kernels_ms[dom], "algorithmic_bytes_per_build": bytes_,
             "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-            "note": note or ("whole build (%d timed launches): the yeast genome's 31-mers fill their top digits unevenly (413 of 2048 "
-                             "buckets over the finishing capacity) and share long prefixes inside a bucket; see synthetic_1e9_pairs "
-                             "for the same call at a size where the kernels set the time" % len(kernels_ms))}
+            "note": note or ("whole build (%d timed launches): one partition of (k-mer, row) words; the yeast genome's 31-mers fill their "
+                             "top digits unevenly (buckets 7x the average) and share long prefixes inside a bucket, which is where the "
+                             "finishing kernels' time goes; see synthetic_1e9_pairs for the same call at a size where the kernels set "
+                             "the time" % len(kernels_ms))}
 
 
 def host_fed_leg(args, text, expected_sums):
@@ -475,9 +476,9 @@ def extras(args, ops, dev, main_stats, copy_rate):
                 "workload": "%d random 31-mers (a third of them twice) in %d rows: bnpk_index_build" % (n_big, rows_big),
                 "build_ms": round(big_ms, 1), "distinct_pairs": int(kd.numel()), "kernels_ms": kernels_big,
                 "roofline": _index_roofline(kernels_big, n_big, int(kd.numel()), big_ms,
-                                            "whole build; the rank of every k-mer among the distinct ones is a binary search at a random "
-                                            "place of an 8 GB array (a prefix table narrows it to ~240 keys): ~4 cache lines per k-mer, "
-                                            "which is what bounds this size — a partition that carries the row along would not need it"),
+                                            "whole build: one partition of (k-mer, row) words (first level by the fixed-line scatter, the "
+                                            "claiming level, a finishing kernel, the decode of the k-mers' top bits); the same pairs by "
+                                            "ranks (option index_pairs 0) take 213 ms, 153 of them random look-ups"),
                 "parity": bool(inc and found and sub[0].size == want),
                 "parity_detail": "(k-mer, row) strictly increasing; 2 M sampled input k-mers found; the first 50 M pairs: as many distinct as torch.unique"}
             del big_k, big_r, pk, pr, kd, rd, sub, part_k, part_r

@@ -127,6 +127,11 @@ int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value) {
     ctx->fastq_encoder = (int)value;
     return BNPK_OK;
   }
+  if (!strcmp(name, "index_pairs")) {
+    if (value < 0 || value > 1) return BNPK_ERR_ARG;
+    ctx->index_pairs = (int)value;
+    return BNPK_OK;
+  }
   if (!strcmp(name, "sparse_claim")) {
     if (value < 0 || value > 1) return BNPK_ERR_ARG;
     ctx->sparse_claim = (int)value;

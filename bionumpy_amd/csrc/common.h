@@ -53,6 +53,7 @@ struct bnpk_ctx {
   int finish_multi_grid = 0;
   void* mailbox = nullptr;       // page-locked words the host scalars of a call come back through (bnpk_fetch_i64)
   int fastq_encoder = 1;         // fastq.hip: 1 = fast tile encoder + the general one for the tiles it hands back, 0 = general only
+  int index_pairs = 1;           // sparse.hip: bnpk_index_build as one partition of (k-mer, row) words where the rows fit (0: always by ranks)
   int sparse_claim = 1;          // sparse.hip: may bnpk_count_sparse run its last level as the claiming level (0: never — tests, experiments)
   int l1_ring = 0;               // radix.hip: the fused first level's scatter — 0 = rp_scatter_kernel, 1 = rp_ring_kernel (one fixed line per bucket: round 6, measured slower)
 };

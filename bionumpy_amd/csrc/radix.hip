@@ -262,6 +262,66 @@ struct kmer_source {
   }
 };
 
+// (k-mer, row) pairs for the k-mer index (round 6): the first level of a partition that carries a payload.  The pair's sort key
+// is 2k + row bits wide — more than a word — but inside one bucket of the first level the top `bits` bits of the k-mer are the
+// same for every key, so what is WRITTEN is  word = (k-mer's remaining bits : row : tag)  — a complete sort key of its bucket in
+// at most 63 bits — while the DIGIT that ranks it comes from the k-mer itself.  Only rp_ring_kernel can do that: its flush
+// never looks at a key's digit again (rp_scatter_kernel re-derives the bucket from the staged key).  tag = parity of the bucket's
+// rank among the non-empty buckets: the bit flips at every bucket boundary of the (compacted, de-duplicated) output, which is how
+// the k-mer's top bits are put back afterwards (sparse.hip).
+struct pair_source {
+  static constexpr int ITEMS = 8;
+  const uint64_t* __restrict__ keys;       // k-mers, < 2^key_bits
+  const int64_t* __restrict__ rows;        // their rows, < 2^row_bits
+  const unsigned* __restrict__ tags;       // one bit per first-level bucket (written between the histogram and the scatter)
+  int dshift;                              // k-mer >> dshift = first-level digit
+  int row_bits;
+  struct raw_t { uint64_t v[ITEMS]; unsigned r[ITEMS]; };
+  template <bool STREAM = false>
+  __device__ __forceinline__ void issue(int64_t t0, int64_t hi, raw_t& raw) const {
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
+      if (i < hi) {
+        raw.v[q] = keys[i];
+        raw.r[q] = (unsigned)rows[i];
+      }
+    }
+  }
+  __device__ __forceinline__ static void landed(const raw_t&) {}
+  __device__ __forceinline__ unsigned digits(int64_t t0, int64_t hi, const raw_t& raw, int, unsigned mask, unsigned d[ITEMS]) const {
+    unsigned vm = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
+      d[q] = (threadIdx.x + q) & mask;                        // (the caller adds zeros for positions past the end: spread them)
+      if (i < hi) { d[q] = (unsigned)(raw.v[q] >> dshift) & mask; vm |= 1u << q; }
+    }
+    return vm;
+  }
+  // words and digits of a tile; lds_tags: the tag bits, staged in LDS by the kernel
+  __device__ __forceinline__ unsigned finish_split(int64_t t0, int64_t hi, int items, const raw_t& raw, uint64_t k[ITEMS],
+                                                   unsigned dg[ITEMS], const unsigned* lds_tags) const {
+    const uint64_t low_mask = (1ull << dshift) - 1ull;
+    unsigned vm = 0;
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+      const int64_t i = t0 + threadIdx.x + (int64_t)q * RP_THREADS;
+      dg[q] = 0;
+      if (q < items && i < hi) {
+        const unsigned d = (unsigned)(raw.v[q] >> dshift);
+        const unsigned tag = (lds_tags[d >> 5] >> (d & 31u)) & 1u;
+        k[q] = (((((raw.v[q] & low_mask) << row_bits) | (uint64_t)raw.r[q]) << 1) | tag);
+        dg[q] = d;
+        vm |= 1u << q;
+      }
+    }
+    return vm;
+  }
+};
+template <typename S> struct split_digit : std::false_type {};
+template <> struct split_digit<pair_source> : std::true_type {};
+
 // ---- pass 1 of a level: digit counts per slab ------------------------------------------------------------------
 template <typename Source>
 __global__ __launch_bounds__(RP_THREADS) void rp_hist_kernel(Source src, const int64_t* __restrict__ seg_off,
@@ -810,7 +870,8 @@ struct rr_cfg {
   static constexpr size_t OFF_CNT = (size_t)MAXB * 16 * 8;
   static constexpr size_t OFF_LINE = OFF_CNT + (size_t)MAXB * 4;
   static constexpr size_t OFF_MISC = OFF_LINE + (size_t)MAXB * 4;
-  static constexpr size_t LDS = OFF_MISC + 8 * 8 + 16;
+  static constexpr size_t OFF_TAGS = OFF_MISC + 8 * 8 + 16;    // pair_source: one bit per bucket
+  static constexpr size_t LDS = OFF_TAGS + MAXB / 8;
 };
 
 template <typename Source>
@@ -824,11 +885,15 @@ __global__ __launch_bounds__(RP_THREADS) void rp_ring_kernel(Source src, const i
   unsigned* line_tab = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_LINE);
   int64_t* sh = reinterpret_cast<int64_t*>(smem + rr_cfg::OFF_MISC);
   unsigned* flags = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_MISC + 64);
+  unsigned* tagl = reinterpret_cast<unsigned*>(smem + rr_cfg::OFF_TAGS);
   const int B = 1 << bits;
   const int tid = threadIdx.x;
   slab_t sl;
   if (!find_slab(seg_off, seg_slabs, n_seg, slab_keys, B, sh, sl)) return;
   if (sl.lo >= sl.hi) return;
+  if constexpr (split_digit<Source>::value) {
+    if (tid < rr_cfg::MAXB / 32) tagl[tid] = tid < (B + 31) / 32 ? src.tags[tid] : 0u;
+  }
   for (int i = tid; i < B * 16; i += RP_THREADS) ring[i] = RP_PHANTOM;
   for (int d = tid; d < B; d += RP_THREADS) {
     const int64_t c0 = offs[sl.hbase + (int64_t)d * sl.nsl + sl.local];
@@ -915,20 +980,31 @@ __global__ __launch_bounds__(RP_THREADS) void rp_ring_kernel(Source src, const i
     }
     return still;
   };
+  unsigned dg[IT] = {};                                        // the keys' digits (a pair's digit is not part of the word it writes)
+  auto make_keys = [&]() -> unsigned {
+    if constexpr (split_digit<Source>::value) {
+      return src.finish_split(t0, sl.hi, IT, raw, k, dg, tagl);
+    } else {
+      const unsigned m = src.finish(t0, sl.hi, IT, raw, k);
+#pragma unroll
+      for (int q = 0; q < IT; ++q) dg[q] = digit(k[q]);
+      return m;
+    }
+  };
   Source::landed(raw);
-  unsigned vm = src.finish(t0, sl.hi, IT, raw, k);
+  unsigned vm = make_keys();
   if (t0 + TILE < sl.hi) src.template issue<true>(t0 + TILE, sl.hi, raw);
   while (true) {
     // the previous round's late keys: their bucket's line left at the end of that round
     write_late();
     // ranks, branch-free and back to back (a position where no k-mer starts adds zero to some bucket)
 #pragma unroll
-    for (int q = 0; q < IT; ++q) ad[q] = atomicAdd(&cnt[digit(k[q])], (vm >> q) & 1u);
+    for (int q = 0; q < IT; ++q) ad[q] = atomicAdd(&cnt[dg[q]], (vm >> q) & 1u);
     unsigned ndm = 0, slow = 0;
 #pragma unroll
     for (int q = 0; q < IT; ++q) {
       const unsigned rel = ad[q];
-      const unsigned slot = digit(k[q]) * 16u + (rel & 15u);
+      const unsigned slot = dg[q] * 16u + (rel & 15u);
       const bool valid = (vm >> q) & 1u;
       if (!(RR_ABL & 4) && valid && rel < 16u) ring[slot] = k[q];
       ad[q] = slot | ((rel >> 4) << 16);
@@ -943,7 +1019,7 @@ __global__ __launch_bounds__(RP_THREADS) void rp_ring_kernel(Source src, const i
     if (!last) {                                               // the next tile's k-mers, the loads of the tile after next
       t0 += TILE;
       Source::landed(raw);
-      vm = src.finish(t0, sl.hi, IT, raw, k);
+      vm = make_keys();
       if (t0 + TILE < sl.hi) src.template issue<true>(t0 + TILE, sl.hi, raw);
     }
     flush_lines();
@@ -1253,7 +1329,73 @@ __global__ __launch_bounds__(RS_THREADS) void rp_split_small_kernel(const uint64
 }
 
 
+// tags of the pair level: bucket b's bit = parity of the number of non-empty buckets before it; list[j] = the j-th non-empty
+// bucket, list_n[0] = how many there are.  One workgroup (B <= 1024 buckets).
+__global__ __launch_bounds__(RP_THREADS) void rp_pair_tags_kernel(const int64_t* __restrict__ child_off, int B, unsigned* __restrict__ tags,
+                                                                  int64_t* __restrict__ list, int64_t* __restrict__ list_n) {
+  __shared__ unsigned wsum[RP_THREADS / 64];
+  __shared__ unsigned bits[rr_cfg::MAXB / 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < rr_cfg::MAXB / 32) bits[tid] = 0;
+  const unsigned full = tid < B && child_off[tid + 1] > child_off[tid] ? 1u : 0u;
+  const unsigned inc = wave_inclusive_scan(full);
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned before = inc - full;
+  for (int w = 0; w < wave; ++w) before += wsum[w];
+  if (tid < B && (before & 1u)) atomicOr(&bits[tid >> 5], 1u << (tid & 31));
+  if (full) list[before] = tid;
+  if (tid == RP_THREADS - 1) list_n[0] = before + full;
+  __syncthreads();
+  if (tid < rr_cfg::MAXB / 32) tags[tid] = bits[tid];
+}
+
 }  // namespace
+
+// (internal, used by sparse.hip) the first level of the k-mer index's partition: n (k-mer, row) pairs -> n words
+// ((k-mer's low key_bits - bits bits : row : tag), see pair_source) grouped by the k-mer's top `bits` bits; d_child_off
+// (2^bits + 1), d_list (2^bits: the non-empty buckets in order), d_list_n (1).  bits <= 10; key_bits - bits + row_bits + 1 <= 63.
+int bnpk_pairs_partition_launch(bnpk_ctx* ctx, const int64_t* d_keys, const int64_t* d_rows, int64_t n, int key_bits, int bits,
+                                int row_bits, int64_t* d_words, int64_t* d_child_off, unsigned* d_tags, int64_t* d_list,
+                                int64_t* d_list_n, hipStream_t s) {
+  if (bits < 1 || bits > 10 || key_bits - bits + row_bits + 1 > 63 || key_bits <= bits) return BNPK_ERR_ARG;
+  void* scratch_v = nullptr;
+  BNPK_CHECK(bnpk_scratch(ctx, rp_level_scratch(n, 1, bits), &scratch_v, s));
+  char* scratch = (char*)scratch_v;
+  const int B = 1 << bits;
+  const int64_t slab_keys = rp_slab_keys(n);
+  const int64_t bound = n / slab_keys + 2;
+  if (bound > BNPK_MAX_BLOCKS / (RP_THREADS / 256)) return BNPK_ERR_RANGE;
+  const int64_t hn = bound << bits;
+  int64_t* own_seg = reinterpret_cast<int64_t*>(scratch);
+  int64_t* seg_slabs = reinterpret_cast<int64_t*>(scratch + align64(16));
+  int64_t* H = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(seg_slabs) + align64((size_t)2 * 8));
+  int64_t* scan_scratch = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(H) + align64((size_t)(hn + 1) * 8));
+  pair_source src{reinterpret_cast<const uint64_t*>(d_keys), d_rows, d_tags, key_bits - bits, row_bits};
+  auto kernel = rp_ring_kernel<pair_source>;
+  if (!ctx->launch_attr_set[7]) {
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rr_cfg::LDS));
+    ctx->launch_attr_set[7] = true;
+  }
+  hipLaunchKernelGGL(rp_single_segment_kernel, dim3(1), dim3(1), 0, s, n, own_seg);
+  {
+    bnpk_timer t(ctx, "pairs_partition_hist", s);
+    hipLaunchKernelGGL(rp_slab_table_kernel, dim3(1), dim3(RP_THREADS), 0, s, (const int64_t*)own_seg, (int64_t)1, slab_keys, seg_slabs);
+    BNPK_HIP(ctx, hipMemsetAsync(H, 0, (size_t)(hn + 1) * 8, s));
+    hipLaunchKernelGGL((rp_hist_kernel<pair_source>), dim3((unsigned)bound), dim3(RP_THREADS), RP_HIST_LDS, s, src, (const int64_t*)own_seg,
+                       (const int64_t*)seg_slabs, (int64_t)1, slab_keys, key_bits - bits, bits, H);
+    BNPK_HIP(ctx, hipGetLastError());
+    BNPK_CHECK(bnpk_scan_launch(ctx, H, hn, 1, H, true, scan_scratch, s));
+    hipLaunchKernelGGL(rp_child_offsets_kernel, dim3(grid_for(ceil_div(B, 256))), dim3(256), 0, s, (const int64_t*)H,
+                       (const int64_t*)seg_slabs, (int64_t)1, B, hn, d_child_off);
+    hipLaunchKernelGGL(rp_pair_tags_kernel, dim3(1), dim3(RP_THREADS), 0, s, (const int64_t*)d_child_off, B, d_tags, d_list, d_list_n);
+  }
+  bnpk_timer t(ctx, "pairs_partition_scatter", s);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)bound), dim3(RP_THREADS), rr_cfg::LDS, s, src, (const int64_t*)own_seg, (const int64_t*)seg_slabs,
+                     (int64_t)1, slab_keys, key_bits - bits, bits, (const int64_t*)H, reinterpret_cast<uint64_t*>(d_words));
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
 
 extern "C" {
 

@@ -21,6 +21,11 @@
 
 #include "common.h"
 
+// radix.hip: the first level of the index's partition ((k-mer, row) pairs -> words grouped by the k-mer's top bits)
+int bnpk_pairs_partition_launch(bnpk_ctx* ctx, const int64_t* d_keys, const int64_t* d_rows, int64_t n, int key_bits, int bits,
+                                int row_bits, int64_t* d_words, int64_t* d_child_off, unsigned* d_tags, int64_t* d_list,
+                                int64_t* d_list_n, hipStream_t s);
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -441,6 +446,29 @@ __global__ __launch_bounds__(256) void rank_compose_kernel(const int64_t* __rest
   }
 }
 
+// ---- the index as ONE partition of (k-mer, row) pairs (round 6) ------------------------------------------------------------
+// flips[j] = 1 where the tag bit of word j differs from word j - 1's: a new first-level bucket starts there
+__global__ __launch_bounds__(256) void pair_flips_kernel(const uint64_t* __restrict__ words, int64_t d, int64_t* __restrict__ flips) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < d; j += stride)
+    flips[j] = j > 0 ? (int64_t)((words[j] ^ words[j - 1]) & 1ull) : 0;
+}
+
+// word j lies in the (before[j] + flips[j])-th non-empty first-level bucket: k-mer = bucket : word's k-mer bits, row = its row bits
+__global__ __launch_bounds__(256) void pair_decode_kernel(const uint64_t* __restrict__ words, const int64_t* __restrict__ before,
+                                                          int64_t d, const int64_t* __restrict__ list, int low_bits, int row_bits,
+                                                          int64_t* __restrict__ keys_out, int64_t* __restrict__ rows_out) {
+  const uint64_t row_mask = (1ull << row_bits) - 1ull;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < d; j += stride) {
+    const uint64_t w = words[j] >> 1;
+    const bool flip = j > 0 && ((words[j] ^ words[j - 1]) & 1ull);
+    const int64_t bucket = list[before[j] + (flip ? 1 : 0)];
+    keys_out[j] = (int64_t)(((uint64_t)bucket << low_bits) | (w >> row_bits));
+    rows_out[j] = (int64_t)(w & row_mask);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -520,6 +548,58 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
   arena_t arena;
   arena.base = reinterpret_cast<char*>(d_work);
   arena.size = (size_t)work_bytes;
+  // ---- the direct way (round 6): ONE partition that carries the row along.  The pair's sort key (2k + row bits) does not fit a
+  // word, but behind a first level over the k-mer's top t bits it does: word = (k-mer's other bits : row : tag) <= 63 bits
+  // (radix.hip: pair_source, written by the fixed-line scatter, the only one that ranks by a digit the word does not hold); the
+  // words are counted like any keys — the planner, with the first level's buckets as its segments — and come out sorted and
+  // de-duplicated bucket after bucket; the tag bit flips at every bucket boundary of that compacted list, a scan of the flips
+  // says which bucket a word lies in, and the k-mer's top bits are put back.  No rank look-ups, no second count.
+  int row_bits = 1;
+  while (row_bits < 31 && (n_rows - 1) >> row_bits) ++row_bits;
+  {
+    int need = 0;
+    while (need < key_bits && (n >> need) > FINISH_TARGET) ++need;
+    const int t = std::min(10, std::max(std::max(1, row_bits), std::min(need, 10)));
+    if (ctx->index_pairs && row_bits <= t && key_bits > t && key_bits - t + row_bits + 1 <= 63) {
+      int64_t* words = arena.words(n);
+      int64_t* wout = arena.words(n);
+      int64_t* counts = arena.words(n);
+      int64_t* child = arena.words((1ll << t) + 1);
+      int64_t* list = arena.words((1ll << t) + 1);
+      unsigned* tags = reinterpret_cast<unsigned*>(arena.words(64));
+      if (!words || !wout || !counts || !child || !list || !tags) return SP_NOMEM(arena);
+      BNPK_CHECK(bnpk_pairs_partition_launch(ctx, d_kmers, d_rows, n, key_bits, t, row_bits, words, child, tags, list, list + (1ll << t), s));
+      const int word_bits = key_bits - t + row_bits + 1;
+      const size_t mark_pairs = arena.used;
+      int64_t m = 0;
+      sparse_info info;
+      // (segments = the first level's buckets, none of the word's bits resolved inside them; planned per segment)
+      BNPK_CHECK(count_sparse_impl(ctx, words, n, word_bits, 0, std::max<int64_t>(n >> t, 1), child, 0, arena, wout, counts, &m, info, s, 0,
+                                   1ll << t));
+      {
+        bnpk_timer tm(ctx, "index_decode", s);
+        int64_t* flips = words;                              // (consumed by the count: free)
+        const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
+        hipLaunchKernelGGL(pair_flips_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), m, flips);
+        BNPK_HIP(ctx, hipGetLastError());
+      }
+      arena.used = mark_pairs;                               // (the count's own tables are done with)
+      int64_t* before = arena.words(m + 1);
+      if (!before) return SP_NOMEM(arena);
+      BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, words, m, before, s));
+      {
+        bnpk_timer tm(ctx, "index_decode", s);
+        const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
+        hipLaunchKernelGGL(pair_decode_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), (const int64_t*)before, m,
+                           (const int64_t*)list, key_bits - t, row_bits, d_keys_out, d_rows_out);
+        BNPK_HIP(ctx, hipGetLastError());
+      }
+      if (d_counts_out) BNPK_HIP(ctx, hipMemcpyAsync(d_counts_out, counts, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+      *h_n_pairs = m;
+      return BNPK_OK;
+    }
+  }
+  // ---- more rows than a first level has buckets (or the option off): the distinct values of rank(k-mer) * n_rows + row ----------
   int64_t* work_keys = arena.words(n);
   int64_t* distinct = arena.words(n);
   int64_t* counts = arena.words(n);

@@ -121,6 +121,8 @@ int bnpk_copy_rates(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes
  *                + general kernel for buckets with a bin of more than 64 keys.  Same results in every mode.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
+ * "index_pairs": bnpk_index_build as ONE partition of (k-mer, row) words where the rows fit a first level's buckets (<= 1024
+ *                rows; 1, default) or always as the distinct values of rank(k-mer) * n_rows + row (0).  Same pairs.
  * "sparse_claim": may bnpk_count_sparse take the claiming level (1, default) or only plain levels (0)?  Same results.
  * "l1_ring":     the scatter of bnpk_kmers_partition (the first radix level, fused with k-mer generation) — 0 = the
  *                write-combining scatter that lays every round out anew (default; what the other levels use), 1 = one fixed

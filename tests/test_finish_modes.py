@@ -266,7 +266,11 @@ def test_index_build_is_one_call(env):
     occurred, against np.unique over the pairs — random 62-bit k-mers, a repeat-rich 'genome' and a heavy hitter"""
     ops, lib, dev, ptr, torch = env
     rng = np.random.default_rng(17)
+    # (up to 1024 rows: ONE partition of (k-mer, row) words — radix.hip pair_source; more: the distinct values of rank * n_rows + row;
+    #  option "index_pairs" 0 forces the second construction on everything)
     for name, n, n_rows, make in (("random", 2_500_000, 17, lambda: rng.integers(0, 1 << 62, size=2_500_000, dtype=np.int64)),
+                                  ("many rows", 1_500_000, 5000, lambda: rng.integers(0, 1 << 62, size=1_500_000, dtype=np.int64)),
+                                  ("1024 rows", 900_000, 1024, lambda: _genome_like(rng, 900_000, 3)),
                                   ("repeats", 1_200_000, 300, lambda: _genome_like(rng, 1_200_000, 40)),
                                   ("hitter", 400_000, 5, lambda: np.where(rng.random(400_000) < 0.5, 777, rng.integers(0, 1 << 40, size=400_000))),
                                   ("tiny", 7, 3, lambda: np.array([5, 5, 9, 1, 5, 9, 1], dtype=np.int64))):
@@ -277,10 +281,13 @@ def test_index_build_is_one_call(env):
         nbytes = int(lib.bnpk_index_build_workspace(n, 62, n_rows))
         work = torch.empty(nbytes, dtype=torch.uint8, device=dev.tdev)
         ok, orow, oc = (torch.empty(n, dtype=torch.int64, device=dev.tdev) for _ in range(3))
-        m = C.c_int64(-1)
-        assert lib.bnpk_index_build(dev.ctx, ptr(d_k), ptr(d_r), n, 62, n_rows, ptr(work), nbytes, ptr(ok), ptr(orow), ptr(oc),
-                                    C.byref(m), dev.stream()) == 0, name
-        assert m.value == pairs.shape[1], (name, m.value, pairs.shape)
-        assert np.array_equal(ok[:m.value].cpu().numpy(), pairs[0]) and np.array_equal(orow[:m.value].cpu().numpy(), pairs[1]), name
-        assert np.array_equal(oc[:m.value].cpu().numpy(), mult), name
+        for direct in (1, 0):
+            assert lib.bnpk_set_option(dev.ctx, b"index_pairs", direct) == 0
+            m = C.c_int64(-1)
+            assert lib.bnpk_index_build(dev.ctx, ptr(d_k), ptr(d_r), n, 62, n_rows, ptr(work), nbytes, ptr(ok), ptr(orow), ptr(oc),
+                                        C.byref(m), dev.stream()) == 0, (name, direct)
+            assert m.value == pairs.shape[1], (name, direct, m.value, pairs.shape)
+            assert np.array_equal(ok[:m.value].cpu().numpy(), pairs[0]) and np.array_equal(orow[:m.value].cpu().numpy(), pairs[1]), (name, direct)
+            assert np.array_equal(oc[:m.value].cpu().numpy(), mult), (name, direct)
+        assert lib.bnpk_set_option(dev.ctx, b"index_pairs", 1) == 0
         assert np.array_equal(d_k.cpu().numpy(), kmers) and np.array_equal(d_r.cpu().numpy(), rows)      # the inputs are left alone
