@@ -118,7 +118,7 @@ int bnpk_prof_get(bnpk_ctx* ctx, int i, char* name64, double* total_ms, int64_t*
 int bnpk_set_option(bnpk_ctx* ctx, const char* name, int64_t value) {
   if (!ctx || !name) return BNPK_ERR_ARG;
   if (!strcmp(name, "finish_mode")) {
-    if (value < 0 || value > 5) return BNPK_ERR_ARG;
+    if (value < 0 || value > 6) return BNPK_ERR_ARG;
     ctx->finish_mode = (int)value;
     return BNPK_OK;
   }

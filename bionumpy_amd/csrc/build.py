@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libbnpk.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["api.hip", "scan.hip", "decode.hip", "multiline.hip", "fastq.hip", "encode.hip", "kmers.hip", "revcomp.hip", "rowops.hip", "radix.hip", "finish.hip", "finish_dup.hip", "finish_wave.hip", "finish_multi.hip", "merge.hip", "count.hip", "sparse.hip", "synth.hip", "collectives.hip"]
+SOURCES = ["api.hip", "scan.hip", "decode.hip", "multiline.hip", "fastq.hip", "encode.hip", "kmers.hip", "revcomp.hip", "rowops.hip", "radix.hip", "finish.hip", "finish_dup.hip", "finish_wave.hip", "finish_multi.hip", "finish_small.hip", "merge.hip", "count.hip", "sparse.hip", "synth.hip", "collectives.hip"]
 LINT = os.path.join(HERE, "isa_lint.py")
 HEADERS = [os.path.join(HERE, "common.h"), os.path.join(HERE, "scan.h"), os.path.join(HERE, "rows.h"),
            os.path.join(HERE, "kmer_gen.h"), os.path.join(HERE, "finish.h"),

@@ -49,6 +49,7 @@ struct bnpk_ctx {
   int finish_dup_grid = 0;
   bool finish_wave_ready = false;   // finish_wave.hip
   int finish_wave_grid = 0;
+  bool finish_small_ready = false;  // finish_small.hip
   bool finish_multi_ready = false;  // finish_multi.hip
   int finish_multi_grid = 0;
   void* mailbox = nullptr;       // page-locked words the host scalars of a call come back through (bnpk_fetch_i64)

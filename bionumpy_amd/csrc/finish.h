@@ -52,3 +52,10 @@ int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t*
                              unsigned long long* header, unsigned* status, uint64_t* keys_out, int64_t* counts_out,
                              const int64_t* big_table, int n_big, const uint64_t* big_keys, const int64_t* big_counts,
                              unsigned* redo_ids, int64_t* redo_bases, int64_t pstride, hipStream_t s);
+
+// One workgroup per bucket, a bitonic sort in LDS (finish_small.hip): small histograms (up to 2^25 keys), any key distribution;
+// the duplicate-aware kernels' convention (distinct keys back over the bucket, counts to loose_counts, D to Dv); buckets over
+// FINISH_CAP keys must be pre-counted (big_table) or set flag 1.
+int bnpk_finish_bitonic_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, unsigned long long* header,
+                               int64_t* Dv, int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
+                               const int64_t* big_counts, int64_t pstride, hipStream_t s);

@@ -1223,13 +1223,17 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
   // million buckets (tickets three iterations ahead, parking rings, look-backs over thousands of status words) idle through
   // most of them: the sacCer3 index spent 3.6 of its 8.4 ms in one finish_multi call over 2048 buckets.
   const bool few = mode == 0 && n_buckets <= (int64_t)16 * ctx->compute_units;
-  // More buckets than that but still a small histogram (up to 2^25 keys: the k-mers of sacCer3 after an extra level over the
-  // yeast genome's skewed 11-bit digits — 16 K buckets of ~740 keys): every kernel pays its per-bucket set-up on buckets a
-  // tenth of the size it was built for (round 6, scripts/exp/exp_index3.py: general 5.7 ms, fast + redo 5.9, workgroup table
-  // 3.8, multiplicities 3.9, the cascade 3.4); the cascade's one wavefront per bucket is the least bad, and the probe that
-  // would choose is a round trip saved.
-  const bool small = mode == 0 && !few && n <= (1ll << 25) && can_wave;
-  bool use_general = mode == 1 || few, use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = (mode == 4 && can_wave) || small;
+  // A small histogram (up to 2^25 keys) in SMALL buckets (2048 keys on average or fewer: what extra levels over a genome's skewed
+  // k-mers leave — sacCer3: 6608 buckets of ~750 keys in the batch of its over-full buckets): one workgroup per bucket sorts it
+  // with a bitonic network (finish_small.hip), no probe, no answer from the device before the end, and no dependence on what the
+  // keys look like.  The counting-sort kernels take 4.8 ms on 4096 even buckets of the yeast genome's 31-mers (long bins: k-mers
+  // that share their next 13 bits) where they take 0.12 ms on random keys, and all of them pay 11-30 us per bucket on 16 K buckets
+  // of 740 keys (round 6, scripts/exp/exp_index3.py: general 5.7 ms, fast + redo 5.9, workgroup table 3.8, multiplicities 3.9,
+  // cascade 3.4).  The network's cost grows with P log^2 P: at 8192-key buckets it is 6x the general kernel on random keys
+  // (0.78 against 0.12 ms per 12 M keys), which is why full-size buckets keep the kernels above.
+  const bool small = mode == 0 && n <= (1ll << 25) && n <= 2048 * n_buckets;
+  bool use_bitonic = mode == 6 || small;
+  bool use_general = mode == 1 || (few && !small), use_dup = mode == 3 || (mode == 4 && !can_wave), use_wave = mode == 4 && can_wave;
   bool try_fast = (mode == 0 || mode == 2) && n_big <= FF_MAXBIG && !few && !small;
   bool use_multi = mode == 5;
   bool nearly_distinct = false;
@@ -1295,7 +1299,7 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       if (host[FS_FLAGS] & 4) try_fast = false;           // duplicate-heavy keys: everything again, with another kernel
       else if (host[FS_REDO] > 0 && !(host[FS_FLAGS] & 1)) BNPK_CHECK(general(true, host[FS_REDO]));
     }
-    if (!try_fast && !use_general && !use_dup && !use_wave && !use_multi) {
+    if (!try_fast && !use_general && !use_dup && !use_wave && !use_multi && !use_bitonic) {
       // the fast kernel refused (repeats in more than FF_LOG buckets) or could not be tried
       if (mode == 2) use_general = true;
       else if (mode == 0 && nearly_distinct && host[FS_MISFIT] == 0) use_multi = true;
@@ -1305,6 +1309,15 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       bnpk_timer t_multi(ctx, "finish.multi", s);
       BNPK_CHECK(multi());
       if (host[FS_FLAGS] & 2) use_general = true;
+    }
+    if (use_bitonic) {
+      bnpk_timer t_small(ctx, "finish.bitonic", s);
+      BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+      BNPK_CHECK(bnpk_finish_bitonic_launch(ctx, part, d_bucket_offsets, n_buckets, state, Dv, d_keys_out, d_big_table, n_big, big_keys,
+                                            d_big_counts, pstride, s));
+      BNPK_CHECK(bnpk_scan_launch(ctx, Dv, n_buckets, 1, Dv, true, (int64_t*)scan_scratch, s));
+      BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_keys_out, d_counts_out, d_bucket_offsets, Dv, n_buckets, state, 0, s));
+      BNPK_CHECK(bnpk_finish_compact_launch(ctx, d_part, d_keys_out, d_bucket_offsets, Dv, n_buckets, state, pstride, s));
     }
     if (use_wave) { bnpk_timer t_wave(ctx, "finish.cascade", s); BNPK_CHECK(duplicate_aware(true)); }
     else if (use_dup) { bnpk_timer t_dup(ctx, "finish.dup", s); BNPK_CHECK(duplicate_aware(false)); }

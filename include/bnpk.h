@@ -118,7 +118,9 @@ int bnpk_copy_rates(bnpk_ctx* ctx, const void* d_src, void* d_dst, int64_t bytes
  *                3 = the workgroup-per-bucket duplicate-aware kernel (+ general kernel for what it hands back);
  *                4 = the whole cascade; 5 = the fast kernel's ranking with multiplicities and exact output positions
  *                (finish_multi.hip; what mode 0 takes when the fast kernel refuses keys that are nearly all distinct),
- *                + general kernel for buckets with a bin of more than 64 keys.  Same results in every mode.
+ *                + general kernel for buckets with a bin of more than 64 keys; 6 = one workgroup per bucket with a bitonic sort
+ *                in LDS (finish_small.hip; what mode 0 takes for histograms of up to 2^25 keys: no dependence on what the keys
+ *                look like).  Same results in every mode.
  * "fastq_encoder": the tile kernels of bnpk_fastq_census / bnpk_fastq_encode — 1 = the fast kernels, with the general
  *                ones for the tiles they hand back (default), 0 = the general kernels only.  Same results either way.
  * "index_pairs": bnpk_index_build as ONE partition of (k-mer, row) words where the rows fit a first level's buckets (<= 1024

@@ -69,7 +69,7 @@ def test_finish_reports_a_bucket_over_capacity_that_nobody_counted(env):
     off = torch.tensor([0, n], dtype=torch.int64, device="cuda")
     out_k, out_c = torch.empty(n, dtype=torch.int64, device="cuda"), torch.empty(n, dtype=torch.int64, device="cuda")
     state = torch.empty(lib.bnpk_finish_state_words(1), dtype=torch.int64, device="cuda")
-    for mode in (0, 1, 2, 3, 4):
+    for mode in (0, 1, 2, 3, 4, 6):
         assert lib.bnpk_set_option(dev.ctx, b"finish_mode", mode) == OK
         nu, ov = C.c_int64(0), C.c_int(0)
         assert lib.bnpk_finish_sorted(dev.ctx, ptr(keys), n, ptr(off), 1, 40, ptr(out_k), ptr(out_c), ptr(state), None, 0, None,

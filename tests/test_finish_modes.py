@@ -14,7 +14,7 @@ from bionumpy_amd.device import HArray
 pytestmark = pytest.mark.gpu
 
 M62 = (1 << 62) - 1
-MODES = (1, 2, 3, 4, 5, 0)      # general / fast + redo / workgroup-per-bucket duplicate-aware / whole cascade / fast with multiplicities / chosen per call
+MODES = (1, 2, 3, 4, 5, 6, 0)   # general / fast + redo / workgroup-per-bucket duplicate-aware / whole cascade / fast with multiplicities / bitonic / chosen per call
 
 
 @pytest.fixture(scope="module")
