@@ -39,7 +39,16 @@ __global__ __launch_bounds__(FB_THREADS) void finish_bitonic_kernel(
   unsigned short* heads = reinterpret_cast<unsigned short*>(smem + FB_OFF_HEADS);
   unsigned* wsum = reinterpret_cast<unsigned*>(smem + FB_OFF_WSUM);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t b = blockIdx.x; b < n_buckets; b += gridDim.x) {
+  // Buckets are handed out by a ticket counter (header[FS_TICKET], zeroed by the launcher), not by blockIdx: a genome's dense
+  // buckets have regular ids (the k-mers that end in AAAA...), a fixed stride would give a few workgroups all of them (sacCer3 at
+  // 14 bits: the busiest of 512 workgroups would sort for 3.5 ms, the average one for 0.64).
+  unsigned* ticket = reinterpret_cast<unsigned*>(heads);   // (the head positions are not in use between two buckets)
+  while (true) {
+    __syncthreads();                                         // everybody is done with the previous bucket — and with its ticket:
+    if (tid == 0) ticket[0] = (unsigned)atomicAdd(&header[FS_TICKET], 1ull);   // (a branch without a barrier of its own would otherwise
+    __syncthreads();                                         //  race with this write: a wavefront still looking at the old ticket)
+    const int64_t b = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)ticket[0]);
+    if (b >= n_buckets) break;
     const int64_t lo = fb_uniform(bucket_off[b]);
     const int64_t size = fb_uniform(bucket_off[b + 1]) - lo;
     const int64_t src = pstride ? b * pstride : lo;
@@ -120,8 +129,7 @@ __global__ __launch_bounds__(FB_THREADS) void finish_bitonic_kernel(
     __syncthreads();
     int64_t* co = loose_counts + lo;
     for (unsigned r = tid; r < D; r += FB_THREADS) co[r] = (int64_t)(r + 1 < D ? (int)heads[r + 1] : nb) - (int64_t)heads[r];
-    __syncthreads();                                         // (the stage and the heads are the next bucket's)
-  }
+  }                                                          // (the barrier at the top hands the stage and the heads to the next bucket)
 }
 
 }  // namespace

@@ -306,6 +306,22 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   const int64_t* offsets = d_part_offsets;
   int done = part_bits;
   int64_t n_seg = n_seg_in > 0 ? n_seg_in : 1ll << done;
+  // A small input that comes in segments (the index's words behind their first level, a chunk's k-mers behind the fused level):
+  // the segments' sizes are known, so the levels are planned for the LARGEST of them instead of the average — a genome's k-mers
+  // fill their top digits unevenly (sacCer3: the fullest of 1024 buckets holds 6x the average), and planning for the average
+  // meant a claiming attempt whose bag overflows, a level too narrow, and a batch of hundreds of over-full buckets.  One census
+  // (one answer) up front; with the bitonic finishing kernel small buckets are cheap.
+  if (depth == 0 && offsets && n_seg > 1 && n <= (1ll << 25)) {
+    int64_t* census = arena.words(2 + 3 * 4);
+    if (!census) return SP_NOMEM(arena);
+    BNPK_CHECK(bnpk_bucket_census(ctx, offsets, n_seg, bnpk_finish_capacity(), 4, census, s));
+    int64_t got[2] = {0, 0};
+    BNPK_CHECK(bnpk_fetch_i64(ctx, census, 2, got, s));
+    ++info.syncs;
+    const int64_t per_segment = done < 40 ? std::min<int64_t>(got[0] << done, 1ll << 61) : 1ll << 61;    // (as if all 2^done were that large)
+    const int64_t as_if = n_seg_in > 0 ? got[0] : per_segment;
+    if (as_if > (n_plan > 0 ? n_plan : n)) n_plan = as_if;
+  }
   int plan[8];
   const int n_levels = radix_plan(n_plan > 0 ? n_plan : n, kb, done, plan);
   const bool may_claim = ctx->sparse_claim != 0;
