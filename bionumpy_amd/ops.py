@@ -788,8 +788,24 @@ class HipOps:
         space = self._empty(work_bytes, np.uint8)
         n_unique = C.c_int64(0)
         info = (C.c_int64 * 5)()
-        self._chk(lib.bnpk_count_sparse(self.ctx, ptr(work), n, key_bits, skip, n_plan, ptr(offsets), done, ptr(space), work_bytes,
-                                        ptr(keys_out), ptr(counts), C.byref(n_unique), info, self._s()))
+        status = lib.bnpk_count_sparse(self.ctx, ptr(work), n, key_bits, skip, n_plan, ptr(offsets), done, ptr(space), work_bytes,
+                                       ptr(keys_out), ptr(counts), C.byref(n_unique), info, self._s())
+        if status == -4 and work_bytes < sizes[2]:
+            # BNPK_ERR_NOMEM: the keys needed a path the workspace had no room for (heavy-hitter buckets on an input too large to
+            # be given the any-input workspace up front).  The call consumed its input; where that was a copy, the caller's keys
+            # are intact and the call is repeated with everything the allocator can give back
+            del space
+            tm.cuda.empty_cache()
+            if consume:
+                raise MemoryError("bnpk_count_sparse: %d keys with over-full buckets need a workspace of %.1f GB (the call was given "
+                                  "%.1f GB and has used its input up); count a copy (consume=False) or smaller batches"
+                                  % (n, sizes[2] / 1e9, work_bytes / 1e9))
+            work = t.clone()
+            work_bytes = sizes[2]
+            space = self._empty(work_bytes, np.uint8)
+            status = lib.bnpk_count_sparse(self.ctx, ptr(work), n, key_bits, skip, n_plan, ptr(offsets), done, ptr(space), work_bytes,
+                                           ptr(keys_out), ptr(counts), C.byref(n_unique), info, self._s())
+        self._chk(status)
         self.last_sparse_info = {"path": int(info[0]), "levels": int(info[1]), "round_trips": int(info[2]), "bag": int(info[3]),
                                  "precounted": int(info[4]), "workspace": work_bytes}
         if info[0] == 1 or info[3] > 0:                      # the claiming level ran (and, if the path is not 1, was given up: its bag overflowed)
