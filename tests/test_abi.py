@@ -51,3 +51,20 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(base, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(base, f)
+
+
+def test_workspace_queries_need_no_gpu():
+    """bnpk_count_sparse_workspace / bnpk_index_build_workspace are host arithmetic: callable on a box without a GPU, monotone
+    in the mode (plain levels <= claiming level <= any input) and in n, and sized as the header says (about n / 1.4 n / 6 n words)"""
+    from bionumpy_amd import _native
+    lib = _native.lib
+    for n in (1, 1000, 1 << 20, 50_000_000, 6_000_000_000):
+        sizes = [lib.bnpk_count_sparse_workspace(n, 62, 0, 0, 0, mode) for mode in (0, 1, 2)]
+        assert 0 < sizes[0] <= sizes[1] <= sizes[2], (n, sizes)
+        assert sizes[2] >= 6 * 8 * n
+        assert lib.bnpk_count_sparse_workspace(2 * n, 62, 0, 0, 0, 2) >= sizes[2]
+    # the headline's shape: 6e9 keys behind a 10-bit first level — the claiming level's slots are 2^20 x 7680 keys
+    claim = lib.bnpk_count_sparse_workspace(6_000_000_000, 62, 0, 0, 10, 1)
+    assert (1 << 20) * 7680 * 8 <= claim <= (1 << 20) * 7680 * 8 + 8 * 6_000_000_000
+    assert lib.bnpk_count_sparse_workspace(0, 62, 0, 0, 0, 2) > 0
+    assert lib.bnpk_index_build_workspace(12_000_000, 62, 17) >= lib.bnpk_count_sparse_workspace(12_000_000, 62, 0, 0, 0, 2)
