@@ -72,7 +72,10 @@ int radix_plan(int64_t n, int key_bits, int done, int levels[8]) {
 
 size_t state_bytes(int64_t n_buckets) { return (size_t)bnpk_finish_state_words(n_buckets) * 8; }
 
-enum { SP_TRY_PLAIN = 1 };                              // (internal) the claiming level could not be used: take the plain one
+enum {
+  SP_TRY_PLAIN = 1,                                     // (internal) the claiming level could not be used: take the plain one
+  SP_NEEDS_KEYS = 2                                     // (internal) segment-blind words would have to be sorted as a whole: see `blind`
+};
 
 struct sparse_info {
   int path = 0;          // 1 = claiming level + strided finish, 2 = plain levels + finish, 3 = sorted (fall-back), 0 = empty input
@@ -83,10 +86,31 @@ struct sparse_info {
 };
 
 // d_part_offsets / part_bits / n_seg_in: the keys come grouped in n_seg_in segments (0: 2^part_bits of them) inside each of
-// which the top part_bits bits (below the skipped ones) are the same
+// which the top part_bits bits (below the skipped ones) are the same.
+// blind: the keys do not say which segment they lie in (the index's words: the k-mer's top bits are the segment and not part of
+// the word) — equal keys of two segments are two results, so nothing may order or merge keys ACROSS segments: the claiming
+// level's bag (merged by key) is only accepted empty, the batch of over-full buckets is relabelled (precount_buckets), and where
+// only a sort of everything is left the call gives up with SP_NEEDS_KEYS (the caller builds the index from whole keys).
 int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
                       const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
-                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in = 0);
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in = 0, bool blind = false);
+
+// words[j]'s bits from `shift` up <- labels[i] (NULL: i itself), i = the segment j lies in (seg_first[i] <= j, nb segments)
+__global__ __launch_bounds__(256) void relabel_kernel(uint64_t* __restrict__ words, int64_t n, const int64_t* __restrict__ seg_first,
+                                                      int nb, int shift, const int64_t* __restrict__ labels) {
+  const uint64_t low_mask = (1ull << shift) - 1ull;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+    int lo = 0, hi = nb;                                 // first segment that starts behind j
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_first[mid] <= j) lo = mid + 1; else hi = mid;
+    }
+    const int i = lo - 1;
+    const uint64_t label = labels ? (uint64_t)labels[i] : (uint64_t)i;
+    words[j] = (words[j] & low_mask) | (label << shift);
+  }
+}
 
 // (sorted distinct keys, counts) by the library sort + run kernels: what heavy-hitter inputs take.  `work` is consumed.
 // keys_out NULL: the distinct keys go to the ping-pong buffer the sort left free, *keys_where says which, *sorted_where where
@@ -126,8 +150,13 @@ int count_by_sorting(bnpk_ctx* ctx, int64_t* work, int64_t n, int key_bits, aren
 // times), inside that call.
 int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& listed, int key_bits, int skip_bits, int done,
                      arena_t& arena, int64_t** table_out, int64_t** big_keys, int64_t** big_counts, sparse_info& info, hipStream_t s,
-                     int depth) {
+                     int depth, bool blind) {
   const int nb = (int)(listed.size() / 3);
+  // Segment-blind words (the index): two listed buckets of different first-level segments may hold EQUAL words, and the cut below
+  // wants a batch that sorts bucket by bucket.  The top `done` bits of a word are the same all over its bucket, so for the time
+  // of the count they carry the bucket's number in the batch instead, and the distinct words get their own bits back.
+  const int label_shift = key_bits - skip_bits - done;
+  if (blind && (depth != 0 || nb > (1ll << std::min(done, 20)))) return SP_NEEDS_KEYS;
   std::vector<int64_t> order(nb);
   for (int i = 0; i < nb; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return listed[3 * a] < listed[3 * b]; });
@@ -156,16 +185,29 @@ int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& l
   int64_t* d_woff = arena.words(nb + 1);
   int64_t* d_prefix = arena.words(nb);
   int64_t* d_starts = arena.words(nb);
+  int64_t* d_labels = blind ? arena.words(nb) : nullptr;
   int64_t* table = arena.words(3 * (int64_t)nb);
+  if (blind && !d_labels) return SP_NOMEM(arena);
   if (!batch || (!recurse && !batch_alt) || (recurse && !k) || !c || !d_lo || !d_off || !d_woff || !d_prefix || !d_starts || !table)
     return SP_NOMEM(arena);
   BNPK_HIP(ctx, hipMemcpyAsync(d_lo, lo8.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_off, byte_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_woff, word_off.data(), (size_t)(nb + 1) * 8, hipMemcpyHostToDevice, s));
   BNPK_HIP(ctx, hipMemcpyAsync(d_prefix, prefix.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
+  if (blind) {
+    std::vector<int64_t> own_bits(nb);
+    for (int i = 0; i < nb; ++i) own_bits[i] = ids[i] & ((1ll << done) - 1);
+    BNPK_HIP(ctx, hipMemcpyAsync(d_labels, own_bits.data(), (size_t)nb * 8, hipMemcpyHostToDevice, s));
+  }
   BNPK_HIP(ctx, hipStreamSynchronize(s));                // (the host vectors go out of scope; pageable copies are staged anyway)
   BNPK_CHECK(bnpk_gather_rows(ctx, reinterpret_cast<const uint8_t*>(keys), d_lo, d_off, nb, total * 8, 0,
                               reinterpret_cast<uint8_t*>(batch), s));
+  const unsigned relabel_grid = (unsigned)std::min<int64_t>(ceil_div(total, 256), (int64_t)ctx->compute_units * 16);
+  if (blind) {
+    hipLaunchKernelGGL(relabel_kernel, dim3(relabel_grid), dim3(256), 0, s, reinterpret_cast<uint64_t*>(batch), total, (const int64_t*)d_woff, nb,
+                       label_shift, (const int64_t*)nullptr);
+    BNPK_HIP(ctx, hipGetLastError());
+  }
   int64_t d = 0;
   int64_t* cum = nullptr;
   if (recurse) {
@@ -181,6 +223,11 @@ int precount_buckets(bnpk_ctx* ctx, const int64_t* keys, std::vector<int64_t>& l
   }
   BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, c, d, cum, s));
   BNPK_CHECK(bnpk_search_sorted(ctx, cum, d + 1, d_prefix, nb, 0, d_starts, s));
+  if (blind && d > 0) {
+    hipLaunchKernelGGL(relabel_kernel, dim3(std::max(1u, std::min(relabel_grid, (unsigned)ceil_div(d, 256)))), dim3(256), 0, s,
+                       reinterpret_cast<uint64_t*>(k), d, (const int64_t*)d_starts, nb, label_shift, (const int64_t*)d_labels);
+    BNPK_HIP(ctx, hipGetLastError());
+  }
   std::vector<int64_t> starts(nb);
   BNPK_CHECK(bnpk_fetch_i64(ctx, d_starts, nb, starts.data(), s));
   ++info.syncs;
@@ -212,7 +259,7 @@ size_t claimed_bytes(int64_t n, int64_t n_b) {
 // SP_TRY_PLAIN if the bag overflowed / a wait between workgroups gave up / the merge has no room: `cur` is intact then.
 int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets, int64_t n_seg, int shift, int bits, int key_bits,
                   arena_t& arena, int64_t* keys_out, int64_t* counts_out, int64_t* h_n_unique, sparse_info& info, hipStream_t s,
-                  int depth) {
+                  int depth, bool blind) {
   const int64_t n_b = n_seg << bits, stride = bnpk_claimed_stride();
   const int64_t bag_cap = std::max<int64_t>(n / 8, 1 << 16);
   const size_t mark = arena.used;
@@ -232,7 +279,7 @@ int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets
   BNPK_CHECK(bnpk_fetch_i64(ctx, bag_fill, 1, &n_bag, s));
   ++info.syncs;
   info.n_bag = n_bag;
-  if (n_bag > bag_cap) {                                 // keys were dropped: the level again, the plain way
+  if (n_bag > bag_cap || (blind && n_bag > 0)) {         // keys were dropped (or could not be merged back by value): the plain level
     arena.used = mark;
     return SP_TRY_PLAIN;
   }
@@ -292,7 +339,7 @@ int count_claimed(bnpk_ctx* ctx, int64_t* cur, int64_t n, const int64_t* offsets
 
 int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, int skip_bits, int64_t n_plan,
                       const int64_t* d_part_offsets, int part_bits, arena_t& arena, int64_t* d_keys_out, int64_t* d_counts_out,
-                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in) {
+                      int64_t* h_n_unique, sparse_info& info, hipStream_t s, int depth, int64_t n_seg_in, bool blind) {
   if (n == 0) {
     *h_n_unique = 0;
     return BNPK_OK;
@@ -330,7 +377,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     const int shift = kb - done - bits;
     if (level == n_levels - 1 && may_claim && bits >= 1 && bits <= 10 && n >= CLAIM_MIN_KEYS &&
         (n_seg << bits) * bnpk_claimed_stride() <= 3 * n && claimed_bytes(n, n_seg << bits) <= arena.left()) {
-      const int r = count_claimed(ctx, cur, n, offsets, n_seg, shift, bits, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, depth);
+      const int r = count_claimed(ctx, cur, n, offsets, n_seg, shift, bits, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, depth, blind);
       if (r != SP_TRY_PLAIN) return r;
     }
     int64_t* out = spare ? spare : arena.words(n);
@@ -375,7 +422,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     bits = std::min(std::min(11, kb - done), bits);
     if (n_over <= MAX_PRECOUNTED && depth == 0) {         // (a batch that is itself being pre-counted: levels, then the sort)
       std::vector<int64_t> listed(got.begin() + 2, got.begin() + 2 + 3 * n_over);
-      BNPK_CHECK(precount_buckets(ctx, cur, listed, key_bits, skip_bits, done, arena, &table, &big_keys, &big_counts, info, s, depth));
+      BNPK_CHECK(precount_buckets(ctx, cur, listed, key_bits, skip_bits, done, arena, &table, &big_keys, &big_counts, info, s, depth, blind));
       n_big = (int)n_over;
       fits = true;
       break;
@@ -412,6 +459,7 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
     }
     // a wait between workgroups gave up (a run-time condition): the partitioned keys are intact, the sort gives the answer
   }
+  if (blind) return SP_NEEDS_KEYS;
   return count_by_sorting(ctx, cur, n, key_bits, arena, d_keys_out, d_counts_out, h_n_unique, info, s, spare);
 }
 
@@ -590,29 +638,35 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
       int64_t m = 0;
       sparse_info info;
       // (segments = the first level's buckets, none of the word's bits resolved inside them; planned per segment)
-      BNPK_CHECK(count_sparse_impl(ctx, words, n, word_bits, 0, std::max<int64_t>(n >> t, 1), child, 0, arena, wout, counts, &m, info, s, 0,
-                                   1ll << t));
-      {
-        bnpk_timer tm(ctx, "index_decode", s);
-        int64_t* flips = words;                              // (consumed by the count: free)
-        const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
-        hipLaunchKernelGGL(pair_flips_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), m, flips);
-        BNPK_HIP(ctx, hipGetLastError());
+      const int st = count_sparse_impl(ctx, words, n, word_bits, 0, std::max<int64_t>(n >> t, 1), child, 0, arena, wout, counts, &m, info, s, 0,
+                                       1ll << t, true);
+      if (st != SP_NEEDS_KEYS) {
+        BNPK_CHECK(st);
+        {
+          bnpk_timer tm(ctx, "index_decode", s);
+          int64_t* flips = words;                              // (consumed by the count: free)
+          const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
+          hipLaunchKernelGGL(pair_flips_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), m, flips);
+          BNPK_HIP(ctx, hipGetLastError());
+        }
+        arena.used = mark_pairs;                               // (the count's own tables are done with)
+        int64_t* before = arena.words(m + 1);
+        if (!before) return SP_NOMEM(arena);
+        BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, words, m, before, s));
+        {
+          bnpk_timer tm(ctx, "index_decode", s);
+          const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
+          hipLaunchKernelGGL(pair_decode_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), (const int64_t*)before, m,
+                             (const int64_t*)list, key_bits - t, row_bits, d_keys_out, d_rows_out);
+          BNPK_HIP(ctx, hipGetLastError());
+        }
+        if (d_counts_out) BNPK_HIP(ctx, hipMemcpyAsync(d_counts_out, counts, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
+        *h_n_pairs = m;
+        return BNPK_OK;
       }
-      arena.used = mark_pairs;                               // (the count's own tables are done with)
-      int64_t* before = arena.words(m + 1);
-      if (!before) return SP_NOMEM(arena);
-      BNPK_CHECK(bnpk_exclusive_scan_i64(ctx, words, m, before, s));
-      {
-        bnpk_timer tm(ctx, "index_decode", s);
-        const unsigned grid = grid_for(std::min<int64_t>(ceil_div(m, 256), (int64_t)ctx->compute_units * 16));
-        hipLaunchKernelGGL(pair_decode_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint64_t*>(wout), (const int64_t*)before, m,
-                           (const int64_t*)list, key_bits - t, row_bits, d_keys_out, d_rows_out);
-        BNPK_HIP(ctx, hipGetLastError());
-      }
-      if (d_counts_out) BNPK_HIP(ctx, hipMemcpyAsync(d_counts_out, counts, (size_t)m * 8, hipMemcpyDeviceToDevice, s));
-      *h_n_pairs = m;
-      return BNPK_OK;
+      // (words that only a sort of everything could count — thousands of over-full buckets of equal words, a wait that gave up:
+      // they do not say which bucket they came from, so the index is built from whole keys below; the inputs are untouched)
+      arena.used = 0;
     }
   }
   // ---- more rows than a first level has buckets (or the option off): the distinct values of rank(k-mer) * n_rows + row ----------

@@ -261,6 +261,24 @@ def test_count_sparse_argument_checks_and_small_workspaces(env):
                                  dev.stream()) == -1
 
 
+def _two_hitters(rng, n):
+    low = int(rng.integers(0, 1 << 52))                                  # (the first level takes 6 bits here, 10 on large inputs)
+    hot = [(13 << 56) | low, (46 << 56) | (low ^ 0x5000)]
+    k = rng.integers(0, 1 << 62, size=n, dtype=np.int64)
+    k[:40_000] = hot[0]
+    k[40_000:70_000] = hot[1]
+    k[70_000:70_040] = hot[0] ^ rng.integers(0, 1 << 16, size=40)       # neighbours: same buckets on every level that runs
+    k[70_040:70_080] = hot[1] ^ rng.integers(0, 1 << 16, size=40)
+    return rng.permutation(k)
+
+
+def _unique_pairs(kmers, rows):
+    order = np.lexsort((rows, kmers))
+    k, r = kmers[order], rows[order]
+    first = np.flatnonzero(np.concatenate([[True], (k[1:] != k[:-1]) | (r[1:] != r[:-1])]))
+    return np.stack([k[first], r[first]]), np.diff(np.append(first, k.size))
+
+
 def test_index_build_is_one_call(env):
     """KmerIndex.create_index (kmer_indexing.py:24-47) from raw pointers: sorted distinct (k-mer, row) pairs and how often each
     occurred, against np.unique over the pairs — random 62-bit k-mers, a repeat-rich 'genome' and a heavy hitter"""
@@ -273,10 +291,16 @@ def test_index_build_is_one_call(env):
                                   ("1024 rows", 900_000, 1024, lambda: _genome_like(rng, 900_000, 3)),
                                   ("repeats", 1_200_000, 300, lambda: _genome_like(rng, 1_200_000, 40)),
                                   ("hitter", 400_000, 5, lambda: np.where(rng.random(400_000) < 0.5, 777, rng.integers(0, 1 << 40, size=400_000))),
-                                  ("tiny", 7, 3, lambda: np.array([5, 5, 9, 1, 5, 9, 1], dtype=np.int64))):
+                                  ("tiny", 7, 3, lambda: np.array([5, 5, 9, 1, 5, 9, 1], dtype=np.int64)),
+                                  # two repeated k-mers in different first-level buckets whose words' remaining bits lie close together,
+                                  # each with a few neighbours in its over-full bucket: the words do not say which bucket they are from,
+                                  # so the batch that counts over-full buckets must not sort them together (found by tests/test_fuzz.py)
+                                  ("two hitters", 300_000, 3, lambda: _two_hitters(rng, 300_000)),
+                                  # more over-full buckets of equal words than are counted in a batch: the whole-key construction takes over
+                                  ("many hitters", 1100 * 8300, 1, lambda: rng.permutation(np.repeat(rng.integers(0, 1 << 62, size=1100, dtype=np.int64), 8300)))):
         kmers = make().astype(np.int64)
         rows = np.sort(rng.integers(0, n_rows, size=n)).astype(np.int64)
-        pairs, mult = np.unique(np.stack([kmers, rows]), axis=1, return_counts=True)
+        pairs, mult = _unique_pairs(kmers, rows)
         d_k, d_r = torch.from_numpy(kmers).to(dev.tdev), torch.from_numpy(rows).to(dev.tdev)
         nbytes = int(lib.bnpk_index_build_workspace(n, 62, n_rows))
         work = torch.empty(nbytes, dtype=torch.uint8, device=dev.tdev)

@@ -101,3 +101,65 @@ def test_fastq_decode_fast_kernels_against_the_general_ones(ops):
             n += 1
     finally:
         lib.bnpk_set_option(dev.ctx, b"fastq_encoder", 1)
+
+
+def test_the_planners_on_random_key_distributions(ops):
+    """bnpk_count_sparse (levels, claiming level + bag, over-full buckets counted by the planner itself, bitonic / cascade / general
+    finishing, the sort fall-back) and bnpk_index_build (one partition of (k-mer, row) words; by ranks) against np.unique on keys
+    of random size, width and shape: uniform, piled up near zero, a few values, heavy hitters over a uniform floor, keys that
+    share their top bits, a genome-like set of repeats — with the claiming level and the pair partition switched on and off"""
+    import ctypes as C
+    import torch
+    from bionumpy_amd._native import lib
+    from bionumpy_amd.device import Device, HArray
+    dev = Device.get()
+    rng = np.random.default_rng(20260929)
+
+    def keys_of(n, bits, shape):
+        top = 1 << bits
+        if shape == 0:
+            k = rng.integers(0, top, size=n, dtype=np.int64)
+        elif shape == 1:                                      # density ~ x^(-3/4)
+            k = np.minimum((rng.random(n) ** 4 * float(top)).astype(np.int64), top - 1)
+        elif shape == 2:
+            k = rng.integers(0, min(top, 40), size=n, dtype=np.int64)
+        elif shape == 3:                                      # heavy hitters over a uniform floor
+            k = rng.integers(0, top, size=n, dtype=np.int64)
+            hot = rng.integers(0, top, size=3, dtype=np.int64)
+            k[rng.random(n) < 0.3] = hot[0]
+            k[rng.random(n) < 0.05] = hot[1]
+        elif shape == 4:                                      # the top bits shared: everything in a 2^-12 slice of the range
+            k = (rng.integers(0, top, dtype=np.int64) & ~((top >> 12) - 1 if top >> 12 else 0)) | rng.integers(0, max(top >> 12, 1), size=n, dtype=np.int64)
+        else:                                                 # every key ~20 times
+            k = rng.integers(0, top, size=max(n // 20, 1), dtype=np.int64)[rng.integers(0, max(n // 20, 1), size=n)]
+        return k.astype(np.int64)
+
+    t0, rounds = time.time(), 0
+    while rounds < 3 or time.time() - t0 < BOX:
+        n = int(rng.choice([1, 7, 3000, 70_000, 1_300_000, 4_000_000]))
+        bits = int(rng.choice([20, 33, 50, 62]))
+        shape = int(rng.integers(0, 6))
+        claim, direct = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        keys = keys_of(n, bits, shape)
+        tag = (n, bits, shape, claim, direct, rounds)
+        assert lib.bnpk_set_option(dev.ctx, b"sparse_claim", claim) == 0 and lib.bnpk_set_option(dev.ctx, b"index_pairs", direct) == 0
+        try:
+            ek, ec = np.unique(keys, return_counts=True)
+            gk, gc = ops.count_sparse(HArray(host=keys.copy()), key_bits=bits)
+            assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec), ("count_sparse", tag, ops.last_sparse_info)
+            n_rows = int(rng.choice([1, 3, 17, 1000, 1024, 1025, 40_000]))
+            rows = np.sort(rng.integers(0, n_rows, size=n)).astype(np.int64)
+            want, mult = np.unique(np.stack([keys, rows]), axis=1, return_counts=True)
+            got = ops.unique_pairs(HArray(host=keys.copy()), HArray(host=rows), key_bits=bits, n_values=n_rows, with_counts=True)
+            gk, gr, gm = got[0].host(), got[1].host(), got[2].host()
+            if not (np.array_equal(gk, want[0]) and np.array_equal(gr, want[1]) and np.array_equal(gm, mult)):
+                m = min(gk.size, want.shape[1])
+                bad = np.flatnonzero((gk[:m] != want[0][:m]) | (gr[:m] != want[1][:m]) | (gm[:m] != mult[:m]))
+                detail = [(int(j), hex(int(gk[j])), int(gr[j]), int(gm[j]), hex(int(want[0][j])), int(want[1][j]), int(mult[j])) for j in bad[:3]]
+                raise AssertionError(("unique_pairs", tag, n_rows, "pairs got / want", gk.size, want.shape[1], "occurrences", int(gm.sum()), n,
+                                      "mismatches", int(bad.size), detail))
+        finally:
+            lib.bnpk_set_option(dev.ctx, b"sparse_claim", 1)
+            lib.bnpk_set_option(dev.ctx, b"index_pairs", 1)
+        rounds += 1
+    assert rounds >= 3
