@@ -4,6 +4,8 @@
 // Two kernels share the work: finish_fast_kernel (duplicate-free buckets: the common case for k = 31) and
 // finish_sorted_kernel (any multiplicities; also works off the fast kernel's redo list).
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "finish.h"
 #include "scan.h"
@@ -1259,11 +1261,24 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       if (host[FS_MISFIT] != 0) { try_fast = false; if (use_multi) { use_multi = false; use_general = true; } }
       if (mode == 0 && can_wave && probe[2] > 0) {
         const int64_t stride = std::max<int64_t>(1, n_buckets / probe_buckets), sampled = ceil_div(n_buckets, stride);
-        if (probe[0] * 16 <= sampled) { use_wave = true; try_fast = false; }
-        // the sampled buckets overflowed the 704-slot table within ~1100 keys: (nearly) every key is new — if the fast
-        // kernel refuses such keys for the repeats among them, the workgroup table would overflow too, and the general
-        // kernel is the one left (random 21-mers: 125 instead of 188 ms by way of the cascade)
-        nearly_distinct = probe[0] > 0 && probe[3] < 1100 * probe[0];
+        if (getenv("BNPK_FINISH_DEBUG"))
+          fprintf(stderr, "bnpk finish probe: sampled %lld bad %lld distinct(good) %lld keys %lld shown(bad) %lld\n", (long long)sampled,
+                  (long long)probe[0], (long long)probe[1], (long long)probe[2], (long long)probe[3]);
+        // (nearly) all sampled buckets fit the wavefront's table: duplicate-heavy keys.  The wavefront kernel pays while a
+        // bucket's distinct keys fill a small part of its 704 slots; above ~150 of them the probe sequences grow and the
+        // workgroup table alone is faster (round 6, reads of a genome, 5.7 K keys per bucket, scripts/exp/exp_finish_rules.sh:
+        // 20x coverage = 358 distinct per bucket: cascade 72-83 ms, workgroup table 22; 40x = 180: 22-25 / 17.6; 60x = 120:
+        // 12.7-14.5 / 16.3; 100x = 72: 10.3-11.8 / 15.3)
+        if (probe[0] * 16 <= sampled) {
+          try_fast = false;
+          if (probe[1] <= 150 * (sampled - probe[0])) use_wave = true; else use_dup = true;
+        }
+        // the sampled buckets overflowed the table's list of 448 distinct keys, and how many keys they had shown by then (in steps
+        // of 256: 559 on average when all are distinct) says how often keys repeat.  The multiplicity kernel's time grows with
+        // the repeats, the workgroup table's falls with them; they cross at 4x coverage (multi / table, ms: 1x 46 / 167, 3x 55 / 73,
+        // 4x 59 / 61, 5x 62 / 44, 8x 71 / 33; shown: 602, 674, 710, 728, 810) — round 5's threshold of 1100 sent everything up
+        // to 8x to the multiplicity kernel
+        nearly_distinct = probe[0] > 0 && probe[3] < 720 * probe[0];
       }
     }
     if (try_fast) {
