@@ -113,7 +113,7 @@ def test_the_planners_on_random_key_distributions(ops):
     from bionumpy_amd._native import lib
     from bionumpy_amd.device import Device, HArray
     dev = Device.get()
-    rng = np.random.default_rng(20260929)
+    rng = np.random.default_rng(int(os.environ.get("BNPK_FUZZ_SEED", "20260929")))
 
     def keys_of(n, bits, shape):
         top = 1 << bits
@@ -130,15 +130,27 @@ def test_the_planners_on_random_key_distributions(ops):
             k[rng.random(n) < 0.05] = hot[1]
         elif shape == 4:                                      # the top bits shared: everything in a 2^-12 slice of the range
             k = (rng.integers(0, top, dtype=np.int64) & ~((top >> 12) - 1 if top >> 12 else 0)) | rng.integers(0, max(top >> 12, 1), size=n, dtype=np.int64)
-        else:                                                 # every key ~20 times
+        elif shape == 5:                                      # every key ~20 times
             k = rng.integers(0, top, size=max(n // 20, 1), dtype=np.int64)[rng.integers(0, max(n // 20, 1), size=n)]
+        else:                                                 # many hitters that differ in their TOP bits only, each with neighbours
+            k = rng.integers(0, top, size=n, dtype=np.int64)  # (the index's words drop the top bits: equal words in different buckets)
+            h = int(rng.choice([2, 20, 300]))
+            low_bits = max(bits - 12, 1)
+            low = int(rng.integers(0, 1 << low_bits))
+            tops = rng.choice(1 << (bits - low_bits), size=min(h, 1 << (bits - low_bits)), replace=False).astype(np.int64)
+            hot = (tops << low_bits) | low
+            share = rng.integers(0, hot.size, size=n)
+            pick = rng.random(n)
+            k = np.where(pick < 0.5, hot[share], k)
+            near = (pick >= 0.5) & (pick < 0.51)
+            k = np.where(near, hot[share] ^ rng.integers(0, 1 << min(low_bits, 12), size=n), k)
         return k.astype(np.int64)
 
     t0, rounds = time.time(), 0
     while rounds < 3 or time.time() - t0 < BOX:
         n = int(rng.choice([1, 7, 3000, 70_000, 1_300_000, 4_000_000]))
         bits = int(rng.choice([20, 33, 50, 62]))
-        shape = int(rng.integers(0, 6))
+        shape = int(rng.integers(0, 7))
         claim, direct = int(rng.integers(0, 2)), int(rng.integers(0, 2))
         keys = keys_of(n, bits, shape)
         tag = (n, bits, shape, claim, direct, rounds)
