@@ -21,6 +21,7 @@ rm -rf gpurun_out/sq/pmc1 gpurun_out/sq/pmc2
 timeout 900 python scripts/bench_configs.py 50000000 > $R/configs.json 2> $R/configs.err
 timeout 600 python scripts/exp/exp_reference_loop.py 8000000 31 2>/dev/null | tail -1 > $R/reference_loop.json
 timeout 300 python bench.py --virtual-ranks 8 --reads 16000000 --steps 1 --warmup 1 --mode genome 2>/dev/null | tail -1 > $R/virtual8_genome.json
+timeout 900 bash scripts/exp/exp_finish_rules.sh "1 2 3 4 5 6 8 12 20 30 40 60 100" "0" > $R/coverage_scan.txt 2>&1; tail -3 $R/coverage_scan.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $R/smoke.log 2>&1; tail -1 $R/smoke.log
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep "passed\|failed\|error" | tail -3 > $R/gpu_tests.txt; cat $R/gpu_tests.txt
 du -sh gpurun_out/r06
