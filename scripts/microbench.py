@@ -14,7 +14,10 @@ ops = get_ops(); dev = Device.get()
 if os.environ.get("MB_L1_RING"):                     # (round 6 experiment: the fixed-line form of the fused first level)
     from bionumpy_amd._native import lib
     assert lib.bnpk_set_option(dev.ctx, b"l1_ring", int(os.environ["MB_L1_RING"])) == 0
-text = ops.synth_fastq(reads, 150, 20260925, mode, 100_000_000, 0)
+if os.environ.get("MB_FINISH_MODE"):                # (force a finishing path: include/bnpk.h "finish_mode")
+    from bionumpy_amd._native import lib
+    assert lib.bnpk_set_option(dev.ctx, b"finish_mode", int(os.environ["MB_FINISH_MODE"])) == 0
+text = ops.synth_fastq(reads, 150, 20260925, mode, int(os.environ.get("MB_GENOME_LEN", "100000000")), 0)
 h, st = fastq_kmer_histogram(text, k); del h
 torch.cuda.synchronize()
 dev.prof_enable(True); dev.prof_reset()
