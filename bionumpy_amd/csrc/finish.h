@@ -59,3 +59,5 @@ int bnpk_finish_multi_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t*
 int bnpk_finish_bitonic_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* bucket_off, int64_t n_buckets, unsigned long long* header,
                                int64_t* Dv, int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
                                const int64_t* big_counts, int64_t pstride, hipStream_t s);
+int bnpk_finish_bitonic_probe_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets,
+                                     int64_t probe_buckets, unsigned long long* header, int64_t pstride, hipStream_t s);

@@ -1273,11 +1273,9 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
           try_fast = false;
           if (probe[1] <= 150 * (sampled - probe[0])) use_wave = true; else use_dup = true;
         }
-        // the sampled buckets overflowed the table's list of 448 distinct keys, and how many keys they had shown by then (in steps
-        // of 256: 559 on average when all are distinct) says how often keys repeat.  The multiplicity kernel's time grows with
-        // the repeats, the workgroup table's falls with them; they cross at 4x coverage (multi / table, ms: 1x 46 / 167, 3x 55 / 73,
-        // 4x 59 / 61, 5x 62 / 44, 8x 71 / 33; shown: 602, 674, 710, 728, 810) — round 5's threshold of 1100 sent everything up
-        // to 8x to the multiplicity kernel
+        // (only if the whole-bucket probe below finds no bucket to sort: the sampled buckets overflowed the table's list of 448
+        // distinct keys, and how many keys they had shown by then — 559 on average when all are distinct, 710 / 728 on reads at 4x /
+        // 5x coverage — says how often keys repeat, as long as the copies of a key arrive spread out)
         nearly_distinct = probe[0] > 0 && probe[3] < 720 * probe[0];
       }
     }
@@ -1317,7 +1315,25 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
     if (!try_fast && !use_general && !use_dup && !use_wave && !use_multi && !use_bitonic) {
       // the fast kernel refused (repeats in more than FF_LOG buckets) or could not be tried
       if (mode == 2) use_general = true;
-      else if (mode == 0 && nearly_distinct && host[FS_MISFIT] == 0) use_multi = true;
+      else if (mode == 0 && host[FS_MISFIT] == 0) {
+        // Keys that repeat in full-size buckets: the multiplicity kernel (its time grows with the longest run of equal keys)
+        // or the workgroup table (its time grows with the bucket's distinct keys: the table's load).  On reads of a genome
+        // they cross where a bucket holds ~1450 distinct keys — 4x-5x coverage at 5.7 K keys per bucket; DESIGN 4c has the
+        // scan — and (k-mer, row) words of which a third occur twice (2500 distinct of 3800) belong to the multiplicity kernel
+        // at half the table's time.  What the wavefront probe saw (the first few hundred keys of a bucket) says how many
+        // distinct keys the whole bucket holds only if the copies of a key arrive spread out, so 256 buckets are sorted
+        // whole (finish_small.hip in probe mode: ~50 us, one more answer from the device; not on the headline's path).
+        bnpk_timer t_probe2(ctx, "finish.probe", s);
+        BNPK_HIP(ctx, hipMemsetAsync(d_state, 0, (size_t)FS_FAST * 8, s));
+        BNPK_CHECK(bnpk_finish_bitonic_probe_launch(ctx, part, d_bucket_offsets, n_buckets, 256, state, pstride, s));
+        int64_t whole[3] = {0, 0, 0};                     // buckets sorted, their distinct keys, their keys
+        BNPK_HIP(ctx, hipMemcpyAsync(whole, d_state + FS_PROBE_BAD, sizeof(whole), hipMemcpyDeviceToHost, s));
+        BNPK_HIP(ctx, hipStreamSynchronize(s));
+        if (getenv("BNPK_FINISH_DEBUG"))
+          fprintf(stderr, "bnpk finish probe (whole buckets): %lld sorted, %lld distinct of %lld keys\n", (long long)whole[0],
+                  (long long)whole[1], (long long)whole[2]);
+        if (whole[0] > 0 ? whole[1] > 1450 * whole[0] : nearly_distinct) use_multi = true; else use_dup = true;
+      }
       else use_dup = true;
     }
     if (use_multi) {

@@ -30,10 +30,15 @@ __device__ __forceinline__ int64_t fb_uniform(int64_t v) {
   return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// PROBE (mode 0 of bnpk_finish_sorted, full-size buckets whose keys repeat): every probe_stride-th bucket is sorted and NOTHING is
+// written but header[FS_PROBE_BAD] += 1, [FS_PROBE_DISTINCT] += its distinct keys, [FS_PROBE_KEYS] += its keys
+// — the exact number the choice between the multiplicity kernel and the workgroup table depends on (the wavefront probe sees the first few hundred keys of a bucket: what they say about the rest
+// depends on the order the keys arrived in).  Buckets over the capacity are skipped.
+template <bool PROBE>
 __global__ __launch_bounds__(FB_THREADS) void finish_bitonic_kernel(
     uint64_t* __restrict__ A, const int64_t* __restrict__ bucket_off, int64_t n_buckets, unsigned long long* __restrict__ header,
     int64_t* __restrict__ Dv, int64_t* __restrict__ loose_counts, const int64_t* __restrict__ big_table, int n_big,
-    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, int64_t pstride) {
+    const uint64_t* __restrict__ big_keys, const int64_t* __restrict__ big_counts, int64_t pstride, int64_t probe_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint64_t* stage = reinterpret_cast<uint64_t*>(smem);
   unsigned short* heads = reinterpret_cast<unsigned short*>(smem + FB_OFF_HEADS);
@@ -47,11 +52,12 @@ __global__ __launch_bounds__(FB_THREADS) void finish_bitonic_kernel(
     __syncthreads();                                         // everybody is done with the previous bucket — and with its ticket:
     if (tid == 0) ticket[0] = (unsigned)atomicAdd(&header[FS_TICKET], 1ull);   // (a branch without a barrier of its own would otherwise
     __syncthreads();                                         //  race with this write: a wavefront still looking at the old ticket)
-    const int64_t b = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)ticket[0]);
+    const int64_t b = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)ticket[0]) * (PROBE ? probe_stride : 1);
     if (b >= n_buckets) break;
     const int64_t lo = fb_uniform(bucket_off[b]);
     const int64_t size = fb_uniform(bucket_off[b + 1]) - lo;
     const int64_t src = pstride ? b * pstride : lo;
+    if (PROBE && (size < 2 || size > FB_CAP)) continue;
     if (size == 0) {
       if (tid == 0) Dv[b] = 0;
       continue;
@@ -116,6 +122,14 @@ __global__ __launch_bounds__(FB_THREADS) void finish_bitonic_kernel(
       D += s;
     }
     __syncthreads();                                         // (the totals lie where the last head positions go)
+    if (PROBE) {
+      if (tid == 0) {
+        atomicAdd(&header[FS_PROBE_BAD], 1ull);
+        atomicAdd(&header[FS_PROBE_DISTINCT], (unsigned long long)D);
+        atomicAdd(&header[FS_PROBE_KEYS], (unsigned long long)nb);
+      }
+      continue;
+    }
     uint64_t* ko = A + src;
     for (int u = 0; u < per; ++u) {
       const int i = first + u;
@@ -138,12 +152,30 @@ int bnpk_finish_bitonic_launch(bnpk_ctx* ctx, uint64_t* part, const int64_t* buc
                                int64_t* Dv, int64_t* loose_counts, const int64_t* big_table, int n_big, const uint64_t* big_keys,
                                const int64_t* big_counts, int64_t pstride, hipStream_t s) {
   if (!ctx->finish_small_ready) {
-    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_bitonic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_bitonic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_bitonic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
     ctx->finish_small_ready = true;
   }
   const unsigned grid = (unsigned)std::min<int64_t>(n_buckets, (int64_t)ctx->compute_units * 2);
-  hipLaunchKernelGGL(finish_bitonic_kernel, dim3(grid), dim3(FB_THREADS), FB_LDS, s, part, bucket_off, n_buckets, header, Dv, loose_counts,
-                     big_table, n_big, big_keys, big_counts, pstride);
+  hipLaunchKernelGGL(finish_bitonic_kernel<false>, dim3(grid), dim3(FB_THREADS), FB_LDS, s, part, bucket_off, n_buckets, header, Dv, loose_counts,
+                     big_table, n_big, big_keys, big_counts, pstride, (int64_t)1);
+  BNPK_HIP(ctx, hipGetLastError());
+  return BNPK_OK;
+}
+
+// ~`probe_buckets` evenly spaced buckets sorted, nothing written but the header's probe words (zeroed by the caller, the ticket too)
+int bnpk_finish_bitonic_probe_launch(bnpk_ctx* ctx, const uint64_t* part, const int64_t* bucket_off, int64_t n_buckets,
+                                     int64_t probe_buckets, unsigned long long* header, int64_t pstride, hipStream_t s) {
+  if (!ctx->finish_small_ready) {
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_bitonic_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+    BNPK_HIP(ctx, hipFuncSetAttribute((const void*)finish_bitonic_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS));
+    ctx->finish_small_ready = true;
+  }
+  const int64_t stride = std::max<int64_t>(1, n_buckets / probe_buckets), sampled = ceil_div(n_buckets, stride);
+  const unsigned grid = (unsigned)std::min<int64_t>(sampled, (int64_t)ctx->compute_units * 2);
+  hipLaunchKernelGGL(finish_bitonic_kernel<true>, dim3(grid), dim3(FB_THREADS), FB_LDS, s, const_cast<uint64_t*>(part), bucket_off, n_buckets, header,
+                     (int64_t*)nullptr, (int64_t*)nullptr, (const int64_t*)nullptr, 0, (const uint64_t*)nullptr, (const int64_t*)nullptr, pstride,
+                     stride);
   BNPK_HIP(ctx, hipGetLastError());
   return BNPK_OK;
 }
