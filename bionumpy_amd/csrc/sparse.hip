@@ -39,7 +39,11 @@ int nomem_at(int line, size_t used, size_t size) {
 }
 #define SP_NOMEM(arena) nomem_at(__LINE__, (arena).used, (arena).size)
 
-constexpr int64_t FINISH_TARGET = 6500;   // average bucket the plan aims for (the fast finishing kernels take 7680 keys; random keys: sigma = 80)
+// average bucket the plan aims for.  The fast finishing kernels and the claiming level's buckets take 7680 keys (7552 + the slabs'
+// leftovers); random keys spread with sigma = sqrt(7000) = 84, so 7000 leaves 6.6 sigma, and keys that repeat overflow into the
+// bag / the batch of over-full buckets as they do at any target.  (6000 until round 4, 6500 until round 6: 57 M reads x 150 bp are
+// 6.84e9 31-mers = 6523 per bucket at 20 bits, and the 21st bit cost 128 ms against 88: 2^21 half-empty buckets, no claiming level.)
+constexpr int64_t FINISH_TARGET = 7000;
 constexpr int MAX_PRECOUNTED = 1024;      // buckets over the finishing capacity that are counted in a batch of their own (round 5: 256, by the library sort)
 constexpr int64_t CLAIM_MIN_KEYS = 1ll << 20;
 

@@ -673,8 +673,7 @@ class HipOps:
         return int(n_runs.value), tile_off
 
     # -- sparse histogram: MSD radix partition (write-combining scatter) + in-LDS finishing sort -------------
-    FINISH_TARGET = 6500          # average bucket size the plan aims for (the fast finishing kernels take 7680 keys, the general one 8192;
-                                  # random keys: sigma = 80, so buckets of 6500 +- 400 fit)
+    FINISH_TARGET = 7000          # average bucket size the plan aims for (csrc/sparse.hip FINISH_TARGET: the same number, and why)
 
     @classmethod
     def radix_plan(cls, n, key_bits, done=0):
