@@ -59,7 +59,7 @@ constexpr int FM_SLOTS = FM_DEFER + 1;                   // parking slots of a w
 #define FM_UNROLL 4
 #endif
 #ifndef FM_ABL
-#define FM_ABL 0                                         // experiment builds: 1 = no look-back (bases = bucket offsets), 4 = no output stores
+#define FM_ABL 0                                         // experiment builds: 1 = no look-back (bases = bucket offsets), 4 = no output stores, 32 = walks of one step
 #endif
 #ifndef FM_LB
 #define FM_LB 2                                          // status words per lane in flight: a poll covers 64 * 8 * FM_LB buckets
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
         }
         t_walk = __builtin_amdgcn_readfirstlane((int)longs) - 1;
         short_bins = t_walk < FM_NEAR;
+        if (FM_ABL & 32) t_walk = min(t_walk, 1);          // (experiment: what the neighbour walks cost — wrong results)
 #pragma unroll
         for (int j = 0; j < FM_SCAN_DW; ++j) {
           const unsigned w = t1 * dwl + j;
