@@ -61,6 +61,9 @@ constexpr int FM_SLOTS = FM_DEFER + 1;                   // parking slots of a w
 #ifndef FM_ABL
 #define FM_ABL 0                                         // experiment builds: 1 = no look-back (bases = bucket offsets), 4 = no output stores, 32 = walks of one step
 #endif
+#ifndef FM_GROUP_WALK
+#define FM_GROUP_WALK 1                                  // the neighbour walks of a group of chunks go as far as ITS longest bin (0: the bucket's)
+#endif
 #ifndef FM_LB
 #define FM_LB 2                                          // status words per lane in flight: a poll covers 64 * 8 * FM_LB buckets
 #endif
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
       lb_take();
       emit_begin(pref_v);
       bool short_bins;
-      int t_walk;
+      int t_bucket;                                        // the bucket's longest bin - 1
       {
         unsigned c[FM_SCAN_DW], sum = 0, longest = 0;
         const unsigned t1 = (unsigned)fm_fresh(tid);
@@ -438,9 +441,9 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
           run += w < wave ? wsum[w] : 0u;
           longs = max(longs, wsum[2 * FM_WAVES + w]);
         }
-        t_walk = __builtin_amdgcn_readfirstlane((int)longs) - 1;
-        short_bins = t_walk < FM_NEAR;
-        if (FM_ABL & 32) t_walk = min(t_walk, 1);          // (experiment: what the neighbour walks cost — wrong results)
+        t_bucket = __builtin_amdgcn_readfirstlane((int)longs) - 1;
+        short_bins = t_bucket < FM_NEAR;
+        if (FM_ABL & 32) t_bucket = min(t_bucket, 1);      // (experiment: what the neighbour walks cost — wrong results)
 #pragma unroll
         for (int j = 0; j < FM_SCAN_DW; ++j) {
           const unsigned w = t1 * dwl + j;
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
       const int slice0 = wave * FM_SLICE;
       now.kind = 1;
       if (short_bins) {
-        for (unsigned i = (unsigned)fm_fresh(tid); i <= n_dw; i += FM_THREADS) P32[i] = 0;
+        if (!FM_GROUP_WALK)
+          for (unsigned i = (unsigned)fm_fresh(tid); i <= n_dw; i += FM_THREADS) P32[i] = 0;
         uint64_t* pk = mypark + cur_slot * FM_PARK + FM_NEAR;
         unsigned* dc = dupc + cur_slot * FM_WAVES;
         if (tid == 0) pk[nb] = ~0ull;                    // the sentinel behind the bucket
@@ -496,6 +500,20 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
             const uint64_t* mid = stage + sl0;
 #pragma unroll
             for (int u = 0; u < FM_WG; ++u) { x[u] = mid[64 * u]; cnt[u] = 0; eq[u] = 0; }
+            // how far THIS group's keys can reach: the longest bin among its 192 slots' bins, not the bucket's longest.  On reads at
+            // 3x coverage the bucket's longest bin holds ~14 keys (a k-mer that occurs ten times and its bin mates), a group's ~9
+            // (NOTES round 6): two 16-bit reads per slot and one wave reduction for five steps less of the walk below.
+            int t_walk = t_bucket;
+            if (FM_GROUP_WALK) {
+              unsigned len = 0;
+#pragma unroll
+              for (int u = 0; u < FM_WG; ++u) {
+                const unsigned bin = (unsigned)(x[u] >> sshift) & (SB - 1);
+                const unsigned l = (unsigned)P16[bin + 1] - (unsigned)P16[bin];
+                len = max(len, sl0 + 64 * u < nb ? l : 1u);
+              }
+              t_walk = min(t_bucket, __builtin_amdgcn_readfirstlane((int)wave_max(len)) - 1);
+            }
 #pragma unroll FM_UNROLL
             for (int d = 1; d <= t_walk; ++d) {
               uint64_t y[FM_WG], z[FM_WG];
@@ -549,7 +567,7 @@ __global__ __launch_bounds__(FM_THREADS, 4) void finish_multi_kernel(
       dups = (unsigned)__builtin_amdgcn_readfirstlane((int)dups);
       now.D = (unsigned)nb - dups;
       if (tid == 0) publish(b, now.D);
-      if (!short_bins) {
+      if (!short_bins || FM_GROUP_WALK) {                  // (the walks read the bins until barrier 5)
         for (unsigned i = (unsigned)fm_fresh(tid); i <= n_dw; i += FM_THREADS) P32[i] = 0;
         __syncthreads();
       }
