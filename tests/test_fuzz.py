@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 BOX = float(os.environ.get("BNPK_FUZZ_SECONDS", 20.0))
+SEED = int(os.environ.get("BNPK_FUZZ_SEED", "0"))             # 0: the suite's own sequences; anything else: other ones
 
 
 @pytest.fixture(scope="module")
@@ -26,7 +27,7 @@ def ops():
 
 def _rounds(ops, seed, make_cases, least=2):
     import test_gpu_parity as T
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(seed + SEED)
     t0, n = time.time(), 0
     while n < least or time.time() - t0 < BOX:
         for f, args in make_cases(T, rng):
@@ -90,7 +91,7 @@ def test_fastq_decode_fast_kernels_against_the_general_ones(ops):
         except Exception as e:                                      # noqa: BLE001
             return ("error", type(e).__name__, str(e), getattr(e, "line_number", None), getattr(e, "offset", None))
 
-    t0, seed, n = time.time(), 5_000_000, 0
+    t0, seed, n = time.time(), 5_000_000 + 1000 * SEED, 0
     try:
         while n < 50 or time.time() - t0 < BOX:
             buf, lpe, seq_line, check_plus = random_text(np.random.default_rng(seed))
@@ -113,7 +114,7 @@ def test_the_planners_on_random_key_distributions(ops):
     from bionumpy_amd._native import lib
     from bionumpy_amd.device import Device, HArray
     dev = Device.get()
-    rng = np.random.default_rng(int(os.environ.get("BNPK_FUZZ_SEED", "20260929")))
+    rng = np.random.default_rng(20260929 + SEED)
 
     def keys_of(n, bits, shape):
         top = 1 << bits
