@@ -960,8 +960,13 @@ __global__ __launch_bounds__(FF_THREADS, 4) void finish_fast_kernel(
 // or if the stray writes of such a bucket reached into its region.
 __global__ void finish_check_kernel(const int64_t* __restrict__ T, const unsigned* __restrict__ meta,
                                     const int64_t* __restrict__ bucket_off, const int64_t* __restrict__ out_off,
-                                    int64_t n_buckets, unsigned* __restrict__ marks) {
+                                    int64_t n_buckets, unsigned* __restrict__ marks, const unsigned long long* __restrict__ header) {
   BNPK_VGPR_FLOOR_32();                                   // (24 VGPRs otherwise: see common.h)
+  // The fast kernel gave up (keys that repeat: every real read set): most distinct counts were never written, T is the scan of
+  // whatever the memory held, and the walk over "every bucket the stray writes touched" below can then run over a million
+  // buckets per thread — 145 ms on the first call of a process, over fresh memory (rocprofv3, round 6: the maximum of finish_check
+  // in profiles/r06_k21_kernel_stats.txt); later calls found the previous call's counts there and were quick, by luck.
+  if (header[FS_FLAGS] & 4ull) return;
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; b < n_buckets; b += stride) {
@@ -985,6 +990,7 @@ __global__ void finish_check_kernel(const int64_t* __restrict__ T, const unsigne
 __global__ void finish_collect_kernel(const int64_t* __restrict__ T, const unsigned* __restrict__ marks, int64_t n_buckets,
                                       unsigned long long* __restrict__ header, unsigned* __restrict__ redo_ids,
                                       int64_t* __restrict__ redo_bases) {
+  if (header[FS_FLAGS] & 4ull) return;                    // (the fast kernel gave up: nothing here is looked at)
   int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   if (b == 0) header[FS_UNIQUE] = (unsigned long long)T[n_buckets];
@@ -1304,7 +1310,7 @@ int bnpk_finish_sorted_strided(bnpk_ctx* ctx, int64_t* d_part, int64_t n, int64_
       BNPK_CHECK(bnpk_scan_launch(ctx, Dv, n_buckets, 1, Dv, true, (int64_t*)scan_scratch, s));
       const unsigned cgrid = grid_for(std::min<int64_t>(ceil_div(n_buckets, 256), 2048));
       hipLaunchKernelGGL(finish_check_kernel, dim3(cgrid), dim3(256), 0, s, (const int64_t*)Dv, (const unsigned*)meta,
-                         d_bucket_offsets, out_off, n_buckets, marks);
+                         d_bucket_offsets, out_off, n_buckets, marks, (const unsigned long long*)state);
       hipLaunchKernelGGL(finish_collect_kernel, dim3(cgrid), dim3(256), 0, s, (const int64_t*)Dv, (const unsigned*)marks,
                          n_buckets, state, redo_ids, redo_bases);
       BNPK_HIP(ctx, hipGetLastError());

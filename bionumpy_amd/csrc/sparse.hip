@@ -431,6 +431,10 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
       fits = true;
       break;
     }
+    // (never more buckets than half the keys: levels cannot split EQUAL keys, and two 8-bit levels over a batch whose keys differ
+    // in their last bits only — one k-mer in a thousand rows — asked for 2^25 buckets' offsets and state for 1.4 M keys: found
+    // by tests/test_fuzz.py as a workspace that was too small)
+    while (bits > 0 && (n_seg << bits) > std::max<int64_t>(n / 2, 1 << 12)) --bits;
     if (attempt == 2 || bits <= 0) break;                // too many heavy buckets: the full sort below
     int64_t* out = spare ? spare : arena.words(n);
     int64_t* child = arena.words((n_seg << bits) + 1);

@@ -171,6 +171,10 @@ def test_the_planners_on_random_key_distributions(ops):
                 detail = [(int(j), hex(int(gk[j])), int(gr[j]), int(gm[j]), hex(int(want[0][j])), int(want[1][j]), int(mult[j])) for j in bad[:3]]
                 raise AssertionError(("unique_pairs", tag, n_rows, "pairs got / want", gk.size, want.shape[1], "occurrences", int(gm.sum()), n,
                                       "mismatches", int(bad.size), detail))
+        except AssertionError:
+            raise
+        except Exception as e:                                # noqa: BLE001  (a status from the library: say which input it was)
+            raise AssertionError(("the library raised", tag, locals().get("n_rows"), repr(e))) from e
         finally:
             lib.bnpk_set_option(dev.ctx, b"sparse_claim", 1)
             lib.bnpk_set_option(dev.ctx, b"index_pairs", 1)
