@@ -648,7 +648,7 @@ int bnpk_index_build(bnpk_ctx* ctx, const int64_t* d_kmers, const int64_t* d_row
       // (segments = the first level's buckets, none of the word's bits resolved inside them; planned per segment)
       const int st = count_sparse_impl(ctx, words, n, word_bits, 0, std::max<int64_t>(n >> t, 1), child, 0, arena, wout, counts, &m, info, s, 0,
                                        1ll << t, true);
-      if (st != SP_NEEDS_KEYS) {
+      if (st != SP_NEEDS_KEYS && st != BNPK_ERR_NOMEM) {     // (no room for this construction: the other one has its own budget)
         BNPK_CHECK(st);
         {
           bnpk_timer tm(ctx, "index_decode", s);

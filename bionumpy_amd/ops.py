@@ -885,12 +885,17 @@ class HipOps:
         if n_values is None:
             n_values = int(v.max().item()) + 1
         work_bytes = int(lib.bnpk_index_build_workspace(n, key_bits, n_values))
-        space = self._empty(work_bytes, np.uint8)
         keys_out, vals_out = self._empty(n, np.int64), self._empty(n, np.int64)
         counts = self._empty(n, np.int64) if with_counts else None
         m = C.c_int64(0)
-        status = lib.bnpk_index_build(self.ctx, ptr(t), ptr(v), n, key_bits, n_values, ptr(space), work_bytes, ptr(keys_out), ptr(vals_out),
-                                      ptr(counts), C.byref(m), self._s())
+        for attempt in range(2):                             # (the inputs are left alone: a workspace that was too small is asked for again, larger)
+            space = self._empty(work_bytes, np.uint8)
+            status = lib.bnpk_index_build(self.ctx, ptr(t), ptr(v), n, key_bits, n_values, ptr(space), work_bytes, ptr(keys_out),
+                                          ptr(vals_out), ptr(counts), C.byref(m), self._s())
+            del space
+            if status != -4:                                 # BNPK_ERR_NOMEM
+                break
+            work_bytes *= 3
         if status == -6:                                     # BNPK_ERR_RANGE: distinct keys x values over 62 bits
             raise NotImplementedError("index too large: %d pairs x %d rows" % (n, n_values))
         self._chk(status)
