@@ -315,3 +315,30 @@ def test_index_build_is_one_call(env):
             assert np.array_equal(oc[:m.value].cpu().numpy(), mult), (name, direct)
         assert lib.bnpk_set_option(dev.ctx, b"index_pairs", 1) == 0
         assert np.array_equal(d_k.cpu().numpy(), kmers) and np.array_equal(d_r.cpu().numpy(), rows)      # the inputs are left alone
+
+
+@pytest.mark.parametrize("copies,path", [(2, "finish.multi"), (8, "finish.dup"), (64, "finish.cascade")])
+def test_mode_0_takes_the_path_the_coverage_scan_found(env, copies, path):
+    """40 M keys, every value `copies` times, in 8192 buckets of 4.9 K keys: 2440 / 610 / 76 distinct keys per bucket.  The rules of
+    bnpk_finish_sorted's mode 0 (csrc/finish.hip; DESIGN 4c has the scan they come from): over 1450 distinct keys per bucket (counted on
+    256 buckets sorted whole) the multiplicity kernel, under it the workgroup table, and the cascade with the wavefront table first only
+    while a bucket holds at most 150 — read from the library's timers; and np.unique's answer whichever it takes"""
+    ops, lib, dev, ptr, torch = env
+    from bionumpy_amd.device import HArray
+    rng = np.random.default_rng(copies)
+    n = 40_000_000
+    values = rng.integers(0, 1 << 62, size=n // copies, dtype=np.int64)
+    keys = rng.permutation(np.repeat(values, copies))
+    assert lib.bnpk_set_option(dev.ctx, b"finish_mode", 0) == 0
+    dev.prof_enable(True)
+    dev.prof_reset()
+    try:
+        gk, gc = ops.count_sparse(HArray(host=keys), key_bits=62)
+        torch.cuda.synchronize()
+        report = dev.prof_report()
+    finally:
+        dev.prof_enable(False)
+    taken = sorted(k for k in report if k.startswith("finish.") and k not in ("finish.probe", "finish.fast"))
+    assert path in taken and not (set(taken) & ({"finish.multi", "finish.dup", "finish.cascade"} - {path})), (copies, taken)
+    ek, ec = np.unique(values, return_counts=True)
+    assert np.array_equal(gk.host(), ek) and np.array_equal(gc.host(), ec * copies)
