@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 BOX = float(os.environ.get("BNPK_FUZZ_SECONDS", 20.0))
+SIZES = [int(x) for x in os.environ.get("BNPK_FUZZ_SIZES", "1,7,3000,70000,1300000,4000000").split(",")]   # (the planners' fuzzer)
 SEED = int(os.environ.get("BNPK_FUZZ_SEED", "0"))             # 0: the suite's own sequences; anything else: other ones
 
 
@@ -149,7 +150,7 @@ def test_the_planners_on_random_key_distributions(ops):
 
     t0, rounds = time.time(), 0
     while rounds < 3 or time.time() - t0 < BOX:
-        n = int(rng.choice([1, 7, 3000, 70_000, 1_300_000, 4_000_000]))
+        n = int(rng.choice(SIZES))
         bits = int(rng.choice([20, 33, 50, 62]))
         shape = int(rng.integers(0, 7))
         claim, direct = int(rng.integers(0, 2)), int(rng.integers(0, 2))
