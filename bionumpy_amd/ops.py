@@ -873,10 +873,11 @@ class HipOps:
 
     def unique_pairs(self, keys, values, key_bits=62, n_values=None, with_counts=False):
         """sorted distinct (key, value) pairs, values in [0, n_values) — KmerIndex.create_index
-        (bionumpy/sequence/indexing/kmer_indexing.py:24-47) as ONE call of bnpk_index_build: no key-value sort, the pairs are
-        the distinct values of id = rank(key) * n_values + value, rank = position among the sorted distinct keys — two runs
-        of the sparse counting path around a rank kernel (csrc/sparse.hip; round 5 sorted (k-mer, row) with the library's
-        radix_sort_pairs for indices under 2^26 pairs)."""
+        (bionumpy/sequence/indexing/kmer_indexing.py:24-47) as ONE call of bnpk_index_build (csrc/sparse.hip): up to 1024
+        values ONE partition of (key's low bits : value : tag) words behind a first level over the key's top bits; more values
+        (or option "index_pairs" 0, or words that only a sort of everything could count) the distinct values of
+        id = rank(key) * n_values + value — two runs of the sparse counting path around a rank kernel.  No library sort on
+        either way (round 5 sorted (k-mer, row) with rocprim's radix_sort_pairs for indices under 2^26 pairs)."""
         t, v = keys.dev(), values.dev()
         n = t.numel()
         if n == 0:
