@@ -375,7 +375,10 @@ int count_sparse_impl(bnpk_ctx* ctx, int64_t* d_keys, int64_t n, int key_bits, i
   }
   int plan[8];
   const int n_levels = radix_plan(n_plan > 0 ? n_plan : n, kb, done, plan);
-  const bool may_claim = ctx->sparse_claim != 0;
+  // (the claiming level is for the caller's keys.  What a recursion counts — the bag of a claiming level, a batch of over-full
+  // buckets — is what did NOT spread evenly: on deep coverage of a small genome the bag's own claiming attempt overflowed in turn,
+  // 20 ms for nothing before the plain level ran — round 6)
+  const bool may_claim = ctx->sparse_claim != 0 && depth == 0;
   for (int level = 0; level < n_levels; ++level) {
     const int bits = plan[level];
     const int shift = kb - done - bits;
